@@ -1,0 +1,500 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE's own Python functions.
+
+Run in the build container only (``python tests/golden/make_golden.py``); /root/reference does not exist on
+the GPU box and nothing in tests/, bench.py or __graft_entry__.py reads it.  Only data (inputs, expected
+outputs) is written -- never reference source text.
+
+How the reference is imported: ``cell_type_annotation/__init__.py`` is empty, so its modules are loaded as
+the synthetic package ``refcta`` whose ``__path__`` is that directory (this bypasses the napari-widget import
+of the parent package, which fails with an ordinary ModuleNotFoundError: magicgui).  Third-party modules
+that are not installed get thin stand-ins registered in ``sys.modules`` first:
+
+* ``skimage.{io,morphology,filters,transform}`` -> oracle/skimage_like.py (scipy.ndimage-backed restatement)
+* ``timm.models.vision_transformer``            -> tests/golden/timm_like.py (plain-torch restatement)
+* ``tifffile``, ``seaborn``, ``umap``           -> empty modules (plot/IO helpers, never called here)
+
+Consequently: fixtures whose arithmetic is pure reference + numpy/scipy/torch (normalize, cell positions,
+crop window/padding/channel-select control flow, parser, vote, CSV) pin the oracle to the reference; the
+soft-mask filters and the ViT forward additionally pass through the restated third-party semantics.
+"""
+from __future__ import annotations
+
+import hashlib
+import importlib
+import json
+import os
+import shutil
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+REF = "/root/reference"
+CTA = os.path.join(REF, "src/multiplexed_image_annotator/cell_type_annotation")
+
+from multiplexed_image_annotator_amd import synth  # noqa: E402
+from oracle import skimage_like  # noqa: E402
+import timm_like  # noqa: E402
+
+
+def install_shims():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    def imread(path):
+        if str(path).endswith(".npy"):
+            return np.load(path)
+        from PIL import Image
+        return np.array(Image.open(path))
+
+    sk = mod("skimage")
+    sk.io = mod("skimage.io", imread=imread)
+    sk.morphology = mod("skimage.morphology", dilation=skimage_like.dilation, disk=skimage_like.disk)
+    sk.filters = mod("skimage.filters", gaussian=skimage_like.gaussian)
+    sk.transform = mod("skimage.transform", resize=skimage_like.resize)
+    mod("tifffile", imwrite=lambda *a, **k: None)
+    mod("seaborn")
+    mod("umap")
+    tm = mod("timm")
+    tm.models = mod("timm.models")
+    tm.models.vision_transformer = mod("timm.models.vision_transformer", VisionTransformer=timm_like.VisionTransformer,
+                                       PatchEmbed=timm_like.PatchEmbed, Block=timm_like.Block)
+    import matplotlib
+    matplotlib.use("Agg")
+    pkg = types.ModuleType("refcta")
+    pkg.__path__ = [CTA]
+    sys.modules["refcta"] = pkg
+
+
+def ref(name):
+    return importlib.import_module("refcta." + name)
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+class _Log:
+    def log(self, *_a, **_k):
+        pass
+
+    def log_all_hyperparameters(self, *_a, **_k):
+        pass
+
+
+# ---------------------------------------------------------------------------------------------- G1
+def small_raw_tile(c, h, w, seed):
+    """uint16 test tile: synthetic cells plus deliberately degenerate channels."""
+    _, img = synth.make_mask_and_image(h, w, max(4, (h * w) // 500), c, seed)
+    return img.numpy().astype(np.uint16)
+
+
+def golden_normalize():
+    pre = ref("preprocess")
+    dummy = object.__new__(pre.ImageProcessor)
+    out = {}
+    tile = small_raw_tile(4, 96, 112, synth.SEED_BASE + 101)
+    tile[2] = 0                       # no positive pixel after background subtraction -> all -1
+    tile[3] = (tile[3] % 23)          # dim channel: percentile <= 20 and max < 25 branches
+    out["a_in"] = tile
+    for blur in (0, 0.3, 0.5, 1):
+        out[f"a_out_blur{blur}"] = pre.ImageProcessor._normalize(dummy, tile.copy(), blur=blur, amax=99.8)
+    out["a_out_amax100"] = pre.ImageProcessor._normalize(dummy, tile.copy(), blur=0, amax=100)
+    tile2 = small_raw_tile(3, 200, 168, synth.SEED_BASE + 102)   # larger than the sigma=20 radius (80) in both axes
+    out["b_in"] = tile2
+    out["b_out_blur0.3"] = pre.ImageProcessor._normalize(dummy, tile2.copy(), blur=0.3, amax=99.8)
+    tile3 = small_raw_tile(2, 40, 56, synth.SEED_BASE + 103)     # smaller than the filter radius: multiple reflections
+    out["c_in"] = tile3
+    out["c_out_blur0"] = pre.ImageProcessor._normalize(dummy, tile3.copy(), blur=0, amax=99.8)
+    np.savez_compressed(os.path.join(HERE, "normalize.npz"), **out)
+    print("normalize.npz", {k: v.shape for k, v in out.items()})
+
+
+# ---------------------------------------------------------------------------------------------- G2
+def odd_mask():
+    """Hand-built mask: border-touching cells, a >40 px cell, 1-px cells, non-contiguous ids, a cell in two pieces."""
+    m = np.zeros((90, 120), np.int32)
+    m[0:5, 0:7] = 3            # top-left corner
+    m[85:90, 110:120] = 7      # bottom-right corner
+    m[0:3, 50:60] = 12         # top edge
+    m[40:50, 0:4] = 500        # left edge, id gap
+    m[20:75, 30:95] = 65000    # 55 x 65 px: larger than the 40 px window
+    m[30:40, 40:50] = 41       # cell nested inside the big one
+    m[10, 100] = 9             # single pixel
+    m[89, 0] = 10              # single pixel in the bottom-left corner
+    m[60:63, 100:103] = 77     # two disjoint pieces of one id
+    m[70:72, 112:118] = 77
+    m[5:12, 110:120] = 100000  # right edge, id above uint16
+    return m
+
+
+def table_from_dict(d):
+    ids = np.array(list(d.keys()), np.int64)
+    tab = np.array([[min(r), max(r), min(c), max(c), sum(r), sum(c), len(r)] for r, c in d.values()], np.int64)
+    return ids, tab
+
+
+def golden_cellpos():
+    pre = ref("preprocess")
+    dummy = object.__new__(pre.ImageProcessor)
+    out = {}
+    m = odd_mask()
+    d = pre.ImageProcessor._cell_pos_dict(dummy, m, n_jobs=0)
+    out["odd_mask"] = m
+    out["odd_ids"], out["odd_table"] = table_from_dict(d)
+    out["odd_first_rows"] = np.array(d[77][0], np.int64)   # scan-order check for the two-piece cell
+    out["odd_first_cols"] = np.array(d[77][1], np.int64)
+    from PIL import Image
+    ex = np.array(Image.open(os.path.join(REF, "examples/example_2_cell_mask.png"))).astype(np.int32)
+    d2 = pre.ImageProcessor._cell_pos_dict(dummy, ex, n_jobs=0)
+    out["example2_mask"] = ex.astype(np.uint16)
+    out["example2_ids"], out["example2_table"] = table_from_dict(d2)
+    ms, _ = synth.make_mask_and_image(160, 200, 60, 1, synth.SEED_BASE + 111, want_image=False)
+    d3 = pre.ImageProcessor._cell_pos_dict(dummy, ms.numpy(), n_jobs=0)
+    out["synth_ids"], out["synth_table"] = table_from_dict(d3)
+    np.savez_compressed(os.path.join(HERE, "cellpos.npz"), **out)
+    print("cellpos.npz", len(d), len(d2), len(d3))
+
+
+# ---------------------------------------------------------------------------------------------- G3
+def golden_patches():
+    pre = ref("preprocess")
+    utils = ref("utils")
+    dummy = object.__new__(pre.ImageProcessor)
+    dummy.scale = 1.0
+    out = {}
+    # case A: the hand-built mask with a 7-channel normalised image
+    m = odd_mask()
+    raw = small_raw_tile(7, 90, 120, synth.SEED_BASE + 121)
+    img = pre.ImageProcessor._normalize(dummy, raw, blur=0.3, amax=99.8)
+    d = pre.ImageProcessor._cell_pos_dict(dummy, m, n_jobs=0)
+    tmp = tempfile.mkdtemp()
+    cases = {
+        "all7": [0, 1, 2, 3, 4, 5, 6],
+        "perm": [4, 2, 6, 0, 1, 5, 3],
+        "one_missing": [0, 1, -1, 3, 4, 5, 6],
+        "two_missing": [0, -1, 2, 3, -1, 5, 6],      # second -1 aliases the last image channel
+        "three": [6, 0, 2],
+    }
+    out["A_raw"] = raw
+    out["A_image"] = img
+    out["A_mask"] = m
+    for name, idx in cases.items():
+        inten = pre.ImageProcessor._img2patches(dummy, img, m, idx, d, None, id="g_" + name, save_path=tmp, save_tensor=True,
+                                                int_full=True)
+        out[f"A_{name}_index"] = np.array(idx, np.int64)
+        out[f"A_{name}_patches"] = torch.load(os.path.join(tmp, f"g_{name}_batch_0.pt")).numpy()
+        out[f"A_{name}_intensity"] = inten
+    # soft mask alone for three cells (fp32)
+    lab = np.zeros((40, 40))
+    lab[:40, :40] = m[20:60, 30:70]
+    out["A_smooth_big"] = utils.smooth(lab, 65000)
+    out["A_smooth_nested"] = utils.smooth(lab, 41)
+    # case B: un-normalised uint16 image (normalization=False path: integer arithmetic in _move_image_range)
+    ms, raw2 = synth.make_mask_and_image(96, 96, 16, 3, synth.SEED_BASE + 122)
+    ms = ms.numpy()
+    raw2 = raw2.numpy().astype(np.uint16)
+    d2 = pre.ImageProcessor._cell_pos_dict(dummy, ms, n_jobs=0)
+    inten = pre.ImageProcessor._img2patches(dummy, raw2, ms, [2, 0, 1], d2, None, id="g_raw", save_path=tmp, save_tensor=True, int_full=True)
+    out["B_raw"] = raw2
+    out["B_mask"] = ms
+    out["B_patches"] = torch.load(os.path.join(tmp, "g_raw_batch_0.pt")).numpy()
+    out["B_intensity"] = inten
+    shutil.rmtree(tmp)
+    np.savez_compressed(os.path.join(HERE, "patches.npz"), **out)
+    print("patches.npz", {k: v.shape for k, v in out.items() if k.endswith("patches")})
+
+
+# ---------------------------------------------------------------------------------------------- G4
+PARSER_CASES = {
+    "basic7": ['CD45', 'CD20', 'CD4', 'CD8', 'DAPI', 'CD11c', 'CD3'],
+    "extended10": ['DAPI', 'CD3', 'CD4', 'CD8', 'CD11c', 'CD20', 'CD45', 'CD68', 'CD163', 'CD56'],
+    "full15": list(synth.FULL_PANEL_MARKERS),
+    "full_1_missing": [m for m in synth.FULL_PANEL_MARKERS if m != 'Trypase'] + ['CollagenIV'],
+    "full_2_missing": [m for m in synth.FULL_PANEL_MARKERS if m not in ('Trypase', 'CD15')],
+    "full_3_missing": [m for m in synth.FULL_PANEL_MARKERS if m not in ('Trypase', 'CD15', 'FoxP3')],
+    "full_4_missing": [m for m in synth.FULL_PANEL_MARKERS if m not in ('Trypase', 'CD15', 'FoxP3', 'CD138')],
+    "examples_markers": None,  # the reference's examples/markers.txt
+    "aliases": ['DNA', 'CD3e', 'CD4', 'CD8', 'CD11c', 'CD79', 'CD45', 'CK', 'SMActin', 'CD31', 'Vimentin', 'Ki67'],
+    "alias_truncated": ['DNA', 'CD3', 'CD4', 'CD8', 'CK', 'aSMA', 'CD31', 'Ki67', 'CD45', 'CD20', 'Vim'],
+    "alias_blocked": ['DNA', 'DAPI', 'CD45', 'GFAP'],
+    "nerve": ['DAPI', 'CD45', 'GFAP', 'X'],
+    "struct_one_missing": ['DAPI', 'aSMA', 'CD31', 'PanCK', 'Vimentin', 'CD45', 'Extra'],
+    "nothing": ['A', 'B', 'C'],
+    "e2e12": ['CD45', 'CD20', 'CD4', 'CD8', 'DAPI', 'CD11c', 'CD3', 'aSMA', 'CD31', 'PanCK', 'Vimentin', 'Ki67'],
+}
+
+
+def golden_parser():
+    mp = ref("markerParse")
+    res = {}
+    tmp = tempfile.mkdtemp()
+    for name, markers in PARSER_CASES.items():
+        if markers is None:
+            path = os.path.join(REF, "examples/markers.txt")
+            with open(path) as f:
+                markers = [ln.strip() for ln in f if ln.strip()]
+        path = os.path.join(tmp, name + ".txt")
+        with open(path, "w") as f:
+            f.write("\n".join(markers) + "\n")
+        for strict in (True, False):
+            p = mp.MarkerParser(strict=strict, logger=_Log())
+            p.parse(path)
+            res[f"{name}|{'strict' if strict else 'loose'}"] = {
+                "markers_in": markers,
+                "markers": [str(m) for m in p.markers],
+                "indices": {k: (None if v is None else [int(i) for i in v]) for k, v in p.indices.items()},
+                "flags": [bool(p.immune_base), bool(p.immune_extended), bool(p.immune_full), bool(p.struct), bool(p.nerve)],
+            }
+    shutil.rmtree(tmp)
+    with open(os.path.join(HERE, "parser_cases.json"), "w") as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+    print("parser_cases.json", len(res))
+
+
+# ---------------------------------------------------------------------------------------------- G5
+ALL_TYPES = ["B cell", "CD4 T cell", "CD8 T cell", "Dendritic cell", "Regulatory T cell", "Granulocyte cell", "Mast cell",
+             "M1 macrophage cell", "M2 macrophage cell", "Natural killer cell", "Plasma cell", "Endothelial cell",
+             "Epithelial cell", "Stroma cell", "Smooth muscle", "Proliferating/tumor cell", "Nerve cell", "Others"]
+MODEL_CLASSES = {"immune_full": 12, "immune_extended": 8, "immune_base": 5, "struct": 6, "nerve": 2}
+
+
+def seeded_probs(model, n, seed, sharp=3.0):
+    k = MODEL_CLASSES[model]
+    z = synth.approx_normal(synth.stream_key(seed, "vote/" + model), n * k).reshape(n, k).to(torch.float32) * sharp
+    p = torch.softmax(z, dim=1).numpy()
+    # force exact ties and near-threshold rows
+    p[0, :] = np.float32(1.0 / k)
+    if k >= 3:
+        p[1, 0] = p[1, 1] = np.float32(0.4)
+        p[1, 2:] = np.float32(0.2 / (k - 2))
+    return p.astype(np.float32)
+
+
+def golden_vote():
+    model = ref("model")
+    n = 64
+    out = {}
+    meta = {}
+    type_conf_json = json.load(open(os.path.join(REF, "hyperparameters.json")))["cell_type_confidence"]
+    per_type_b = dict(type_conf_json)
+    per_type_b["CD4 T cell"] = 0.5
+    per_type_b["Epithelial cell"] = 0.0
+    per_type_b["Nerve cell"] = 0.9
+    combos = [
+        ("b2_full_struct", "immune_full", True, False),
+        ("b2_ext_struct", "immune_extended", True, False),
+        ("b2_base_struct_nerve", "immune_base", True, True),   # nerve ignored by branch 2
+        ("b3_struct_nerve", None, True, True),
+        ("b4_base_nerve", "immune_base", False, True),
+        ("b4_full_nerve", "immune_full", False, True),
+        ("b5_full", "immune_full", False, False),
+        ("b5_ext", "immune_extended", False, False),
+        ("b5_base", "immune_base", False, False),
+        ("b6_struct", None, True, False),
+        ("b7_nerve", None, False, True),
+    ]
+    settings = [("default", 0.25, None), ("conf03", 0.3, None), ("json", 0.3, type_conf_json), ("mixed", 0.3, per_type_b)]
+    for ci, (cname, immune, use_s, use_n) in enumerate(combos):
+        tables = {}
+        if immune:
+            tables[immune] = seeded_probs(immune, n, 1000 + ci)
+        if use_s:
+            tables["struct"] = seeded_probs("struct", n, 2000 + ci)
+        if use_n:
+            tables["nerve"] = seeded_probs("nerve", n, 3000 + ci)
+        for k, v in tables.items():
+            out[f"{cname}__p_{k}"] = v
+        for sname, conf, tconf in settings:
+            a = object.__new__(model.Annotator)
+            a.immune_full_pred, a.struct_pred, a.nerve_pred = [], [], []
+            a.immune_annotations, a.struct_annotations, a.nerve_annotations = [], [], []
+            a.annotations, a.confidence = [], []
+            a.confidence_thresh = conf
+            a.extra_cell_types = False
+            a.cell_type_confidence = tconf if tconf is not None else {k: -1 for k in ALL_TYPES}
+            names = {"immune_full": ["CD4 T cell", "CD8 T cell", "Dendritic cell", "B cell", "M1 macrophage cell", "M2 macrophage cell",
+                                     "Regulatory T cell", "Granulocyte cell", "Plasma cell", "Natural killer cell", "Mast cell", "Others"],
+                     "immune_extended": ["CD4 T cell", "CD8 T cell", "Dendritic cell", "B cell", "M1 macrophage cell",
+                                         "M2 macrophage cell", "Natural killer cell", "Others"],
+                     "immune_base": ["B cell", "CD4 T cell", "CD8 T cell", "Others", "Dendritic cell"],
+                     "struct": ["Stroma cell", "Smooth muscle", "Endothelial cell", "Epithelial cell", "Proliferating/tumor cell", "Others"],
+                     "nerve": ["Nerve cell", "Others"]}
+
+            def dicts(m):
+                return [{names[m][i]: row[i] for i in range(len(row))} for row in tables[m]]
+            if immune:
+                a.immune_annotations.append(dicts(immune))
+                if immune == "immune_full":
+                    a.immune_full_pred.append(a.immune_annotations[0])
+            if use_s:
+                a.struct_annotations.append(dicts("struct"))
+                a.struct_pred.append(a.struct_annotations[0])
+            if use_n:
+                a.nerve_annotations.append(dicts("nerve"))
+                a.nerve_pred.append(a.nerve_annotations[0])
+            a.merge_by_voting()
+            labels = a.annotations[0]
+            confs = a.confidence[0]
+            key = f"{cname}__{sname}"
+            meta[key] = {"immune": immune, "struct": use_s, "nerve": use_n, "conf": conf, "type_conf": tconf, "labels": labels,
+                         "conf_is_int": [isinstance(c, int) for c in confs]}
+            out[key + "__conf"] = np.array([np.float32(c) for c in confs], np.float32)
+            # predict() tail + CSV through the reference's own methods
+            a.cell_types = a._get_unique_cell_types()
+            a.cell_types = np.delete(a.cell_types, np.where(a.cell_types == "Others"))
+            a.cell_types = np.append(a.cell_types, "Others")
+            meta[key]["cell_types"] = [str(s) for s in a.cell_types]
+            if sname in ("default", "mixed"):
+                pos = {}
+                for j in range(n):
+                    rows = [j, j + 1, j + 3, (7 * j) % 13]
+                    cols = [2 * j, 2 * j + 1, 5, (11 * j) % 17]
+                    pos[100 + 3 * j] = (rows, cols)
+                a.preprocessor = types.SimpleNamespace(cell_pos_dict=[pos])
+                tmp = tempfile.mkdtemp()
+                a.result_dir = tmp
+                a.batch_id = "g"
+                a.logger = _Log()
+                a.export_annotations()
+                meta[key]["csv"] = open(os.path.join(tmp, "g_annotation_0.csv")).read()
+                shutil.rmtree(tmp)
+    # branch 1 raises KeyError('Others')
+    a = object.__new__(model.Annotator)
+    a.annotations, a.confidence = [], []
+    a.confidence_thresh = 0.25
+    a.extra_cell_types = False
+    a.cell_type_confidence = {k: -1 for k in ["CD4 T cell", "Others"]}
+    one = [{"CD4 T cell": np.float32(0.6), "Others": np.float32(0.4)}]
+    a.immune_full_pred = [one]
+    a.struct_pred = [[{"Stroma cell": np.float32(0.5), "Others": np.float32(0.5)}]]
+    a.nerve_pred = [[{"Nerve cell": np.float32(0.5), "Others": np.float32(0.5)}]]
+    try:
+        a.merge_by_voting()
+        meta["branch1"] = "no error"
+    except KeyError as e:
+        meta["branch1"] = "KeyError:" + str(e.args[0])
+    np.savez_compressed(os.path.join(HERE, "vote_cases.npz"), **out)
+    with open(os.path.join(HERE, "vote_cases.json"), "w") as f:
+        json.dump(meta, f, indent=0, sort_keys=True)
+    print("vote_cases", len(meta), meta["branch1"])
+
+
+# ---------------------------------------------------------------------------------------------- G7
+def vit_inputs(model_name, n, seed):
+    d, c, k = synth.VIT_CONFIGS[model_name]
+    u = synth.uniform(synth.stream_key(seed, "vitx/" + model_name), n * c * 1600).reshape(n, c, 40, 40).to(torch.float32)
+    x = u * 2 - 1
+    return torch.where(x > 0.1, x, torch.full_like(x, -1.0))
+
+
+def build_ref_model(model_mod, name):
+    d, c, k = synth.VIT_CONFIGS[name]
+    fac = {"nerve": model_mod.vit_tiny, "immune_base": model_mod.vit_s, "struct": model_mod.vit_s,
+           "immune_extended": model_mod.vit_m, "immune_full": model_mod.vit_l}[name]
+    return fac(img_size=40, in_chans=c, num_classes=k, drop_path_rate=0.1, global_pool=False)
+
+
+def golden_vit():
+    model = ref("model")
+    out = {}
+    for name in synth.VIT_CONFIGS:
+        sd = synth.make_vit_state_dict(name, synth.SEED_BASE + 7)
+        m = build_ref_model(model, name)
+        m.load_state_dict(sd)
+        m.eval()
+        x = vit_inputs(name, 8, synth.SEED_BASE + 7)
+        with torch.no_grad():
+            lg = m(x)
+            pr = torch.nn.functional.softmax(lg, dim=1)
+        out[name + "_logits"] = lg.numpy()
+        out[name + "_probs"] = pr.numpy()
+        out[name + "_x_sha"] = np.frombuffer(bytes.fromhex(sha(x.numpy())), np.uint8)
+    np.savez_compressed(os.path.join(HERE, "vit_logits.npz"), **out)
+    print("vit_logits.npz ok")
+
+
+# ---------------------------------------------------------------------------------------------- G8
+def golden_e2e():
+    """Whole reference Annotator (preprocess -> predict -> export_annotations) on small synthetic tiles with seeded weights."""
+    model = ref("model")
+    cases = {
+        # name: (markers, H, W, cells, seed, strict, blur, amax, conf, models needed)
+        "two_model": (PARSER_CASES["e2e12"], 176, 208, 56, synth.SEED_BASE + 201, False, 0.3, 99.8, 0.3, ["immune_base", "struct"]),
+        "basic": (PARSER_CASES["basic7"], 160, 160, 40, synth.SEED_BASE + 202, True, 0.3, 99.8, 0.3, ["immune_base"]),
+    }
+    meta = {}
+    out = {}
+    cwd = os.getcwd()
+    for cname, (markers, h, w, cells, seed, strict, blur, amax, conf, models) in cases.items():
+        tmp = tempfile.mkdtemp()
+        os.chdir(tmp)
+        mdir = "src/multiplexed_image_annotator/cell_type_annotation/models"
+        os.makedirs(mdir)
+        for m in models:
+            torch.save({"model": synth.make_vit_state_dict(m, seed)}, os.path.join(mdir, m + ".pth"))
+        mask, img = synth.make_mask_and_image(h, w, cells, len(markers), seed)
+        np.save("img.npy", img.numpy().astype(np.uint16))
+        np.save("mask.npy", mask.numpy().astype(np.int32))
+        with open("markers.txt", "w") as f:
+            f.write("\n".join(markers) + "\n")
+        with open("images.csv", "w") as f:
+            f.write("image_path,mask_path\nimg.npy,mask.npy\n")
+        a = model.Annotator("markers.txt", "images.csv", "cpu", "./", "g", strict, False, -1, True, blur, amax, conf, 30, None, n_jobs=0)
+        a.preprocess()
+        # centre each model's logits on this tile (stored with the fixture) so labels spread over classes
+        tensor_name = {"immune_base": "immune_base", "struct": "structure"}
+        for m in models:
+            sd = synth.make_vit_state_dict(m, seed)
+            net = build_ref_model(model, m)
+            net.load_state_dict(sd)
+            net.eval()
+            x = torch.load(os.path.join("tmp", f"g_0_{tensor_name[m]}_batch_0.pt"))
+            with torch.no_grad():
+                feats = net.forward_features(x)
+            sd["head.bias"] = synth.calibrate_head_bias(sd, feats)
+            out[cname + "__head_bias_" + m] = sd["head.bias"].numpy()
+            torch.save({"model": sd}, os.path.join(mdir, m + ".pth"))
+        a.predict(8)
+        a.export_annotations()
+        a.logger.close()
+        meta[cname] = {"markers": markers, "h": h, "w": w, "cells": cells, "seed": seed, "strict": strict, "blur": blur, "amax": amax,
+                       "conf": conf, "models": models, "labels": list(a.annotations[0]), "cell_types": [str(s) for s in a.cell_types],
+                       "csv": open("results/g_annotation_0.csv").read(),
+                       "type_ints": [int(r["Cell type"]) for r in a.annotations_all[0]],
+                       "cell_ids": [int(r["Cell ID"]) for r in a.annotations_all[0]],
+                       "img_sha": sha(img.numpy().astype(np.uint16)), "mask_sha": sha(mask.numpy().astype(np.int32))}
+        out[cname + "__conf"] = np.array([np.float32(c) for c in a.confidence[0]], np.float32)
+        out[cname + "__intensity"] = a.preprocessor.intensity_full[0]
+        names = {"immune_base": ["B cell", "CD4 T cell", "CD8 T cell", "Others", "Dendritic cell"],
+                 "struct": ["Stroma cell", "Smooth muscle", "Endothelial cell", "Epithelial cell", "Proliferating/tumor cell", "Others"]}
+        if "immune_base" in models:
+            out[cname + "__p_immune_base"] = np.array([[d[k] for k in names["immune_base"]] for d in a.immune_base_pred[0]], np.float32)
+        if "struct" in models:
+            out[cname + "__p_struct"] = np.array([[d[k] for k in names["struct"]] for d in a.struct_pred[0]], np.float32)
+        os.chdir(cwd)
+        shutil.rmtree(tmp)
+    np.savez_compressed(os.path.join(HERE, "e2e.npz"), **out)
+    with open(os.path.join(HERE, "e2e.json"), "w") as f:
+        json.dump(meta, f, indent=0, sort_keys=True)
+    print("e2e", {k: len(v["labels"]) for k, v in meta.items()})
+
+
+if __name__ == "__main__":
+    install_shims()
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["normalize", "cellpos", "patches", "parser", "vote", "vit", "e2e"]
+    for w in which:
+        globals()["golden_" + w]()

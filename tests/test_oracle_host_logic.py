@@ -1,0 +1,100 @@
+"""Oracle parser / vote / CSV restatements vs goldens from the reference's own MarkerParser and Annotator methods."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ref_parser, ref_vote
+
+
+@pytest.fixture(scope="module")
+def parser_cases(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "parser_cases.json")))
+
+
+def test_parser_cases(parser_cases, tmp_path):
+    assert len(parser_cases) >= 30
+    for key, case in parser_cases.items():
+        name, mode = key.split("|")
+        f = tmp_path / (name + ".txt")
+        f.write_text("\n".join(case["markers_in"]) + "\n")
+        got = ref_parser.parse_marker_file(str(f), strict=(mode == "strict"))
+        assert got["indices"] == case["indices"], key
+        assert [got["immune_base"], got["immune_extended"], got["immune_full"], got["struct"], got["nerve"]] == case["flags"], key
+        assert got["markers"] == case["markers"], key
+
+
+def test_parser_known_answers(parser_cases):
+    assert parser_cases["full15|strict"]["indices"]["immune_full"] == list(range(15))
+    assert parser_cases["full15|strict"]["flags"] == [True, True, True, False, False]
+    assert parser_cases["full_1_missing|loose"]["indices"]["immune_full"] == list(range(14)) + [-1]
+    assert parser_cases["full_1_missing|strict"]["indices"]["immune_full"] is None
+    assert parser_cases["full_4_missing|loose"]["indices"]["immune_full"] is None
+    # 'CK' -> 'PanCK' is truncated to the file's widest name (fixed-width numpy strings): structure panel lost
+    assert parser_cases["alias_truncated|loose"]["indices"]["structure"] is None
+    assert parser_cases["aliases|loose"]["indices"]["structure"] is not None
+
+
+@pytest.fixture(scope="module")
+def vote_cases(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "vote_cases.json"))), np.load(os.path.join(golden_dir, "vote_cases.npz"))
+
+
+def _run_case(meta, arrs, key):
+    m = meta[key]
+    cname = key.split("__")[0]
+    immune = ref_vote.probs_to_dicts(m["immune"], arrs[f"{cname}__p_{m['immune']}"]) if m["immune"] else None
+    struct = ref_vote.probs_to_dicts("struct", arrs[f"{cname}__p_struct"]) if m["struct"] else None
+    nerve = ref_vote.probs_to_dicts("nerve", arrs[f"{cname}__p_nerve"]) if m["nerve"] else None
+    return ref_vote.merge_by_voting(immune, m["immune"], struct, nerve, m["conf"], m["type_conf"])
+
+
+def test_vote_all_branches(vote_cases):
+    meta, arrs = vote_cases
+    keys = [k for k in meta if k != "branch1"]
+    assert len(keys) == 44
+    for key in keys:
+        labels, confs = _run_case(meta, arrs, key)
+        assert labels == meta[key]["labels"], key
+        assert [isinstance(c, int) for c in confs] == meta[key]["conf_is_int"], key
+        np.testing.assert_array_equal(np.array([np.float32(c) for c in confs]), arrs[key + "__conf"])
+        assert [str(s) for s in ref_vote.unique_cell_types([labels])] == meta[key]["cell_types"], key
+
+
+def test_vote_csv_bytes(vote_cases):
+    meta, arrs = vote_cases
+    n = 64
+    ids = [100 + 3 * j for j in range(n)]
+    rows = [[j, j + 1, j + 3, (7 * j) % 13] for j in range(n)]
+    cols = [[2 * j, 2 * j + 1, 5, (11 * j) % 17] for j in range(n)]
+    checked = 0
+    for key in meta:
+        if key == "branch1" or "csv" not in meta[key]:
+            continue
+        labels, confs = _run_case(meta, arrs, key)
+        csv = ref_vote.annotation_csv(ids, labels, confs, [sum(r) for r in rows], [sum(c) for c in cols], [4] * n)
+        assert csv == meta[key]["csv"], key
+        checked += 1
+    assert checked == 22
+
+
+def test_vote_branch1_raises(vote_cases):
+    meta, _ = vote_cases
+    assert meta["branch1"] == "KeyError:Others"
+    one = [{"CD4 T cell": np.float32(0.6), "Others": np.float32(0.4)}]
+    with pytest.raises(KeyError):
+        ref_vote.merge_by_voting(one, "immune_full", one, one)
+    with pytest.raises(ValueError):
+        ref_vote.merge_by_voting(None, None, None, None)
+
+
+def test_vote_tie_break_order(vote_cases):
+    meta, arrs = vote_cases
+    # row 0 is uniform (1/K < threshold -> Others, -1); row 1 has an exact tie p0 == p1 == 0.4:
+    # single model: first class index wins; two models: first key in the void-vote order wins
+    assert meta["b5_base__default"]["labels"][0] == "Others" and meta["b5_base__default"]["conf_is_int"][0]
+    assert meta["b5_base__default"]["labels"][1] == "B cell"
+    assert meta["b2_full_struct__default"]["labels"][1] == "CD4 T cell"
+    # row 0, two models: all struct classes tie at 1/6 > 1/12 -> first struct key in vote order
+    assert meta["b2_full_struct__default"]["labels"][0] == "Stroma cell"
