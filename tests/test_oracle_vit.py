@@ -44,22 +44,29 @@ def test_vit_matches_hf_implementation():
          "vit.embeddings.patch_embeddings.projection.bias": sd["patch_embed.proj.bias"],
          "vit.layernorm.weight": sd["norm.weight"], "vit.layernorm.bias": sd["norm.bias"],
          "classifier.weight": sd["head.weight"], "classifier.bias": sd["head.bias"]}
+    have = set(hf.state_dict().keys())
+    new_names = "vit.layers.0.attention.q_proj.weight" in have      # transformers >= 5 naming
     for i in range(3):
-        p, q = f"blocks.{i}.", f"vit.encoder.layer.{i}."
+        p = f"blocks.{i}."
+        q = f"vit.layers.{i}." if new_names else f"vit.encoder.layer.{i}."
         w, b = sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]
-        for j, nm in enumerate(("query", "key", "value")):
-            m[q + f"attention.attention.{nm}.weight"] = w[j * d:(j + 1) * d]
-            m[q + f"attention.attention.{nm}.bias"] = b[j * d:(j + 1) * d]
-        m[q + "attention.output.dense.weight"] = sd[p + "attn.proj.weight"]
-        m[q + "attention.output.dense.bias"] = sd[p + "attn.proj.bias"]
+        for j, nm in enumerate(("q_proj", "k_proj", "v_proj") if new_names else ("query", "key", "value")):
+            pre = q + (f"attention.{nm}." if new_names else f"attention.attention.{nm}.")
+            m[pre + "weight"] = w[j * d:(j + 1) * d]
+            m[pre + "bias"] = b[j * d:(j + 1) * d]
+        o = q + ("attention.o_proj." if new_names else "attention.output.dense.")
+        m[o + "weight"] = sd[p + "attn.proj.weight"]
+        m[o + "bias"] = sd[p + "attn.proj.bias"]
         m[q + "layernorm_before.weight"] = sd[p + "norm1.weight"]
         m[q + "layernorm_before.bias"] = sd[p + "norm1.bias"]
         m[q + "layernorm_after.weight"] = sd[p + "norm2.weight"]
         m[q + "layernorm_after.bias"] = sd[p + "norm2.bias"]
-        m[q + "intermediate.dense.weight"] = sd[p + "mlp.fc1.weight"]
-        m[q + "intermediate.dense.bias"] = sd[p + "mlp.fc1.bias"]
-        m[q + "output.dense.weight"] = sd[p + "mlp.fc2.weight"]
-        m[q + "output.dense.bias"] = sd[p + "mlp.fc2.bias"]
+        f1 = q + ("mlp.fc1." if new_names else "intermediate.dense.")
+        f2 = q + ("mlp.fc2." if new_names else "output.dense.")
+        m[f1 + "weight"] = sd[p + "mlp.fc1.weight"]
+        m[f1 + "bias"] = sd[p + "mlp.fc1.bias"]
+        m[f2 + "weight"] = sd[p + "mlp.fc2.weight"]
+        m[f2 + "bias"] = sd[p + "mlp.fc2.bias"]
     missing, unexpected = hf.load_state_dict(m, strict=False)
     assert not unexpected and all("pooler" in k for k in missing), (missing, unexpected)
     x = vit_inputs(name, 4, 3)
