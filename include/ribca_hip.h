@@ -1,0 +1,110 @@
+/* libribca_hip.so -- C ABI of the MI355X-native RIBCA hot path (gfx950 only).
+ *
+ * The reference (sun-huangqingbo/multiplexed-image-annotator) is pure Python and has no FFI: its compute boundary is a
+ * set of Python methods.  Each entry point below replaces the body of one of them; the Python host in
+ * multiplexed-image-annotator_amd/ binds these symbols with ctypes and keeps the reference's class/method surface
+ * (INTEGRATION.md shows the stub a maintainer would add to the reference).  Paths cited are relative to
+ * src/multiplexed_image_annotator/cell_type_annotation/ of the reference.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named *_host; sizes are element counts unless named *_bytes;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work and return;
+ *   - the caller owns all memory; only ribca_vit_create allocates (the packed-weight handle);
+ *   - return value 0 = ok, non-zero = error, text via ribca_last_error() (thread-local).
+ */
+#ifndef RIBCA_HIP_H
+#define RIBCA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ribca_vit ribca_vit_t;
+
+int ribca_version(void);
+const char* ribca_last_error(void);
+
+/* ---- pre-processing ------------------------------------------------------------------------------------------ */
+
+/* out2[0] = max(mask), out2[1] = min(mask).  Sizes the label table (preprocess.py:159-181 builds a dict instead). */
+int ribca_mask_minmax(const int32_t* mask, int64_t n, int32_t* out2, void* stream);
+
+/* Replaces ImageProcessor._cell_pos_dict (preprocess.py:159-211) for everything the hot path reads from it.
+ * L = max label + 1.  tab_i32 = [5][L]: row min, row max, col min, col max, pixel count (count 0 = label absent);
+ * tab_u64 = [2][L]: sum of rows, sum of cols.  Label 0 (background) is skipped; labels must be in [1, L). */
+int ribca_label_table(const int32_t* mask, int32_t H, int32_t W, int32_t L, int32_t* tab_i32, uint64_t* tab_u64, void* stream);
+
+/* Replaces ImageProcessor._move_image_range (preprocess.py:153-157): per-channel minimum of an fp32 (C, H*W) image. */
+int ribca_channel_min(const float* image, int32_t C, int64_t hw, float* out_min, void* stream);
+
+/* Replaces utils.crop_cell + utils.smooth (utils.py:226-270) for patch_size 40 (cell_size 30): for each of n cells writes
+ * the soft-masked fp32 patch of EVERY image channel, (n, C, 40, 40), bit-identical to the reference arithmetic, and
+ * optionally avg (n, C) fp64 = mean over labelled pixels of the window (reference avg_int, before the (x+1)/2 of
+ * preprocess.py:145-149).  bbox = (n, 4) int32 rmin, rmax, cmin, cmax from the label table.  taps = 27 fp64 Gaussian
+ * weights: sigma 1 -> taps[0..4], sigma 2 -> taps[5..13], sigma 3 -> taps[14..26], entry k = weight at distance k
+ * (host computes them exactly as scipy.ndimage._gaussian_kernel1d does). */
+int ribca_extract_patches(const float* image, int32_t C, int32_t H, int32_t W, const int32_t* mask, const float* chan_min,
+                          const int32_t* cell_id, const int32_t* bbox, const double* taps, int32_t n, float* patches, double* avg,
+                          void* stream);
+
+/* ---- ViT classifier (timm VisionTransformer subclass, model.py:31-88) -------------------------------------- */
+
+/* Number of fp32 values in the flat parameter blob ribca_vit_create expects, in this order:
+ *   cls_token[D], pos_embed[101*D], patch_embed.proj.weight[D*C*16], patch_embed.proj.bias[D],
+ *   per block: norm1.weight[D], norm1.bias[D], attn.qkv.weight[3D*D], attn.qkv.bias[3D], attn.proj.weight[D*D],
+ *              attn.proj.bias[D], norm2.weight[D], norm2.bias[D], mlp.fc1.weight[4D*D], mlp.fc1.bias[4D],
+ *              mlp.fc2.weight[D*4D], mlp.fc2.bias[D],
+ *   norm.weight[D], norm.bias[D], head.weight[K*D], head.bias[K]
+ * (the state-dict key order of the checkpoints Annotator.load_models reads, model.py:188-239). */
+int64_t ribca_vit_blob_len(int32_t D, int32_t C, int32_t K, int32_t depth);
+
+/* Replaces Annotator.load_models for one model: repacks the fp32 parameters (device blob) into the MFMA layouts.
+ * D % 48 == 0 (12 heads, head dim % 4 == 0), D <= 768, K <= 16. */
+int ribca_vit_create(const float* blob, int64_t blob_len, int32_t D, int32_t C, int32_t K, int32_t depth, void* stream,
+                     ribca_vit_t** out);
+void ribca_vit_destroy(ribca_vit_t* m);
+
+/* Scratch bytes ribca_vit_forward needs to process `chunk_cells` cells at a time. */
+int64_t ribca_vit_workspace_bytes(const ribca_vit_t* m, int32_t chunk_cells);
+
+/* Replaces the body of Annotator._predict_cell_types' inner loop (model.py:397-406): probs = softmax(model(x), dim=1).
+ * patches: (n_cells, c_img, 40, 40) fp32 full-channel patches from ribca_extract_patches (or the imputer);
+ * src_chan: (C) int32, image channel feeding each model channel, -1 = blank plane of -1.0 (preprocess.py:110-120);
+ * probs: (n_cells, K) fp32.  Cells are processed in chunks of chunk_cells through `workspace`. */
+int ribca_vit_forward(const ribca_vit_t* m, const float* patches, int32_t c_img, const int32_t* src_chan, int32_t n_cells,
+                      float* probs, void* workspace, int64_t workspace_bytes, int32_t chunk_cells, void* stream);
+
+/* Algorithmic FLOPs per cell of this model (BASELINE.md section 3 formula). */
+double ribca_vit_flops_per_cell(const ribca_vit_t* m);
+
+/* ---- vote (Annotator.merge_by_voting, model.py:481-633) ------------------------------------------------------ */
+/* Global class ids: 0..16 = key order of utils.get_void_vote (utils.py:143-146), 17 = "Others".
+ * p_a (n, k_a) and optional p_b (n, k_b) are softmax outputs; map_* (k) int8 give each class's global id;
+ * type_conf (18) fp32 per-type thresholds (negative = unset); label (n) int8 and conf (n) fp32 (-1 = thresholded). */
+int ribca_vote(const float* p_a, int32_t k_a, const int8_t* map_a, const float* p_b, int32_t k_b, const int8_t* map_b,
+               const float* type_conf, float conf, int32_t n, int8_t* label, float* out_conf, void* stream);
+
+/* ---- profiling + kernel-level test hooks --------------------------------------------------------------------- */
+/* When enabled, every kernel launch of the ViT forward is bracketed by HIP events on its stream; ribca_prof_read
+ * synchronises and returns, per kernel class, total milliseconds and launch count since the last reset.
+ * classes: 0 gemm_qkv 1 gemm_proj 2 gemm_fc1 3 gemm_fc2 4 gemm_embed 5 attention 6 layernorm 7 im2col 8 head 9 other */
+int ribca_prof_enable(int32_t on);
+int ribca_prof_read(double* ms_out10, int64_t* count_out10);
+const char* ribca_prof_name(int32_t cls);
+
+/* Kernel-level hooks used by tests/ to localise a mismatch (same kernels the forward launches). */
+int ribca_test_pack_weight(const float* w, int32_t N, int32_t K, uint16_t* out, int32_t Np, int32_t Kp, void* stream);
+int ribca_test_layernorm(const float* z, int32_t ldz, const float* gamma, const float* beta, uint16_t* out, int32_t ldo, int32_t M,
+                         int32_t D, void* stream);
+int ribca_test_gemm(int32_t kind, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
+                    const float* bias, void* out, int32_t ldo, void* stream); /* kind 0: z += ..., 1: gelu -> PS */
+int ribca_test_qkv_attention(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t cells, int32_t D, int32_t Kp,
+                             const float* bias, uint16_t* q, uint16_t* k, uint16_t* vt, uint16_t* out, int32_t ldo, void* stream);
+int32_t ribca_gemm_padded_n(int32_t N);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RIBCA_HIP_H */

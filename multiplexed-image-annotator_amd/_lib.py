@@ -1,0 +1,93 @@
+"""ctypes binding of ``libribca_hip.so`` (C ABI in ``include/ribca_hip.h``).
+
+The product path has no CPU fallback: if the shared library is missing or a call fails this raises.
+torch is used only to own device memory and streams; raw pointers cross the boundary.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libribca_hip.so")
+
+_lib = None
+
+#: name -> (restype, argtypes); must list every function declared in include/ribca_hip.h
+SIGNATURES = {
+    "ribca_version": (c_int32, []),
+    "ribca_last_error": (c_char_p, []),
+    "ribca_mask_minmax": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "ribca_label_table": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "ribca_channel_min": (c_int32, [c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
+    "ribca_extract_patches": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                        c_void_p, c_void_p, c_void_p]),
+    "ribca_vit_blob_len": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
+    "ribca_vit_create": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, POINTER(c_void_p)]),
+    "ribca_vit_destroy": (None, [c_void_p]),
+    "ribca_vit_workspace_bytes": (c_int64, [c_void_p, c_int32]),
+    "ribca_vit_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "ribca_vit_flops_per_cell": (c_double, [c_void_p]),
+    "ribca_vote": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_float, c_int32, c_void_p, c_void_p,
+                             c_void_p]),
+    "ribca_prof_enable": (c_int32, [c_int32]),
+    "ribca_prof_read": (c_int32, [POINTER(c_double), POINTER(c_int64)]),
+    "ribca_prof_name": (c_char_p, [c_int32]),
+    "ribca_test_pack_weight": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
+    "ribca_test_layernorm": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "ribca_test_gemm": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
+                                  c_void_p]),
+    "ribca_test_qkv_attention": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_int32, c_void_p]),
+    "ribca_gemm_padded_n": (c_int32, [c_int32]),
+}
+
+
+class RibcaError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RibcaError(
+                f"{LIB_PATH} not found: build it with `python -m multiplexed_image_annotator_amd.build` "
+                "(hipcc, gfx950). There is no CPU fallback for the hot path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib().ribca_last_error()
+        raise RibcaError(f"{what} failed: {msg.decode() if msg else 'unknown error'}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (must be contiguous) or None."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise ValueError("tensor passed to the HIP library must be contiguous")
+    return t.data_ptr()
+
+
+def stream_ptr():
+    """Current torch HIP stream as an integer handle (the library enqueues on it)."""
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RibcaError("no HIP device visible: the RIBCA hot path runs only on an MI355X (gfx950); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())

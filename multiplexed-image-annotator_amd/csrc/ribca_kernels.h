@@ -1,0 +1,74 @@
+// Host-side launcher declarations shared by the translation units of libribca_hip.so.
+// Every launcher enqueues on the given stream and returns immediately (no allocation, no sync).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ribca {
+
+// ----- GEMM (gemm_bf16x3.hip): C = A * W^T with A [M][2*Kp] and W [Np][2*Kp] in packed-split bf16 ---------------
+int gemm_pick_bn(int N);            // column-tile width used for an N-wide weight (64 / 96 / 128)
+int gemm_padded_n(int N);           // N rounded up to that tile width (rows the packed weight must have)
+
+struct GemmArgs {
+  const uint16_t* A; int lda;       // activations, row stride in bf16 elements (= 2*Kp)
+  const uint16_t* W; int ldw;       // packed weight, Np rows
+  int M, N, Kp;
+  const float* bias;                // [N]
+};
+// z[m][n] += acc + bias                                   (attn.proj, mlp.fc2)
+void launch_gemm_resid(const GemmArgs& g, float* z, int ldz, hipStream_t s);
+// out_ps[m][n] = gelu(acc + bias), packed-split          (mlp.fc1)
+void launch_gemm_gelu(const GemmArgs& g, uint16_t* out, int ldo, hipStream_t s);
+// patch-embed: row m = cell*100 + t  ->  z[cell*101 + 1 + t][n] = acc + bias + pos[1+t][n]
+void launch_gemm_embed(const GemmArgs& g, float* z, int ldz, const float* pos, int D, hipStream_t s);
+// qkv: scatter into per-head attention operands (Q pre-scaled by hd^-0.5, V transposed + key-permuted)
+void launch_gemm_qkv(const GemmArgs& g, uint16_t* q, uint16_t* k, uint16_t* vt, int D, int hd, int hdp, int hdv, float scale,
+                     hipStream_t s);
+
+// ----- attention (attention.hip) ---------------------------------------------------------------------------
+// q,k: [cells][12][112][2*hdp]  vt: [cells][12][hdv][2*128]  out: packed-split [cells*101][ldo]
+void launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int ldo, int cells, int hd,
+                      int hdp, int hdv, hipStream_t s);
+
+// ----- small ViT kernels (vit_misc.hip) ----------------------------------------------------------------------
+void launch_layernorm_ps(const float* z, int ldz, const float* gamma, const float* beta, uint16_t* out, int ldo, int M, int D,
+                         hipStream_t s);
+void launch_im2col_ps(const float* patches, int c_img, const int* src_chan, int C, uint16_t* out, int ldo, int Kp, int cells,
+                      hipStream_t s);
+void launch_cls_rows(float* z, int ldz, const float* cls, const float* pos, int D, int cells, hipStream_t s);
+void launch_head_softmax(const float* z, int ldz, const float* gamma, const float* beta, const float* hw, const float* hb,
+                         float* probs, int D, int K, int cells, hipStream_t s);
+void launch_pack_weight(const float* w, int N, int K, uint16_t* out, int Np, int Kp, hipStream_t s);
+
+// ----- pre-processing (preprocess.hip) -----------------------------------------------------------------------
+void launch_mask_max(const int32_t* mask, long long n, int32_t* out_max, hipStream_t s);
+void launch_label_table_init(int32_t* tab_i32, unsigned long long* tab_u64, int L, hipStream_t s);
+void launch_label_table(const int32_t* mask, int H, int W, int L, int32_t* tab_i32, unsigned long long* tab_u64, hipStream_t s);
+void launch_channel_min(const float* img, int C, long long hw, float* out_min, hipStream_t s);
+struct PatchArgs {
+  const float* img; int C, H, W;     // normalised image (C,H,W) fp32
+  const int32_t* mask;               // (H,W)
+  const float* chan_min;             // (C)  per-channel minimum (reference _move_image_range)
+  const int32_t* cell_id;            // (n)
+  const int32_t* bbox;               // (n,4) rmin,rmax,cmin,cmax
+  const double* taps;                // Gaussian taps sigma=1,2,3: [9 + 17 + 25] doubles, centre-out order documented in .hip
+  float* patches;                    // (n, C, 40, 40)
+  double* avg_int;                   // (n, C) or nullptr
+  int n;
+};
+void launch_extract_patches(const PatchArgs& a, hipStream_t s);
+
+// ----- vote (vote.hip) -----------------------------------------------------------------------------------------
+struct VoteArgs {
+  const float* p_a; int k_a; const int8_t* map_a;   // first model: probs (n,k_a), class -> global id (17 = Others)
+  const float* p_b; int k_b; const int8_t* map_b;   // second model or nullptr
+  const float* type_conf;                           // [18] per-type thresholds (global id order), negative = unset
+  float conf;                                       // global confidence threshold
+  int n;
+  int8_t* label;                                    // out: global class id
+  float* out_conf;                                  // out: confidence, -1 when thresholded to Others
+};
+void launch_vote(const VoteArgs& a, hipStream_t s);
+
+}  // namespace ribca

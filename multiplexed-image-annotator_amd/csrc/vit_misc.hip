@@ -1,0 +1,182 @@
+// Small HBM-bound kernels of the ViT forward: LayerNorm -> packed-split, im2col of the 4x4/4 patch-embed conv,
+// CLS rows, final LayerNorm + head + softmax, and the one-off weight packer.
+// Reference semantics: timm Block.norm1/norm2 and VisionTransformer.norm are nn.LayerNorm(eps=1e-6) (model.py:66-88);
+// patch embedding is Conv2d(C, D, 4, 4) with K order (c, ky, kx) and token order py*10+px; head + softmax at model.py:402-404.
+#include "ribca_common.h"
+#include "ribca_kernels.h"
+
+namespace ribca {
+
+constexpr float kLnEps = 1e-6f;
+
+// One wave per row; D <= 768 (<= 3 float4 per lane).  Two-pass mean / biased variance in registers.
+__global__ __launch_bounds__(256) void layernorm_ps_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, uint16_t* __restrict__ out, int ldo, int M,
+                                                           int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nv = D >> 2;
+  const float4* zr = reinterpret_cast<const float4*>(z + (size_t)row * ldz);
+  float4 x[3];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int v = lane + 64 * i;
+    x[i] = v < nv ? zr[v] : float4{0.f, 0.f, 0.f, 0.f};
+    sum += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int v = lane + 64 * i;
+    if (v < nv) {
+      const float a = x[i].x - mean, b = x[i].y - mean, c = x[i].z - mean, d = x[i].w - mean;
+      sq += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + kLnEps);
+  uint16_t* orow = out + (size_t)row * ldo;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int v = lane + 64 * i;
+    if (v < nv) {
+      const float4 gm = reinterpret_cast<const float4*>(gamma)[v];
+      const float4 bt = reinterpret_cast<const float4*>(beta)[v];
+      float y[4] = {(x[i].x - mean) * rstd * gm.x + bt.x, (x[i].y - mean) * rstd * gm.y + bt.y,
+                    (x[i].z - mean) * rstd * gm.z + bt.z, (x[i].w - mean) * rstd * gm.w + bt.w};
+      ps_store4(orow, 4 * v, y);
+    }
+  }
+}
+
+void launch_layernorm_ps(const float* z, int ldz, const float* gamma, const float* beta, uint16_t* out, int ldo, int M, int D,
+                         hipStream_t s) {
+  if (M <= 0) return;
+  hipLaunchKernelGGL(layernorm_ps_kernel, dim3((M + 3) / 4), dim3(256), 0, s, z, ldz, gamma, beta, out, ldo, M, D);
+}
+
+// im2col for Conv2d(C, D, k=4, s=4) on (cells, c_img, 40, 40) fp32 patches -> rows (cell*100 + py*10 + px) of Kp columns,
+// column k = c*16 + ky*4 + kx.  src_chan[c] = image channel feeding model channel c, or -1 for a blank (-1.0) plane
+// (reference preprocess.py:110-120).  Columns >= 16*C are zero.  One thread per 4 consecutive kx.
+__global__ __launch_bounds__(256) void im2col_ps_kernel(const float* __restrict__ patches, int c_img, const int* __restrict__ src_chan,
+                                                        int C, uint16_t* __restrict__ out, int ldo, int Kp, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int kq = Kp >> 2;
+  const long long rowi = idx / kq;
+  const int q = (int)(idx - rowi * kq);  // column group: k = 4q = c*16 + ky*4
+  const int c = q >> 2, ky = q & 3;
+  const long long cell = rowi / 100;
+  const int t = (int)(rowi - cell * 100);
+  const int py = t / 10, px = t - py * 10;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    const int sc = src_chan[c];
+    if (sc < 0) {
+      v[0] = v[1] = v[2] = v[3] = -1.0f;
+    } else {
+      const float4 p = *reinterpret_cast<const float4*>(patches + (((size_t)cell * c_img + sc) * 40 + (4 * py + ky)) * 40 + 4 * px);
+      v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w;
+    }
+  }
+  ps_store4(out + (size_t)rowi * ldo, 4 * q, v);
+}
+
+void launch_im2col_ps(const float* patches, int c_img, const int* src_chan, int C, uint16_t* out, int ldo, int Kp, int cells,
+                      hipStream_t s) {
+  const long long total = (long long)cells * 100 * (Kp >> 2);
+  if (total <= 0) return;
+  hipLaunchKernelGGL(im2col_ps_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, patches, c_img, src_chan, C, out, ldo, Kp,
+                     total);
+}
+
+// z[cell*101 + 0][:] = cls_token + pos_embed[0]   (model.py:49-51)
+__global__ void cls_rows_kernel(float* __restrict__ z, int ldz, const float* __restrict__ cls, const float* __restrict__ pos, int D,
+                                int cells) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= cells * D) return;
+  const int cell = idx / D, d = idx - cell * D;
+  z[(size_t)cell * kTokens * ldz + d] = cls[d] + pos[d];
+}
+void launch_cls_rows(float* z, int ldz, const float* cls, const float* pos, int D, int cells, hipStream_t s) {
+  if (cells <= 0) return;
+  hipLaunchKernelGGL(cls_rows_kernel, dim3((cells * D + 255) / 256), dim3(256), 0, s, z, ldz, cls, pos, D, cells);
+}
+
+// final LayerNorm of the CLS row -> Linear(D, K) -> softmax(dim=1), all fp32.  One wave per cell, K <= 16.
+__global__ __launch_bounds__(256) void head_softmax_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ hw,
+                                                           const float* __restrict__ hb, float* __restrict__ probs, int D, int K,
+                                                           int cells) {
+  const int lane = threadIdx.x & 63;
+  const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (cell >= cells) return;
+  const float* zr = z + (size_t)cell * kTokens * ldz;
+  float x[12];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const int d = lane + 64 * i;
+    x[i] = d < D ? zr[d] : 0.f;
+    sum += x[i];
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const int d = lane + 64 * i;
+    if (d < D) { const float a = x[i] - mean; sq += a * a; }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + kLnEps);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const int d = lane + 64 * i;
+    x[i] = d < D ? (x[i] - mean) * rstd * gamma[d] + beta[d] : 0.f;
+  }
+  float logit[16];
+  float mx = -INFINITY;
+  for (int k = 0; k < K; ++k) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int d = lane + 64 * i;
+      if (d < D) acc += x[i] * hw[(size_t)k * D + d];
+    }
+    acc = wave_sum(acc) + hb[k];
+    logit[k] = acc;
+    mx = fmaxf(mx, acc);
+  }
+  float den = 0.f;
+  for (int k = 0; k < K; ++k) { logit[k] = expf(logit[k] - mx); den += logit[k]; }
+  if (lane == 0)
+    for (int k = 0; k < K; ++k) probs[(size_t)cell * K + k] = logit[k] / den;
+}
+
+void launch_head_softmax(const float* z, int ldz, const float* gamma, const float* beta, const float* hw, const float* hb, float* probs,
+                         int D, int K, int cells, hipStream_t s) {
+  if (cells <= 0) return;
+  hipLaunchKernelGGL(head_softmax_kernel, dim3((cells + 3) / 4), dim3(256), 0, s, z, ldz, gamma, beta, hw, hb, probs, D, K, cells);
+}
+
+// fp32 nn.Linear weight [N][K] -> packed-split bf16 [Np][2*Kp], zero padded.  One thread per 4 consecutive k.
+__global__ void pack_weight_kernel(const float* __restrict__ w, int N, int K, uint16_t* __restrict__ out, int Np, int Kp) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int kq = Kp >> 2;
+  if (idx >= (long long)Np * kq) return;
+  const int n = (int)(idx / kq), q = (int)(idx - (long long)n * kq);
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (n < N) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (4 * q + i < K) v[i] = w[(size_t)n * K + 4 * q + i];
+  }
+  ps_store4(out + (size_t)n * (2 * Kp), 4 * q, v);
+}
+void launch_pack_weight(const float* w, int N, int K, uint16_t* out, int Np, int Kp, hipStream_t s) {
+  const long long total = (long long)Np * (Kp >> 2);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, N, K, out, Np, Kp);
+}
+
+}  // namespace ribca

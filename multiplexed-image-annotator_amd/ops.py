@@ -1,0 +1,233 @@
+"""Thin Python wrappers over the C ABI: one function per entry point of ``include/ribca_hip.h``.
+
+Inputs and outputs are torch CUDA(HIP) tensors; nothing here computes on the CPU except tiny host-side
+parameter preparation (Gaussian taps, index tables).  All calls enqueue on the current torch stream.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+
+PATCH = 40
+OTHERS = 17
+#: utils.py:143-146 key order (tie-break order of the vote); index = global class id, 17 = Others
+VOTE_ORDER: List[str] = ["CD4 T cell", "CD8 T cell", "Dendritic cell", "B cell", "M1 macrophage cell", "M2 macrophage cell",
+                         "Regulatory T cell", "Granulocyte cell", "Plasma cell", "Natural killer cell", "Mast cell",
+                         "Stroma cell", "Smooth muscle", "Endothelial cell", "Epithelial cell", "Proliferating/tumor cell",
+                         "Nerve cell"]
+GLOBAL_NAMES: List[str] = VOTE_ORDER + ["Others"]
+
+#: state-dict key order of the flat parameter blob (include/ribca_hip.h, ribca_vit_blob_len)
+def blob_keys(depth: int) -> List[str]:
+    keys = ["cls_token", "pos_embed", "patch_embed.proj.weight", "patch_embed.proj.bias"]
+    for i in range(depth):
+        p = f"blocks.{i}."
+        keys += [p + "norm1.weight", p + "norm1.bias", p + "attn.qkv.weight", p + "attn.qkv.bias", p + "attn.proj.weight",
+                 p + "attn.proj.bias", p + "norm2.weight", p + "norm2.bias", p + "mlp.fc1.weight", p + "mlp.fc1.bias",
+                 p + "mlp.fc2.weight", p + "mlp.fc2.bias"]
+    return keys + ["norm.weight", "norm.bias", "head.weight", "head.bias"]
+
+
+def gaussian_taps() -> np.ndarray:
+    """27 fp64 weights for sigma = 1, 2, 3 (truncate 4.0), computed exactly as scipy.ndimage's
+    ``_gaussian_kernel1d`` does (reference utils.py:265 -> skimage.filters.gaussian -> scipy): entry k of each
+    segment is the normalised weight at distance k."""
+    out = []
+    for sigma in (1, 2, 3):
+        sd = float(sigma)
+        radius = int(4.0 * sd + 0.5)
+        x = np.arange(-radius, radius + 1)
+        phi = np.exp(-0.5 / (sd * sd) * x ** 2)
+        phi = phi / phi.sum()
+        out.append(phi[radius:])
+    taps = np.concatenate(out)
+    assert taps.shape == (27,)
+    return taps
+
+
+_TAPS_DEV: Dict[int, torch.Tensor] = {}
+_WS: Dict[int, torch.Tensor] = {}
+
+
+def _taps(device) -> torch.Tensor:
+    key = device.index or 0
+    if key not in _TAPS_DEV:
+        _TAPS_DEV[key] = torch.from_numpy(gaussian_taps()).to(device)
+    return _TAPS_DEV[key]
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch buffer shared by all models on a device (caller-owned memory of the C ABI)."""
+    key = device.index or 0
+    cur = _WS.get(key)
+    if cur is None or cur.numel() < nbytes:
+        _WS[key] = None
+        cur = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _WS[key] = cur
+    return cur
+
+
+# ------------------------------------------------------------------------------------------- pre-processing
+def mask_minmax(mask: torch.Tensor) -> Tuple[int, int]:
+    assert mask.dtype == torch.int32 and mask.is_cuda
+    out = torch.empty(2, dtype=torch.int32, device=mask.device)
+    check(lib().ribca_mask_minmax(ptr(mask), mask.numel(), ptr(out), stream_ptr()), "ribca_mask_minmax")
+    mx, mn = out.tolist()
+    return mx, mn
+
+
+def label_table(mask: torch.Tensor) -> Tuple[np.ndarray, np.ndarray]:
+    """(H, W) int32 device mask -> (ids ascending int64 [n], table int64 [n, 7]: rmin, rmax, cmin, cmax, sum_r, sum_c,
+    count) on the host.  The per-label reduction runs on the GPU; the host only drops absent labels."""
+    assert mask.dtype == torch.int32 and mask.is_cuda and mask.dim() == 2
+    h, w = mask.shape
+    if mask.numel() == 0:
+        return np.zeros(0, np.int64), np.zeros((0, 7), np.int64)
+    mx, mn = mask_minmax(mask)
+    if mn < 0:
+        raise ValueError("segmentation mask holds negative labels; cell ids must be 1..N with 0 = background")
+    if mx <= 0:
+        return np.zeros(0, np.int64), np.zeros((0, 7), np.int64)
+    L = mx + 1
+    ti = torch.empty((5, L), dtype=torch.int32, device=mask.device)
+    tu = torch.empty((2, L), dtype=torch.int64, device=mask.device)
+    check(lib().ribca_label_table(ptr(mask), h, w, L, ptr(ti), ptr(tu), stream_ptr()), "ribca_label_table")
+    ti_h = ti.cpu().numpy().astype(np.int64)
+    tu_h = tu.cpu().numpy()
+    ids = np.flatnonzero(ti_h[4] > 0)
+    table = np.stack([ti_h[0, ids], ti_h[1, ids], ti_h[2, ids], ti_h[3, ids], tu_h[0, ids], tu_h[1, ids], ti_h[4, ids]], axis=1)
+    return ids.astype(np.int64), table.astype(np.int64)
+
+
+def channel_min(image: torch.Tensor) -> torch.Tensor:
+    assert image.dtype == torch.float32 and image.is_cuda and image.dim() == 3
+    c, h, w = image.shape
+    out = torch.empty(c, dtype=torch.float32, device=image.device)
+    check(lib().ribca_channel_min(ptr(image), c, h * w, ptr(out), stream_ptr()), "ribca_channel_min")
+    return out
+
+
+def extract_patches(image: torch.Tensor, mask: torch.Tensor, chan_min: torch.Tensor, ids: torch.Tensor, bbox: torch.Tensor,
+                    want_avg: bool = False, out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Soft-masked fp32 patches (n, C, 40, 40) for the given cells (ids int32 [n], bbox int32 [n, 4])."""
+    c, h, w = image.shape
+    n = ids.numel()
+    assert image.dtype == torch.float32 and mask.dtype == torch.int32 and ids.dtype == torch.int32 and bbox.dtype == torch.int32
+    assert mask.shape == (h, w) and bbox.shape == (n, 4)
+    if out is None:
+        out = torch.empty((n, c, PATCH, PATCH), dtype=torch.float32, device=image.device)
+    avg = torch.empty((n, c), dtype=torch.float64, device=image.device) if want_avg else None
+    if n:
+        check(lib().ribca_extract_patches(ptr(image), c, h, w, ptr(mask), ptr(chan_min), ptr(ids), ptr(bbox), ptr(_taps(image.device)), n,
+                                          ptr(out), ptr(avg), stream_ptr()), "ribca_extract_patches")
+    return out, avg
+
+
+# ------------------------------------------------------------------------------------------- ViT
+class VitModel:
+    """One packed classifier on one device (replaces a timm ``VisionTransformer`` instance of reference
+    model.py:188-234).  ``state_dict`` uses the timm key names of the reference checkpoints."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device=None):
+        device = device or _lib.require_gpu()
+        self.device = torch.device(device)
+        d = state_dict["cls_token"].shape[-1]
+        c = state_dict["patch_embed.proj.weight"].shape[1]
+        k = state_dict["head.weight"].shape[0]
+        depth = 0
+        while f"blocks.{depth}.norm1.weight" in state_dict:
+            depth += 1
+        if state_dict["pos_embed"].shape[1] != 101 or tuple(state_dict["patch_embed.proj.weight"].shape[2:]) != (4, 4):
+            raise ValueError("expected a 40x40 / patch-4 ViT (101 tokens)")
+        self.D, self.C, self.K, self.depth = int(d), int(c), int(k), depth
+        blob = torch.cat([state_dict[key].detach().to(torch.float32).reshape(-1) for key in blob_keys(depth)]).to(self.device)
+        want = lib().ribca_vit_blob_len(self.D, self.C, self.K, depth)
+        if blob.numel() != want:
+            raise ValueError(f"state dict has {blob.numel()} parameters, expected {want}")
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().ribca_vit_create(ptr(blob), blob.numel(), self.D, self.C, self.K, depth, stream_ptr(), ctypes.byref(handle)),
+                  "ribca_vit_create")
+            torch.cuda.current_stream().synchronize()  # the blob may be freed once packing has finished
+        self._h = handle
+        self.flops_per_cell = float(lib().ribca_vit_flops_per_cell(self._h))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                lib().ribca_vit_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def predict_proba(self, patches: torch.Tensor, src_chan: Sequence[int], chunk_cells: int = 256) -> torch.Tensor:
+        """softmax(model(x), dim=1) for full-channel patches (n, C_img, 40, 40); ``src_chan[c]`` = image channel of model
+        channel c or -1 for a blank plane (reference preprocess.py:110-120, model.py:397-406)."""
+        assert patches.is_cuda and patches.dtype == torch.float32 and patches.dim() == 4 and patches.shape[2:] == (PATCH, PATCH)
+        if len(src_chan) != self.C:
+            raise ValueError(f"model expects {self.C} channels, got an index list of {len(src_chan)}")
+        n, c_img = patches.shape[0], patches.shape[1]
+        if any(s >= c_img or s < -1 for s in src_chan):
+            raise ValueError("channel index out of range")
+        probs = torch.empty((n, self.K), dtype=torch.float32, device=patches.device)
+        if n == 0:
+            return probs
+        chunk = max(1, min(int(chunk_cells), n))
+        src = torch.tensor(list(src_chan), dtype=torch.int32, device=patches.device)
+        nbytes = lib().ribca_vit_workspace_bytes(self._h, chunk)
+        ws = workspace(nbytes + 256, patches.device)
+        base = ws.data_ptr()
+        aligned = (base + 255) & ~255
+        check(lib().ribca_vit_forward(self._h, ptr(patches.contiguous()), c_img, ptr(src), n, ptr(probs), aligned, nbytes, chunk,
+                                      stream_ptr()), "ribca_vit_forward")
+        return probs
+
+
+def resolve_channels(channel_index: Sequence[int], c_img: int) -> List[int]:
+    """Reference channel-select semantics (preprocess.py:110-120): the FIRST -1 becomes a blank plane, every further -1
+    stays in a numpy fancy index and therefore picks the LAST image channel."""
+    out, seen_blank = [], False
+    for ci in channel_index:
+        if ci == -1 and not seen_blank:
+            out.append(-1)
+            seen_blank = True
+        elif ci == -1:
+            out.append(c_img - 1)
+        else:
+            out.append(int(ci))
+    return out
+
+
+# ------------------------------------------------------------------------------------------- vote
+def vote(p_a: torch.Tensor, map_a: Sequence[int], p_b: Optional[torch.Tensor], map_b: Optional[Sequence[int]],
+         type_conf: Sequence[float], conf: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    n = p_a.shape[0]
+    dev = p_a.device
+    label = torch.empty(n, dtype=torch.int8, device=dev)
+    out_conf = torch.empty(n, dtype=torch.float32, device=dev)
+    ma = torch.tensor(list(map_a), dtype=torch.int8, device=dev)
+    mb = torch.tensor(list(map_b), dtype=torch.int8, device=dev) if p_b is not None else None
+    tc = torch.tensor([float(np.float32(v)) for v in type_conf], dtype=torch.float32, device=dev)
+    check(lib().ribca_vote(ptr(p_a.contiguous()), p_a.shape[1], ptr(ma), ptr(p_b.contiguous()) if p_b is not None else None,
+                           p_b.shape[1] if p_b is not None else 0, ptr(mb), ptr(tc), float(np.float32(conf)), n, ptr(label),
+                           ptr(out_conf), stream_ptr()), "ribca_vote")
+    return label, out_conf
+
+
+# ------------------------------------------------------------------------------------------- profiling
+def prof_enable(on: bool) -> None:
+    lib().ribca_prof_enable(1 if on else 0)
+
+
+def prof_read() -> Dict[str, Tuple[float, int]]:
+    ms = (ctypes.c_double * 10)()
+    cnt = (ctypes.c_int64 * 10)()
+    lib().ribca_prof_read(ms, cnt)
+    return {lib().ribca_prof_name(i).decode(): (ms[i], cnt[i]) for i in range(10)}

@@ -1,0 +1,301 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (ctypes).  Floating-point kernels are compared with a plain
+torch fp64/fp32 statement of the same op (tolerances written at each assert); integer / byte work with the golden
+fixtures (bit-exact)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from multiplexed_image_annotator_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from multiplexed_image_annotator_amd import _lib
+    return _lib.require_gpu()
+
+
+def _ops():
+    from multiplexed_image_annotator_amd import ops
+    return ops
+
+
+def ps_encode(x: torch.Tensor, kp: int, rows_pad: int = None) -> torch.Tensor:
+    """fp32 [R, K] -> packed-split bf16 bits [Rp, 2*Kp] (int16 storage) via the library's own packer."""
+    from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
+    r, k = x.shape
+    rp = rows_pad or r
+    out = torch.zeros((rp, 2 * kp), dtype=torch.int16, device=x.device)
+    check(lib().ribca_test_pack_weight(ptr(x.contiguous()), r, k, ptr(out), rp, kp, stream_ptr()), "pack")
+    return out
+
+
+def ps_decode(buf: torch.Tensor, k: int) -> torch.Tensor:
+    """packed-split [R, 2*Kp] int16 -> fp64 [R, K] (hi + lo)."""
+    r = buf.shape[0]
+    b = buf.view(r, -1, 2, 8).to(torch.int32) & 0xFFFF
+    f = (b << 16).view(torch.float32)
+    hi, lo = f[:, :, 0, :].reshape(r, -1), f[:, :, 1, :].reshape(r, -1)
+    return (hi.double() + lo.double())[:, :k]
+
+
+def rnd(shape, seed, dev, scale=1.0):
+    n = int(np.prod(shape))
+    return (synth.approx_normal(synth.stream_key(seed, "t"), n).reshape(shape) * scale).to(torch.float32).to(dev)
+
+
+def test_pack_roundtrip(dev):
+    x = rnd((37, 100), 1, dev)
+    buf = ps_encode(x, 128, 48)
+    y = ps_decode(buf, 100)
+    # two bf16 terms carry >= 16 mantissa bits: relative error <= 2^-16
+    assert torch.all((y[:37] - x.double()).abs() <= x.double().abs() * 2.0 ** -16 + 1e-30)
+    assert torch.all(y[37:] == 0) and torch.all(ps_decode(buf, 128)[:, 100:] == 0)
+
+
+@pytest.mark.parametrize("d", [144, 288, 384, 576])
+def test_layernorm(dev, d):
+    from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
+    m = 203
+    z = rnd((m, d), 2, dev, 3.0) + 0.5
+    g = rnd((d,), 3, dev, 0.1) + 1.0
+    b = rnd((d,), 4, dev, 0.1)
+    dp = (d + 31) // 32 * 32
+    out = torch.zeros((m, 2 * dp), dtype=torch.int16, device=dev)
+    check(lib().ribca_test_layernorm(ptr(z), d, ptr(g), ptr(b), ptr(out), 2 * dp, m, d, stream_ptr()), "ln")
+    ref = torch.nn.functional.layer_norm(z.double(), (d,), g.double(), b.double(), 1e-6)
+    got = ps_decode(out, d)
+    assert (got - ref).abs().max().item() < 2e-5   # fp32 statistics + 2^-16 split error on |y| <~ 5
+    assert torch.all(ps_decode(out, dp)[:, d:] == 0)
+
+
+GEMM_SHAPES = [(1, 288, 288), (100, 864, 288), (128, 1152, 288), (300, 288, 1152), (257, 144, 144), (130, 432, 144),
+               (77, 576, 2304), (200, 1728, 576), (129, 384, 384), (64, 64, 64)]
+
+
+@pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
+def test_gemm_residual(dev, m, n, k):
+    from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
+    kp = (k + 31) // 32 * 32
+    a = rnd((m, k), 5, dev)
+    w = rnd((n, k), 6, dev, 1.0 / np.sqrt(k))
+    bias = rnd((n,), 7, dev, 0.1)
+    z0 = rnd((m, n), 8, dev)
+    a_ps = ps_encode(a, kp)
+    w_ps = ps_encode(w, kp, lib().ribca_gemm_padded_n(n))
+    z = z0.clone()
+    check(lib().ribca_test_gemm(0, ptr(a_ps), 2 * kp, ptr(w_ps), 2 * kp, m, n, kp, ptr(bias), ptr(z), n, stream_ptr()), "gemm")
+    ref = z0.double() + a.double() @ w.double().t() + bias.double()
+    err = (z.double() - ref).abs().max().item()
+    assert err < 5e-5, err   # bf16x3: ~2^-16 per operand, fp32 accumulate; |terms| ~ 1
+
+
+@pytest.mark.parametrize("m,n,k", [(150, 1152, 288), (101, 576, 144), (260, 2304, 576)])
+def test_gemm_gelu(dev, m, n, k):
+    from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
+    kp = (k + 31) // 32 * 32
+    a = rnd((m, k), 9, dev)
+    w = rnd((n, k), 10, dev, 2.0 / np.sqrt(k))
+    bias = rnd((n,), 11, dev, 0.1)
+    a_ps = ps_encode(a, kp)
+    w_ps = ps_encode(w, kp, lib().ribca_gemm_padded_n(n))
+    out = torch.zeros((m, 2 * n), dtype=torch.int16, device=dev)
+    check(lib().ribca_test_gemm(1, ptr(a_ps), 2 * kp, ptr(w_ps), 2 * kp, m, n, kp, ptr(bias), ptr(out), 2 * n, stream_ptr()), "gemm")
+    ref = torch.nn.functional.gelu(a.double() @ w.double().t() + bias.double())
+    err = (ps_decode(out, n) - ref).abs().max().item()
+    assert err < 1e-4, err
+
+
+@pytest.mark.parametrize("d", [144, 288, 384, 576])
+def test_qkv_attention(dev, d):
+    from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
+    cells, heads, ntok = 3, 12, 101
+    hd = d // heads
+    hdp, hdv = (hd + 31) // 32 * 32, (hd + 15) // 16 * 16
+    m = cells * ntok
+    dp = (d + 31) // 32 * 32
+    y = rnd((m, d), 12, dev)
+    w = rnd((3 * d, d), 13, dev, 2.0 / np.sqrt(d))
+    bias = rnd((3 * d,), 14, dev, 0.1)
+    y_ps = ps_encode(y, dp)
+    w_ps = ps_encode(w, dp, lib().ribca_gemm_padded_n(3 * d))
+    q = torch.zeros((cells, heads, 112, 2 * hdp), dtype=torch.int16, device=dev)
+    k = torch.zeros_like(q)
+    vt = torch.zeros((cells, heads, hdv, 256), dtype=torch.int16, device=dev)
+    out = torch.zeros((m, 2 * dp), dtype=torch.int16, device=dev)
+    check(lib().ribca_test_qkv_attention(ptr(y_ps), 2 * dp, ptr(w_ps), 2 * dp, cells, d, dp, ptr(bias), ptr(q), ptr(k), ptr(vt),
+                                         ptr(out), 2 * dp, stream_ptr()), "qkv+attention")
+    qkv = (y.double() @ w.double().t() + bias.double()).reshape(cells, ntok, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    qq, kk, vv = qkv[0], qkv[1], qkv[2]
+    # intermediate layouts first (localises a failure): Q rows pre-scaled, K rows, V transposed + key-permuted
+    qd = ps_decode(q.reshape(-1, 2 * hdp), hdp).reshape(cells, heads, 112, hdp)
+    kd = ps_decode(k.reshape(-1, 2 * hdp), hdp).reshape(cells, heads, 112, hdp)
+    assert (qd[:, :, :ntok, :hd] - qq * hd ** -0.5).abs().max().item() < 5e-5
+    assert (kd[:, :, :ntok, :hd] - kk).abs().max().item() < 5e-5
+    assert torch.all(qd[:, :, ntok:] == 0) and torch.all(qd[..., hd:] == 0)
+    t = torch.arange(128)
+    pos = (t & ~31) | (((t >> 2) & 3) << 3) | (((t >> 4) & 1) << 2) | (t & 3)
+    vd = ps_decode(vt.reshape(-1, 256), 128).reshape(cells, heads, hdv, 128)
+    vd_nat = vd[..., pos.to(dev)]          # natural key order
+    assert (vd_nat[:, :, :hd, :ntok] - vv.transpose(-1, -2)).abs().max().item() < 5e-5
+    att = torch.softmax((qq * hd ** -0.5) @ kk.transpose(-1, -2), dim=-1)
+    ref = (att @ vv).transpose(1, 2).reshape(m, d)
+    err = (ps_decode(out, d) - ref).abs().max().item()
+    assert err < 1e-4, err
+    assert torch.all(ps_decode(out, dp)[:, d:] == 0)
+
+
+@pytest.mark.parametrize("name", list(synth.VIT_CONFIGS))
+def test_vit_forward_vs_oracle(dev, name):
+    from oracle import ref_vit
+    ops = _ops()
+    d, c, k = synth.VIT_CONFIGS[name]
+    sd = synth.make_vit_state_dict(name, synth.SEED_BASE + 7)
+    n = 21
+    u = synth.uniform(synth.stream_key(5, "vitx/" + name), n * c * 1600).reshape(n, c, 40, 40).to(torch.float32)
+    x = torch.where(u * 2 - 1 > 0.1, u * 2 - 1, torch.full_like(u, -1.0))
+    ref = ref_vit.predict_proba(sd, x, 8)
+    model = ops.VitModel(sd, dev)
+    got = model.predict_proba(x.to(dev), list(range(c)), chunk_cells=8).cpu()   # 3 chunks, last one ragged
+    err = (got - ref).abs().max().item()
+    assert err < 1e-4, err            # north-star tolerance is 1e-3 on confidences
+    assert torch.equal(got.argmax(1), ref.argmax(1))
+    got2 = model.predict_proba(x.to(dev), list(range(c)), chunk_cells=64).cpu()
+    assert torch.equal(got, got2)     # chunking does not change results
+
+
+def test_vit_golden_logits(dev, golden_dir):
+    ops = _ops()
+    g = np.load(os.path.join(golden_dir, "vit_logits.npz"))
+    for name, (d, c, k) in synth.VIT_CONFIGS.items():
+        sd = synth.make_vit_state_dict(name, synth.SEED_BASE + 7)
+        u = synth.uniform(synth.stream_key(synth.SEED_BASE + 7, "vitx/" + name), 8 * c * 1600).reshape(8, c, 40, 40).to(torch.float32)
+        x = torch.where(u * 2 - 1 > 0.1, u * 2 - 1, torch.full_like(u, -1.0))
+        got = ops.VitModel(sd, dev).predict_proba(x.to(dev), list(range(c))).cpu().numpy()
+        assert np.abs(got - g[name + "_probs"]).max() < 1e-4
+        assert (got.argmax(1) == g[name + "_probs"].argmax(1)).all()
+
+
+def test_blank_and_aliased_channels(dev):
+    from oracle import ref_vit, ref_preprocess
+    ops = _ops()
+    name = "immune_base"
+    d, c, k = synth.VIT_CONFIGS[name]
+    sd = synth.make_vit_state_dict(name, 3)
+    n, c_img = 5, 9
+    full = (synth.uniform(synth.stream_key(6, "full"), n * c_img * 1600).reshape(n, c_img, 40, 40) * 2 - 1).to(torch.float32)
+    index = [3, -1, 0, 8, -1, 2, 5]                      # first -1 blank, second -1 -> last image channel
+    sel = np.stack([ref_preprocess.select_channels(full[i].numpy(), index) for i in range(n)])
+    ref = ref_vit.predict_proba(sd, torch.from_numpy(sel.astype(np.float32)))
+    got = ops.VitModel(sd, dev).predict_proba(full.to(dev), ops.resolve_channels(index, c_img)).cpu()
+    assert (got - ref).abs().max().item() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------- integer / byte work
+def test_label_table_golden(dev, golden_dir):
+    ops = _ops()
+    g = np.load(os.path.join(golden_dir, "cellpos.npz"))
+    for key, mask in (("odd", g["odd_mask"]), ("example2", g["example2_mask"].astype(np.int32))):
+        ids, tab = ops.label_table(torch.from_numpy(mask.astype(np.int32)).to(dev))
+        np.testing.assert_array_equal(ids, g[key + "_ids"])
+        np.testing.assert_array_equal(tab, g[key + "_table"])
+    ms, _ = synth.make_mask_and_image(160, 200, 60, 1, synth.SEED_BASE + 111, want_image=False)
+    ids, tab = ops.label_table(ms.to(dev))
+    np.testing.assert_array_equal(ids, g["synth_ids"])
+    np.testing.assert_array_equal(tab, g["synth_table"])
+
+
+def test_label_table_edge_cases(dev):
+    ops = _ops()
+    ids, tab = ops.label_table(torch.zeros((7, 13), dtype=torch.int32, device=dev))
+    assert ids.shape == (0,) and tab.shape == (0, 7)
+    one = torch.zeros((3, 5), dtype=torch.int32)
+    one[2, 4] = 7
+    ids, tab = ops.label_table(one.to(dev))
+    assert ids.tolist() == [7] and tab.tolist() == [[2, 2, 4, 4, 2, 4, 1]]
+    with pytest.raises(ValueError):
+        ops.label_table(torch.full((2, 2), -1, dtype=torch.int32, device=dev))
+
+
+def test_label_table_matches_oracle_large(dev):
+    from oracle import ref_preprocess
+    ops = _ops()
+    ms, _ = synth.make_mask_and_image(1000, 1001, 3000, 1, 99, want_image=False)   # W not a multiple of 8
+    ids, tab = ops.label_table(ms.to(dev))
+    rids, rtab = ref_preprocess.cell_table(ms.numpy())
+    np.testing.assert_array_equal(ids, rids)
+    np.testing.assert_array_equal(tab, rtab)
+
+
+def test_channel_min(dev):
+    ops = _ops()
+    x = rnd((5, 97, 131), 20, dev)
+    x[3] = x[3].abs() + 0.25
+    np.testing.assert_array_equal(ops.channel_min(x).cpu().numpy(), x.amin(dim=(1, 2)).cpu().numpy())
+
+
+def test_patches_golden(dev, golden_dir):
+    ops = _ops()
+    g = np.load(os.path.join(golden_dir, "patches.npz"))
+    img = torch.from_numpy(g["A_image"]).to(dev)
+    mask = torch.from_numpy(g["A_mask"]).to(dev)
+    ids, tab = ops.label_table(mask)
+    cmin = ops.channel_min(img)
+    patches, avg = ops.extract_patches(img, mask, cmin, torch.from_numpy(ids.astype(np.int32)).to(dev),
+                                       torch.from_numpy(tab[:, :4].astype(np.int32)).to(dev), want_avg=True)
+    got = patches.cpu().numpy()
+    np.testing.assert_array_equal(got, g["A_all7_patches"])             # same arithmetic, operation for operation
+    inten = (avg.cpu().numpy() + 1) / 2
+    np.testing.assert_allclose(inten, g["A_all7_intensity"], rtol=1e-12, atol=1e-14)   # summation order differs only
+    for name in ("perm", "one_missing", "two_missing", "three"):
+        idx = ops.resolve_channels(g[f"A_{name}_index"].tolist(), 7)
+        sel = np.stack([got[:, s] if s >= 0 else np.full_like(got[:, 0], -1.0) for s in idx], axis=1)
+        np.testing.assert_array_equal(sel, g[f"A_{name}_patches"])
+
+
+def test_patches_unnormalised_golden(dev, golden_dir):
+    ops = _ops()
+    g = np.load(os.path.join(golden_dir, "patches.npz"))
+    img = torch.from_numpy(g["B_raw"].astype(np.float32)).to(dev)      # uint16 -> fp32 is exact
+    mask = torch.from_numpy(g["B_mask"]).to(dev)
+    ids, tab = ops.label_table(mask)
+    patches, avg = ops.extract_patches(img, mask, ops.channel_min(img), torch.from_numpy(ids.astype(np.int32)).to(dev),
+                                       torch.from_numpy(tab[:, :4].astype(np.int32)).to(dev), want_avg=True)
+    got = patches.cpu().numpy()[:, [2, 0, 1]]
+    np.testing.assert_array_equal(got, g["B_patches"])
+    np.testing.assert_allclose((avg.cpu().numpy() + 1) / 2, g["B_intensity"], rtol=1e-12)
+
+
+def test_vote_golden(dev, golden_dir):
+    from oracle import ref_vote
+    ops = _ops()
+    meta = json.load(open(os.path.join(golden_dir, "vote_cases.json")))
+    arrs = np.load(os.path.join(golden_dir, "vote_cases.npz"))
+    gid = {n: i for i, n in enumerate(ops.GLOBAL_NAMES)}
+    n_checked = 0
+    for key, m in meta.items():
+        if key == "branch1":
+            continue
+        cname = key.split("__")[0]
+        tables = []
+        if m["immune"]:
+            tables.append((m["immune"], arrs[f"{cname}__p_{m['immune']}"]))
+        if m["struct"]:
+            tables.append(("struct", arrs[f"{cname}__p_struct"]))
+        if m["nerve"] and len(tables) < 2:
+            tables.append(("nerve", arrs[f"{cname}__p_nerve"]))
+        tc = m["type_conf"] or {n: -1 for n in ops.GLOBAL_NAMES}
+        tcv = [tc[n] for n in ops.GLOBAL_NAMES]
+        (ma, pa) = tables[0]
+        pb = torch.from_numpy(tables[1][1]).to(dev) if len(tables) > 1 else None
+        mb = [gid[c] for c in ref_vote.CLASS_NAMES[tables[1][0]]] if len(tables) > 1 else None
+        lab, conf = ops.vote(torch.from_numpy(pa).to(dev), [gid[c] for c in ref_vote.CLASS_NAMES[ma]], pb, mb, tcv, m["conf"])
+        labels = [ops.GLOBAL_NAMES[i] for i in lab.cpu().tolist()]
+        assert labels == m["labels"], key
+        np.testing.assert_array_equal(conf.cpu().numpy(), arrs[key + "__conf"])
+        n_checked += 1
+    assert n_checked == 44
