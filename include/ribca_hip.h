@@ -49,6 +49,26 @@ int ribca_extract_patches(const float* image, int32_t C, int32_t H, int32_t W, c
                           const int32_t* cell_id, const int32_t* bbox, const double* taps, int32_t n, float* patches, double* avg,
                           void* stream);
 
+/* ---- whole-image normalisation primitives (ImageProcessor._normalize, preprocess.py:214-239) ---------------------
+ * The host drives them per image (ops.normalize_image in the Python package shows the sequence): the percentile needs
+ * a data-dependent host decision, everything touching pixels runs here.  Results are bit-identical to the reference. */
+int ribca_u16_to_f32(const uint16_t* in, float* out, int64_t n, void* stream);
+/* One axis of scipy.ndimage.gaussian_filter on `planes` fp32 (H, W) images: fp64 accumulation in scipy's order, fp32 result.
+ * taps[k] = weight at distance k (k = 0..R); mode 0 = 'reflect', 1 = 'nearest'; axis 0 = rows, 1 = columns; in != out. */
+int ribca_gauss1d(const float* in, float* out, int32_t planes, int32_t H, int32_t W, int32_t axis, const double* taps, int32_t R,
+                  int32_t mode, void* stream);
+/* x = max(x - min(bg, cap), 0) (preprocess.py:219-222) */
+int ribca_bg_subtract(float* x, const float* bg, int64_t n, float cap, void* stream);
+/* out[p] = max over plane p of non-negative fp32 data */
+int ribca_plane_max(const float* x, int32_t planes, int64_t hw, float* out, void* stream);
+/* One radix-select pass over non-negative fp32 keys: hist[p][b] = #{k in plane p : (k & mask_hi) == prefix[p],
+ * (k >> shift) & (2^bits - 1) == b}; hist is (planes, 2048) uint32.  Three passes (11 + 11 + 10 bits) locate any order
+ * statistic exactly; np.percentile's interpolation between two of them is done by the host. */
+int ribca_radix_hist(const float* x, int32_t planes, int64_t hw, const uint32_t* prefix, uint32_t mask_hi, int32_t shift, int32_t bits,
+                     uint32_t* hist, void* stream);
+/* per plane: mode 0 -> fill -1; else x = 2 * (min(x, clip) / denom) - 1 (preprocess.py:229-238) */
+int ribca_norm_finalize(float* x, int32_t planes, int64_t hw, const int32_t* mode, const float* clip, const float* denom, void* stream);
+
 /* ---- ViT classifier (timm VisionTransformer subclass, model.py:31-88) -------------------------------------- */
 
 /* Number of fp32 values in the flat parameter blob ribca_vit_create expects, in this order:

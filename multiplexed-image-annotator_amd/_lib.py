@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_uint32, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libribca_hip.so")
@@ -23,6 +23,12 @@ SIGNATURES = {
     "ribca_channel_min": (c_int32, [c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
     "ribca_extract_patches": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                         c_void_p, c_void_p, c_void_p]),
+    "ribca_u16_to_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "ribca_gauss1d": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
+    "ribca_bg_subtract": (c_int32, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+    "ribca_plane_max": (c_int32, [c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
+    "ribca_radix_hist": (c_int32, [c_void_p, c_int32, c_int64, c_void_p, c_uint32, c_int32, c_int32, c_void_p, c_void_p]),
+    "ribca_norm_finalize": (c_int32, [c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ribca_vit_blob_len": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
     "ribca_vit_create": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, POINTER(c_void_p)]),
     "ribca_vit_destroy": (None, [c_void_p]),
@@ -56,6 +62,9 @@ def lib() -> ctypes.CDLL:
             raise RibcaError(
                 f"{LIB_PATH} not found: build it with `python -m multiplexed_image_annotator_amd.build` "
                 "(hipcc, gfx950). There is no CPU fallback for the hot path.")
+        # torch must be imported first: it bundles its own HIP runtime (same SONAME); loading ours first would pull in a
+        # second runtime from /opt/rocm and the two do not share device state
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)

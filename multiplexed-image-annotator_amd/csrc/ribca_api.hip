@@ -74,7 +74,7 @@ struct ribca_vit {
   char* arena = nullptr;
   size_t arena_bytes = 0;
   const float *cls, *pos, *pe_b, *norm_w, *norm_b, *head_w, *head_b;
-  const uint16_t* pe_w;
+  const float* pe_w;   // fp32 [D][16*C]: the patch embedding stays in fp32 (vit_misc.hip embed_f32_kernel)
   struct Layer {
     const float *ln1w, *ln1b, *qkvb, *projb, *ln2w, *ln2b, *fc1b, *fc2b;
     const uint16_t *qkvw, *projw, *fc1w, *fc2w;
@@ -101,7 +101,7 @@ size_t layout(ribca_vit* m, char* base) {
   m->cls = c.take<float>(D);
   m->pos = c.take<float>((size_t)kTokens * D);
   m->pe_b = c.take<float>(D);
-  m->pe_w = c.take<uint16_t>((size_t)gemm_padded_n(D) * 2 * m->Kpe);
+  m->pe_w = c.take<float>((size_t)D * 16 * m->C);
   m->layers.resize(m->depth);
   for (auto& L : m->layers) {
     L.ln1w = c.take<float>(D); L.ln1b = c.take<float>(D);
@@ -134,10 +134,7 @@ Workspace carve_ws(const ribca_vit* m, int chunk, char* base) {
   w.k = c.take<uint16_t>((size_t)chunk * kHeads * kTokPad * 2 * m->hdp);
   w.vt_bytes = (size_t)chunk * kHeads * m->hdv * 2 * kKeyPad * sizeof(uint16_t);
   w.vt = c.take<uint16_t>((size_t)chunk * kHeads * m->hdv * 2 * kKeyPad);
-  // h (fc1 output) doubles as the im2col matrix of the patch embedding
-  const size_t h_elems = Mc * 2 * m->H4;
-  const size_t pe_elems = (size_t)chunk * 100 * 2 * m->Kpe;
-  w.h = c.take<uint16_t>(h_elems > pe_elems ? h_elems : pe_elems);
+  w.h = c.take<uint16_t>(Mc * 2 * m->H4);
   w.total = c.off;
   return w;
 }
@@ -189,7 +186,7 @@ int ribca_vit_create(const float* blob, int64_t blob_len, int32_t D, int32_t C, 
 #define CP(dst, n) do { hipError_t r_ = copyf(dst, n); if (r_ != hipSuccess) { ribca_vit_destroy(m); return hip_fail(r_, "hipMemcpyAsync(param)"); } } while (0)
   CP(m->cls, D);
   CP(m->pos, (size_t)kTokens * D);
-  pack(m->pe_w, D, 16 * C, m->Kpe);
+  CP(m->pe_w, (size_t)D * 16 * C);
   CP(m->pe_b, D);
   for (auto& L : m->layers) {
     CP(L.ln1w, D); CP(L.ln1b, D);
@@ -238,7 +235,7 @@ int ribca_vit_forward(const ribca_vit_t* m, const float* patches, int32_t c_img,
   const Workspace w = carve_ws(m, chunk_cells, (char*)workspace);
   if ((int64_t)w.total > workspace_bytes) return fail("ribca_vit_forward: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  const int D = m->D, Dp = m->Dp, ld_x = 2 * Dp, ld_h = 2 * m->H4, ld_pe = 2 * m->Kpe;
+  const int D = m->D, Dp = m->Dp, ld_x = 2 * Dp, ld_h = 2 * m->H4;
   const float scale = 1.0f / sqrtf((float)m->hd);
 
   // pads (tokens >= 101, head dims >= hd, feature columns >= D) are never written by any kernel: zero them once per call
@@ -253,13 +250,8 @@ int ribca_vit_forward(const ribca_vit_t* m, const float* patches, int32_t c_img,
     const int bc = n_cells - c0 < chunk_cells ? n_cells - c0 : chunk_cells;
     const int Mc = bc * kTokens;
     {
-      ProfScope ps(P_IM2COL, s);
-      launch_im2col_ps(patches + (size_t)c0 * c_img * 1600, c_img, src_chan, m->C, w.h, ld_pe, m->Kpe, bc, s);
-    }
-    {
       ProfScope ps(P_EMBED, s);
-      GemmArgs g{w.h, ld_pe, m->pe_w, ld_pe, bc * 100, D, m->Kpe, m->pe_b};
-      launch_gemm_embed(g, w.z, D, m->pos, D, s);
+      launch_embed_f32(patches + (size_t)c0 * c_img * 1600, c_img, src_chan, m->C, m->pe_w, m->pe_b, m->pos, w.z, D, D, bc, s);
     }
     {
       ProfScope ps(P_OTHER, s);
@@ -345,6 +337,49 @@ int ribca_vote(const float* p_a, int32_t k_a, const int8_t* map_a, const float* 
   if (k_a <= 0 || k_a > 16 || (p_b && (k_b <= 0 || k_b > 16))) return fail("ribca_vote: class counts must be in [1, 16]");
   VoteArgs a{p_a, k_a, map_a, p_b, k_b, map_b, type_conf, conf, n, label, out_conf};
   launch_vote(a, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------- normalisation primitives
+int ribca_u16_to_f32(const uint16_t* in, float* out, int64_t n, void* stream) {
+  if (n > 0 && (!in || !out)) return fail("ribca_u16_to_f32: NULL buffer");
+  launch_u16_to_f32(in, out, n, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int ribca_gauss1d(const float* in, float* out, int32_t planes, int32_t H, int32_t W, int32_t axis, const double* taps, int32_t R,
+                  int32_t mode, void* stream) {
+  if (!in || !out || !taps) return fail("ribca_gauss1d: NULL buffer");
+  if (in == out) return fail("ribca_gauss1d: in-place filtering is not supported");
+  if (axis < 0 || axis > 1 || mode < 0 || mode > 1 || R < 0) return fail("ribca_gauss1d: bad axis/mode/radius");
+  launch_gauss1d(in, out, planes, H, W, axis, taps, R, mode, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int ribca_bg_subtract(float* x, const float* bg, int64_t n, float cap, void* stream) {
+  if (n > 0 && (!x || !bg)) return fail("ribca_bg_subtract: NULL buffer");
+  launch_bg_subtract(x, bg, n, cap, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int ribca_plane_max(const float* x, int32_t planes, int64_t hw, float* out, void* stream) {
+  if (!x || !out) return fail("ribca_plane_max: NULL buffer");
+  launch_plane_max(x, planes, hw, out, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int ribca_radix_hist(const float* x, int32_t planes, int64_t hw, const uint32_t* prefix, uint32_t mask_hi, int32_t shift, int32_t bits,
+                     uint32_t* hist, void* stream) {
+  if (!x || !prefix || !hist) return fail("ribca_radix_hist: NULL buffer");
+  if (bits < 1 || bits > 11 || shift < 0 || shift + bits > 32) return fail("ribca_radix_hist: bad shift/bits");
+  launch_radix_hist(x, planes, hw, prefix, mask_hi, shift, bits, hist, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int ribca_norm_finalize(float* x, int32_t planes, int64_t hw, const int32_t* mode, const float* clip, const float* denom, void* stream) {
+  if (!x || !mode || !clip || !denom) return fail("ribca_norm_finalize: NULL buffer");
+  launch_norm_finalize(x, planes, hw, mode, clip, denom, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return 0;
 }

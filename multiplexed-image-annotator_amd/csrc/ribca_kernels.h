@@ -36,6 +36,8 @@ void launch_layernorm_ps(const float* z, int ldz, const float* gamma, const floa
                          hipStream_t s);
 void launch_im2col_ps(const float* patches, int c_img, const int* src_chan, int C, uint16_t* out, int ldo, int Kp, int cells,
                       hipStream_t s);
+void launch_embed_f32(const float* patches, int c_img, const int* src_chan, int C, const float* w, const float* bias, const float* pos,
+                      float* z, int ldz, int D, int cells, hipStream_t s);
 void launch_cls_rows(float* z, int ldz, const float* cls, const float* pos, int D, int cells, hipStream_t s);
 void launch_head_softmax(const float* z, int ldz, const float* gamma, const float* beta, const float* hw, const float* hb,
                          float* probs, int D, int K, int cells, hipStream_t s);
@@ -58,6 +60,15 @@ struct PatchArgs {
   int n;
 };
 void launch_extract_patches(const PatchArgs& a, hipStream_t s);
+
+// ----- whole-image normalisation (normalize.hip) ---------------------------------------------------------------
+void launch_u16_to_f32(const uint16_t* in, float* out, long long n, hipStream_t s);
+void launch_gauss1d(const float* in, float* out, int planes, int H, int W, int axis, const double* w, int R, int mode, hipStream_t s);
+void launch_bg_subtract(float* x, const float* bg, long long n, float cap, hipStream_t s);
+void launch_plane_max(const float* x, int planes, long long hw, float* out, hipStream_t s);
+void launch_radix_hist(const float* x, int planes, long long hw, const unsigned int* prefix, unsigned int mask_hi, int shift, int bits,
+                       unsigned int* hist, hipStream_t s);
+void launch_norm_finalize(float* x, int planes, long long hw, const int* mode, const float* clip, const float* denom, hipStream_t s);
 
 // ----- vote (vote.hip) -----------------------------------------------------------------------------------------
 struct VoteArgs {

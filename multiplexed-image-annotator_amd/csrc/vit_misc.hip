@@ -92,6 +92,79 @@ void launch_im2col_ps(const float* patches, int c_img, const int* src_chan, int 
                      total);
 }
 
+// Patch embedding in plain fp32 (timm PatchEmbed: Conv2d(C, D, k=4, s=4), model.py:47):
+//   z[cell*101 + 1 + t][n] = sum_{c,ky,kx} W[n][c][ky][kx] * x[cell][src[c]][4py+ky][4px+kx] + bias[n] + pos[1+t][n]
+// It is 1-2 % of the FLOPs but feeds the first LayerNorm directly: background tokens embed to ~pos_embed (|z| ~ 0.02) by
+// cancellation of O(1) terms, and LayerNorm rescales that row to unit variance, so a 2^-16-relative product error
+// (bf16x3) is amplified ~50x there.  fp32 FMA keeps this stage at the reference's own precision.
+// Classic 64x64 LDS-tiled SGEMM, one input channel (16 taps) per K step, im2col done on the fly from the fp32 patches.
+__global__ __launch_bounds__(256) void embed_f32_kernel(const float* __restrict__ patches, int c_img, const int* __restrict__ src_chan,
+                                                        int C, const float* __restrict__ w /*[D][C*16]*/, const float* __restrict__ bias,
+                                                        const float* __restrict__ pos, float* __restrict__ z, int ldz, int D, int M) {
+  __shared__ float As[16][64 + 4];  // [k][row]
+  __shared__ float Ws[16][64 + 4];  // [k][col]
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;  // 16 x 16 threads, 4 x 4 outputs each
+  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  // staging: thread -> (row = tid>>2, ky = tid&3) loads 4 kx for A; (col = tid>>2, 4 taps) for W
+  const int srow = tid >> 2, sq = tid & 3;
+  const int gm = m0 + srow;
+  const bool a_ok = gm < M;
+  const int cell = a_ok ? gm / 100 : 0;
+  const int t = a_ok ? gm - cell * 100 : 0;
+  const int py = t / 10, px = t - py * 10;
+  const float* abase = patches + ((size_t)cell * c_img * 40 + (4 * py + sq)) * 40 + 4 * px;  // + src*1600
+  const int gn = n0 + srow;
+  const bool w_ok = gn < D;
+  const float* wbase = w + (size_t)(w_ok ? gn : 0) * (C * 16) + sq * 4;
+  float acc[4][4] = {};
+  for (int c = 0; c < C; ++c) {
+    const int sc = src_chan[c];
+    float4 av = {0.f, 0.f, 0.f, 0.f};
+    if (a_ok) {
+      if (sc < 0) av = float4{-1.f, -1.f, -1.f, -1.f};
+      else av = *reinterpret_cast<const float4*>(abase + (size_t)sc * 1600);
+    }
+    float4 wv = {0.f, 0.f, 0.f, 0.f};
+    if (w_ok) wv = *reinterpret_cast<const float4*>(wbase + c * 16);
+    __syncthreads();
+    As[sq * 4 + 0][srow] = av.x; As[sq * 4 + 1][srow] = av.y; As[sq * 4 + 2][srow] = av.z; As[sq * 4 + 3][srow] = av.w;
+    Ws[sq * 4 + 0][srow] = wv.x; Ws[sq * 4 + 1][srow] = wv.y; Ws[sq * 4 + 2][srow] = wv.z; Ws[sq * 4 + 3][srow] = wv.w;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float4 a4 = *reinterpret_cast<const float4*>(&As[k][ty * 4]);
+      const float4 b4 = *reinterpret_cast<const float4*>(&Ws[k][tx * 4]);
+      const float a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+  }
+  const int n = n0 + tx * 4;
+  if (n >= D) return;
+  const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    if (m >= M) continue;
+    const int cl = m / 100, tt = m - cl * 100;
+    const float4 pe = *reinterpret_cast<const float4*>(pos + (size_t)(1 + tt) * D + n);
+    float4 o;
+    o.x = acc[i][0] + bv.x + pe.x; o.y = acc[i][1] + bv.y + pe.y; o.z = acc[i][2] + bv.z + pe.z; o.w = acc[i][3] + bv.w + pe.w;
+    *reinterpret_cast<float4*>(z + ((size_t)cl * kTokens + 1 + tt) * ldz + n) = o;
+  }
+}
+
+void launch_embed_f32(const float* patches, int c_img, const int* src_chan, int C, const float* w, const float* bias, const float* pos,
+                      float* z, int ldz, int D, int cells, hipStream_t s) {
+  const int M = cells * 100;
+  if (M <= 0) return;
+  hipLaunchKernelGGL(embed_f32_kernel, dim3((M + 63) / 64, (D + 63) / 64), dim3(256), 0, s, patches, c_img, src_chan, C, w, bias, pos, z,
+                     ldz, D, M);
+}
+
 // z[cell*101 + 0][:] = cls_token + pos_embed[0]   (model.py:49-51)
 __global__ void cls_rows_kernel(float* __restrict__ z, int ldz, const float* __restrict__ cls, const float* __restrict__ pos, int D,
                                 int cells) {

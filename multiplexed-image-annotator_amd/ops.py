@@ -129,6 +129,124 @@ def extract_patches(image: torch.Tensor, mask: torch.Tensor, chan_min: torch.Ten
     return out, avg
 
 
+# ------------------------------------------------------------------------------------------- whole-image normalisation
+def _gauss_weights(sigma: float) -> np.ndarray:
+    """Taps at distance 0..R of scipy.ndimage.gaussian_filter(sigma, truncate=4.0), computed as scipy computes them."""
+    sd = float(sigma)
+    radius = int(4.0 * sd + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sd * sd) * x ** 2)
+    phi = phi / phi.sum()
+    return np.ascontiguousarray(phi[radius:])
+
+
+def gaussian_filter_f32(x: torch.Tensor, sigma: float, tmp: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                        mode: str = "reflect") -> torch.Tensor:
+    """scipy.ndimage.gaussian_filter(x, sigma) on (C, H, W) fp32 planes: axis 0 pass then axis 1 pass, bit-identical."""
+    assert x.dtype == torch.float32 and x.is_cuda and x.dim() == 3
+    c, h, w = x.shape
+    taps = torch.from_numpy(_gauss_weights(sigma)).to(x.device)
+    r = taps.numel() - 1
+    tmp = torch.empty_like(x) if tmp is None else tmp
+    out = torch.empty_like(x) if out is None else out
+    md = {"reflect": 0, "nearest": 1}[mode]
+    check(lib().ribca_gauss1d(ptr(x), ptr(tmp), c, h, w, 0, ptr(taps), r, md, stream_ptr()), "ribca_gauss1d")
+    check(lib().ribca_gauss1d(ptr(tmp), ptr(out), c, h, w, 1, ptr(taps), r, md, stream_ptr()), "ribca_gauss1d")
+    return out
+
+
+def _order_statistics(x: torch.Tensor, ranks: np.ndarray) -> np.ndarray:
+    """Exact k-th smallest value (0-based rank per plane) of non-negative fp32 planes (C, H, W) by a 3-pass radix select
+    (11 + 11 + 10 key bits).  The histograms are built on the GPU; the host only walks 2048-bin prefix sums."""
+    c = x.shape[0]
+    hw = x.shape[1] * x.shape[2]
+    dev = x.device
+    hist = torch.empty((c, 2048), dtype=torch.int32, device=dev)
+    prefix = np.zeros(c, dtype=np.uint32)
+    remaining = np.asarray(ranks, dtype=np.int64).copy()
+    mask_hi = 0
+    for shift, bits in ((21, 11), (10, 11), (0, 10)):
+        pre_d = torch.from_numpy(prefix.view(np.int32).copy()).to(dev)
+        check(lib().ribca_radix_hist(ptr(x), c, hw, ptr(pre_d), mask_hi, shift, bits, ptr(hist), stream_ptr()), "ribca_radix_hist")
+        h = hist.cpu().numpy().astype(np.int64)
+        cum = np.cumsum(h, axis=1)
+        for p in range(c):
+            b = int(np.searchsorted(cum[p], remaining[p], side="right"))
+            remaining[p] -= cum[p, b - 1] if b > 0 else 0
+            prefix[p] |= np.uint32(b << shift)
+        mask_hi |= ((1 << bits) - 1) << shift
+    return prefix.view(np.float32).copy()
+
+
+def _percentile_plan(n: int, amax):
+    """The two sorted-array indexes np.percentile(x, amax) (method 'linear', fp32 data of n values) interpolates between,
+    and its fp32 interpolation weight -- obtained by running numpy's own index/gamma helpers, so dtypes and rounding are
+    numpy's whatever its version.  Returns (prev, next, gamma) with prev == next and gamma None when no interpolation."""
+    from numpy.lib import _function_base_impl as fb
+    q = np.asanyarray(np.true_divide(amax, np.float32(100)))     # np.percentile divides by a.dtype.type(100) for float data
+    virtual = np.asanyarray(fb._QuantileMethods["linear"]["get_virtual_index"](n, q))
+    if np.issubdtype(virtual.dtype, np.integer):
+        return int(virtual), int(virtual), None
+    prev, nxt = fb._get_indexes(np.empty((0,), dtype=np.float32), virtual, n)
+    gamma = fb._get_gamma(virtual, prev, fb._QuantileMethods["linear"])
+    return int(prev) % n, int(nxt) % n, gamma
+
+
+def _percentile_like_numpy(n: int, amax, lo_hi_getter):
+    """np.percentile of one fp32 plane given a callable returning its exact order statistics (prev, next)."""
+    from numpy.lib import _function_base_impl as fb
+    prev, nxt, gamma = _percentile_plan(n, amax)
+    a, b = lo_hi_getter(np.array([prev]), np.array([nxt]))
+    return np.float32(a) if gamma is None else fb._lerp(np.float32(a), np.float32(b), gamma)
+
+
+def normalize_image(raw, blur=0, amax=100) -> torch.Tensor:
+    """ImageProcessor._normalize (reference preprocess.py:214-239) on the GPU, bit-identical to the CPU path.
+    ``raw``: (C, H, W) numpy array or torch tensor of any real dtype; returns a fp32 CUDA tensor in [-1, 1]."""
+    from numpy.lib import _function_base_impl as fb
+    dev = _lib.require_gpu()
+    if isinstance(raw, np.ndarray):
+        if raw.dtype == np.uint16:
+            src = torch.from_numpy(np.ascontiguousarray(raw).view(np.int16)).to(dev)
+            img = torch.empty(raw.shape, dtype=torch.float32, device=dev)
+            check(lib().ribca_u16_to_f32(ptr(src), ptr(img), src.numel(), stream_ptr()), "ribca_u16_to_f32")
+        else:
+            img = torch.from_numpy(raw.astype(np.float32)).to(dev)
+    else:
+        img = raw.to(device=dev, dtype=torch.float32).contiguous().clone()
+    c, h, w = img.shape
+    hw = h * w
+    tmp = torch.empty_like(img)
+    bg = gaussian_filter_f32(img, 20, tmp=tmp)
+    check(lib().ribca_bg_subtract(ptr(img), ptr(bg), img.numel(), 125.0, stream_ptr()), "ribca_bg_subtract")
+    if blur:
+        blurred = gaussian_filter_f32(img, blur, tmp=tmp, out=bg)
+        img, bg = blurred, img
+    mx_d = torch.empty(c, dtype=torch.float32, device=dev)
+    check(lib().ribca_plane_max(ptr(img), c, hw, ptr(mx_d), stream_ptr()), "ribca_plane_max")
+    mx = mx_d.cpu().numpy()
+    mode = np.zeros(c, np.int32)                 # 0: no positive pixel -> plane of -1
+    clip = np.full(c, np.inf, np.float32)
+    denom = np.ones(c, np.float32)
+    sel = np.flatnonzero(mx > 0)
+    if sel.size:
+        prev, nxt, gamma = _percentile_plan(hw, amax)
+        planes = img[torch.from_numpy(sel).to(dev)] if sel.size < c else img
+        lo = _order_statistics(planes, np.full(sel.size, prev))
+        hi = lo if nxt == prev else _order_statistics(planes, np.full(sel.size, nxt))
+        for j, p in enumerate(sel):
+            t = np.float32(lo[j]) if gamma is None else fb._lerp(np.float32(lo[j]), np.float32(hi[j]), gamma)
+            m = np.float32(mx[p])
+            if t > 20:                            # preprocess.py:234-235
+                clip[p] = t
+                m = min(m, np.float32(t))
+            mode[p] = 1
+            denom[p] = max(25, m)                 # preprocess.py:238
+    check(lib().ribca_norm_finalize(ptr(img), c, hw, ptr(torch.from_numpy(mode).to(dev)), ptr(torch.from_numpy(clip).to(dev)),
+                                    ptr(torch.from_numpy(denom).to(dev)), stream_ptr()), "ribca_norm_finalize")
+    return img
+
+
 # ------------------------------------------------------------------------------------------- ViT
 class VitModel:
     """One packed classifier on one device (replaces a timm ``VisionTransformer`` instance of reference

@@ -119,7 +119,7 @@ def test_qkv_attention(dev, d):
     m = cells * ntok
     dp = (d + 31) // 32 * 32
     y = rnd((m, d), 12, dev)
-    w = rnd((3 * d, d), 13, dev, 2.0 / np.sqrt(d))
+    w = rnd((3 * d, d), 13, dev, 1.0 / np.sqrt(d))   # q, k ~ N(0,1): scores O(1) like a trained ViT
     bias = rnd((3 * d,), 14, dev, 0.1)
     y_ps = ps_encode(y, dp)
     w_ps = ps_encode(w, dp, lib().ribca_gemm_padded_n(3 * d))
@@ -134,18 +134,20 @@ def test_qkv_attention(dev, d):
     # intermediate layouts first (localises a failure): Q rows pre-scaled, K rows, V transposed + key-permuted
     qd = ps_decode(q.reshape(-1, 2 * hdp), hdp).reshape(cells, heads, 112, hdp)
     kd = ps_decode(k.reshape(-1, 2 * hdp), hdp).reshape(cells, heads, 112, hdp)
-    assert (qd[:, :, :ntok, :hd] - qq * hd ** -0.5).abs().max().item() < 5e-5
-    assert (kd[:, :, :ntok, :hd] - kk).abs().max().item() < 5e-5
+    def close(got, ref):   # stored as hi+lo bf16 (2^-16 relative) + GEMM error ~ sqrt(K) * 2^-16 * |a||w| (4-sigma over 5e5 outputs)
+        return bool(torch.all((got - ref).abs() <= ref.abs() * 2.0 ** -15 + 1e-4))
+    assert close(qd[:, :, :ntok, :hd], qq * hd ** -0.5)
+    assert close(kd[:, :, :ntok, :hd], kk)
     assert torch.all(qd[:, :, ntok:] == 0) and torch.all(qd[..., hd:] == 0)
     t = torch.arange(128)
     pos = (t & ~31) | (((t >> 2) & 3) << 3) | (((t >> 4) & 1) << 2) | (t & 3)
     vd = ps_decode(vt.reshape(-1, 256), 128).reshape(cells, heads, hdv, 128)
     vd_nat = vd[..., pos.to(dev)]          # natural key order
-    assert (vd_nat[:, :, :hd, :ntok] - vv.transpose(-1, -2)).abs().max().item() < 5e-5
+    assert close(vd_nat[:, :, :hd, :ntok], vv.transpose(-1, -2))
     att = torch.softmax((qq * hd ** -0.5) @ kk.transpose(-1, -2), dim=-1)
     ref = (att @ vv).transpose(1, 2).reshape(m, d)
     err = (ps_decode(out, d) - ref).abs().max().item()
-    assert err < 1e-4, err
+    assert err < 2e-4, err     # |out| <~ 5; softmax of O(10) scores amplifies the 2^-16 operand error a few times
     assert torch.all(ps_decode(out, dp)[:, d:] == 0)
 
 
@@ -299,3 +301,46 @@ def test_vote_golden(dev, golden_dir):
         np.testing.assert_array_equal(conf.cpu().numpy(), arrs[key + "__conf"])
         n_checked += 1
     assert n_checked == 44
+
+
+# ------------------------------------------------------------------------------------------- whole-image normalisation
+@pytest.mark.parametrize("key,src,blur,amax", [
+    ("a_out_blur0", "a_in", 0, 99.8), ("a_out_blur0.3", "a_in", 0.3, 99.8), ("a_out_blur0.5", "a_in", 0.5, 99.8),
+    ("a_out_blur1", "a_in", 1, 99.8), ("a_out_amax100", "a_in", 0, 100), ("b_out_blur0.3", "b_in", 0.3, 99.8),
+    ("c_out_blur0", "c_in", 0, 99.8)])
+def test_normalize_golden(dev, golden_dir, key, src, blur, amax):
+    ops = _ops()
+    g = np.load(os.path.join(golden_dir, "normalize.npz"))
+    got = ops.normalize_image(g[src], blur=blur, amax=amax).cpu().numpy()
+    np.testing.assert_array_equal(got, g[key])      # same operations in the same order and precision as scipy / numpy
+
+
+def test_gaussian_filter_matches_scipy(dev):
+    from scipy.ndimage import gaussian_filter
+    ops = _ops()
+    x = (rnd((2, 70, 45), 31, dev).abs() * 100).contiguous()
+    for sigma, mode in ((20, "reflect"), (0.3, "reflect"), (2, "nearest"), (1, "reflect")):
+        got = ops.gaussian_filter_f32(x, sigma, mode=mode).cpu().numpy()
+        ref = np.stack([gaussian_filter(p, sigma, mode=mode) for p in x.cpu().numpy()])
+        np.testing.assert_array_equal(got, ref)
+
+
+def test_order_statistics_exact(dev):
+    ops = _ops()
+    x = (rnd((3, 211, 97), 32, dev).abs() * 1000).contiguous()
+    x[1] = torch.floor(x[1] / 100)            # many ties
+    x[2, :100] = 0
+    n = 211 * 97
+    xs = np.sort(x.cpu().numpy().reshape(3, -1), axis=1)
+    for rank in (0, 1, n // 2, n - 2, n - 1, 12345):
+        got = ops._order_statistics(x, np.full(3, rank))
+        np.testing.assert_array_equal(got, xs[:, rank])
+
+
+def test_normalize_large_matches_oracle(dev):
+    from oracle import ref_preprocess
+    ops = _ops()
+    _, img = synth.make_mask_and_image(700, 900, 2500, 3, 77)
+    raw = img.numpy().astype(np.uint16)
+    got = ops.normalize_image(raw, blur=0.3, amax=99.8).cpu().numpy()
+    np.testing.assert_array_equal(got, ref_preprocess.normalize_image(raw, blur=0.3, amax=99.8))
