@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: cells/sec annotated on a synthetic 15-channel 4096x4096 tile with 100k cells, Full Panel,
+all five ViT classifiers per cell (BASELINE.json configs[2]; with --gpus N>1 the same tile's cells are sharded across
+ranks with one RCCL all-gather of the per-cell probabilities = configs[3]).
+
+One step = one pass of the hot path over the tile, inputs (uint16 image, int32 mask, packed weights) resident in HBM:
+normalise -> label table -> per-cell crop / soft mask -> 5 x (patch-embed, 12 blocks, head, softmax) -> vote -> labels
+on the host.  Prints ONE JSON line (rank 0).  ``roofline`` is measured live with HIP events around every GEMM launch of
+one extra (untimed) profiled pass; ``cpu_baseline`` times the CPU oracle on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_BF16_DENSE_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cells", type=int, default=100000)
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--channels", type=int, default=15)
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("RIBCA_CHUNK_CELLS", "256")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as tdist
+        torch.cuda.set_device(local_rank)
+        tdist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    if world > 1:
+        tdist.barrier()
+    from multiplexed_image_annotator_amd import _lib, dist, ops, synth
+    from multiplexed_image_annotator_amd.annotator import CLASS_NAMES
+    from multiplexed_image_annotator_amd.marker_parse import PANELS
+    dev = _lib.require_gpu()
+    seed = synth.SEED_BASE + 3
+
+    # ---- synthetic inputs, generated on the device (bit-identical on every rank) ------------------------------------
+    mask, img = synth.make_mask_and_image(args.size, args.size, args.cells, args.channels, seed, device=dev)
+    raw = img.to(torch.int16)            # uint16 bit pattern (values < 65536)
+    del img
+    markers = synth.FULL_PANEL_MARKERS[:args.channels]
+    models, srcs = {}, {}
+    for name, (d, c, k) in synth.VIT_CONFIGS.items():
+        if c > args.channels:
+            continue
+        models[name] = ops.VitModel(synth.make_vit_state_dict(name, seed), dev)
+        panel = {"immune_base": "immune_base", "immune_extended": "immune_extended", "immune_full": "immune_full"}.get(name)
+        if panel and all(m in markers for m in PANELS[panel]):
+            srcs[name] = [markers.index(m) for m in PANELS[panel]]
+        else:
+            srcs[name] = list(range(c))  # struct / nerve markers are not in a 15-marker immune panel: fixed synthetic mapping
+    flops_cell = sum(m.flops_per_cell for m in models.values())
+    gid = {n: i for i, n in enumerate(ops.GLOBAL_NAMES)}
+    tc = [-1.0] * 18
+    vote_pair = ("immune_full", "struct") if "immune_full" in models and "struct" in models else (next(iter(models)), None)
+
+    def one_pass():
+        image = ops.normalize_image(raw, blur=0.3, amax=99.8)
+        ids, tab = ops.label_table(mask)
+        n = len(ids)
+        lo, hi = dist.shard_bounds(n, rank, world)
+        cmin = ops.channel_min(image)
+        ids_d = torch.from_numpy(ids[lo:hi].astype(np.int32)).to(dev)
+        bb_d = torch.from_numpy(tab[lo:hi, :4].astype(np.int32)).to(dev)
+        patches, _ = ops.extract_patches(image, mask, cmin, ids_d, bb_d)
+        probs = {}
+        for name, model in models.items():
+            local = model.predict_proba(patches, srcs[name], chunk_cells=args.chunk)
+            probs[name] = dist.all_gather_rows(local, n) if world > 1 else local
+        a, b = vote_pair
+        lab, conf = ops.vote(probs[a], [gid[c] for c in CLASS_NAMES[a]], probs[b] if b else None,
+                             [gid[c] for c in CLASS_NAMES[b]] if b else None, tc, 0.3)
+        return n, lab.cpu(), conf.cpu()
+
+    def sync_all():
+        if world > 1:
+            tdist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_pass()
+    sync_all()
+    t0 = time.perf_counter()
+    n_cells = 0
+    for _ in range(args.steps):
+        n_cells, lab, conf = one_pass()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = n_cells * args.steps / dt
+
+    out = {
+        "metric": "cells/sec annotated (whole node)", "value": round(value, 2), "unit": "cells/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"synthetic {args.channels}-ch {args.size}x{args.size} tile, {n_cells} cells, Full Panel, "
+                               f"{len(models)} ViT classifiers per cell (normalise + label table + crop/soft-mask + ViT + vote)",
+                   "cells": n_cells, "models": list(models), "chunk_cells": args.chunk, "precision": "bf16x3 split MFMA, fp32 accumulate",
+                   "parallelism": f"cells sharded over {world} rank(s), all-gather of per-cell probabilities" if world > 1 else "single GPU"},
+        "vit_gflop_per_cell": round(flops_cell / 1e9, 4),
+        "vit_mfma_util_vs_bf16_dense": round(value * flops_cell / (world * PEAK_BF16_DENSE_TFLOPS * 1e12), 5),
+    }
+
+    # ---- roofline of the dominant kernel (the bf16x3 GEMM family), one extra profiled pass -----------------------------
+    if not args.no_roofline and rank == 0:
+        ops.prof_enable(True)
+        one_pass()
+        torch.cuda.synchronize()
+        prof = ops.prof_read()
+        ops.prof_enable(False)
+        lo, hi = dist.shard_bounds(n_cells, rank, world)
+        n_local = hi - lo
+        gemm_flops = 0.0
+        for name, model in models.items():
+            d = model.D
+            gemm_flops += n_local * model.depth * 24.0 * 101 * d * d          # qkv + proj + fc1 + fc2 (algorithmic, unpadded)
+        g_ms = sum(prof[k][0] for k in ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2"))
+        g_n = sum(prof[k][1] for k in ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2"))
+        achieved = gemm_flops / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_ps_kernel (qkv/proj/fc1/fc2, bf16x3)", "achieved": round(achieved, 2),
+                           "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 5),
+                           "traffic": None, "launches": int(g_n), "avg_launch_ms": round(g_ms / max(g_n, 1), 5),
+                           "algorithmic_gflop_per_launch": round(gemm_flops / max(g_n, 1) / 1e9, 4), "mfma_passes_per_product": 3,
+                           "per_kernel_ms": {k: round(v[0], 3) for k, v in prof.items() if v[1]}}
+
+    # ---- CPU baseline: the oracle (numpy/scipy/torch fp32 restatement of the reference path) on a bounded sample ------------
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args, raw, mask, markers, seed, n_cells)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        tdist.destroy_process_group()
+
+
+def cpu_baseline(args, raw_dev, mask_dev, markers, seed, n_cells):
+    """kind 'port': oracle/ on the host cores.  Sample: normalise + label scan on a 1024x1024 corner of the same tile (scaled by
+    area), crop/soft-mask + the same five ViTs on 48 of its cells; per-cell times are combined into end-to-end cells/s."""
+    from multiplexed_image_annotator_amd import synth
+    from oracle import ref_preprocess as rp, ref_vit
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    side = min(1024, args.size)
+    raw = raw_dev[:, :side, :side].cpu().numpy().view(np.uint16)
+    mask = mask_dev[:side, :side].cpu().numpy()
+    area_scale = (args.size * args.size) / float(side * side)
+    t = time.perf_counter()
+    image = rp.normalize_image(raw, blur=0.3, amax=99.8)
+    t_norm = (time.perf_counter() - t) * area_scale
+    t = time.perf_counter()
+    ids, tab = rp.cell_table(mask)
+    t_label = (time.perf_counter() - t) * area_scale
+    k = min(48, len(ids))
+    sel = np.linspace(0, len(ids) - 1, k).astype(int)
+    t = time.perf_counter()
+    patches, _ = rp.patches_for_panel(image, mask, list(range(raw.shape[0])), ids[sel], tab[sel], want_intensity=False)
+    t_crop = (time.perf_counter() - t) / k
+    x = torch.from_numpy(patches)
+    t_vit = 0.0
+    n_models = 0
+    for name, (d, c, kk) in synth.VIT_CONFIGS.items():
+        if c > raw.shape[0]:
+            continue
+        sd = synth.make_vit_state_dict(name, seed)
+        t = time.perf_counter()
+        ref_vit.predict_proba(sd, x[:, :c], 48)
+        t_vit += (time.perf_counter() - t) / k
+        n_models += 1
+    per_cell = (t_norm + t_label) / n_cells + n_models * t_crop + t_vit     # the reference crops once per applicable panel
+    return {"value": round(1.0 / per_cell, 3), "unit": "cells/s", "cores": threads, "kind": "port",
+            "sample": f"oracle on a {side}x{side} corner: normalise+label scan scaled by area to the full tile ({t_norm:.1f}s+{t_label:.2f}s), "
+                      f"crop/soft-mask {t_crop*1e3:.2f} ms/cell/panel (1 thread, as the reference) and {n_models} fp32 ViTs "
+                      f"{t_vit*1e3:.1f} ms/cell ({threads} threads, batch 48) on {k} cells"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,303 @@
+"""``Annotator``: drop-in for the reference orchestrator on its hot path (cell_type_annotation/model.py:90-919):
+same constructor, ``preprocess()``, ``predict(batch_size)``, ``export_annotations()``, ``clear_tmp()``,
+``get_cell_type_names()`` and the attributes downstream code reads (``annotations``, ``confidence``, ``annotations_all``,
+``cell_types``, ``channel_parser``, ``preprocessor``, ``*_pred``).  Compute runs in the HIP library; post-analysis / plotting
+methods of the reference are outside the accelerated path and raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, dist, ops
+from .logger import Logger
+from .marker_parse import MarkerParser
+from .preprocess import ImageProcessor
+
+#: per-model class order (model.py:247-252, 266-270, 284-287, 309-312, 334)
+CLASS_NAMES: Dict[str, List[str]] = {
+    "immune_full": ["CD4 T cell", "CD8 T cell", "Dendritic cell", "B cell", "M1 macrophage cell", "M2 macrophage cell",
+                    "Regulatory T cell", "Granulocyte cell", "Plasma cell", "Natural killer cell", "Mast cell", "Others"],
+    "immune_extended": ["CD4 T cell", "CD8 T cell", "Dendritic cell", "B cell", "M1 macrophage cell", "M2 macrophage cell",
+                        "Natural killer cell", "Others"],
+    "immune_base": ["B cell", "CD4 T cell", "CD8 T cell", "Others", "Dendritic cell"],
+    "struct": ["Stroma cell", "Smooth muscle", "Endothelial cell", "Epithelial cell", "Proliferating/tumor cell", "Others"],
+    "nerve": ["Nerve cell", "Others"],
+}
+#: model name -> (parser panel name, checkpoint file under MODEL_DIR)
+MODEL_PANEL = {"immune_base": "immune_base", "immune_extended": "immune_extended", "immune_full": "immune_full",
+               "struct": "structure", "nerve": "nerve_cell"}
+MODEL_DIR = "src/multiplexed_image_annotator/cell_type_annotation/models"   # CWD-relative, as in model.py:189-231
+_GID = {name: i for i, name in enumerate(ops.GLOBAL_NAMES)}
+
+
+class _LazyPredictions:
+    """list of {cell type: probability} dicts (model.py:412-414) built on first access from the (n, K) table."""
+
+    def __init__(self, model: str, probs: np.ndarray):
+        self.model, self.probs, self._dicts = model, probs, None
+
+    def _get(self):
+        if self._dicts is None:
+            names = CLASS_NAMES[self.model]
+            self._dicts = [{names[i]: row[i] for i in range(len(row))} for row in self.probs]
+        return self._dicts
+
+    def __len__(self):
+        return len(self.probs)
+
+    def __getitem__(self, i):
+        return self._get()[i]
+
+    def __iter__(self):
+        return iter(self._get())
+
+
+class Annotator(object):
+    def __init__(self, marker_list_path, image_path, device, main_dir='./', batch_id='', strict=True, infer=True, min_cells=-1,
+                 normalize=True, blur=False, amax=1, confidence=0.25, cell_size=30, cell_type_confidence=None, n_jobs=0):
+        self.device = device
+        self.cell_types = ["B cell", "CD4 T cell", "CD8 T cell", "Dendritic cell", "Regulatory T cell", "Granulocyte cell", "Mast cell",
+                           "M1 macrophage cell", "M2 macrophage cell", "Natural killer cell", "Plasma cell", "Endothelial cell",
+                           "Epithelial cell", "Stroma cell", "Smooth muscle", "Proliferating/tumor cell", "Nerve cell", "Others"]
+        self.batch_id = batch_id
+        self.rank, self.world_size = dist.world()
+        log_dir = main_dir if self.rank == 0 else os.path.join(main_dir, f".rank{self.rank}")
+        os.makedirs(log_dir, exist_ok=True)
+        self.logger = Logger(log_dir)
+        self.logger.log_all_hyperparameters({
+            "Batch name": batch_id, "Strictly match panel(s)": strict, "Normalize image(s)": normalize,
+            "Image blurring kernel size": blur, "Percentile of intensity to upper clip": amax, "Confidence threshold": confidence,
+            "Estimated cell size (in pixels)": cell_size})
+        self.logger.log("")
+        self.logger.log("Start parsing the marker list.")
+        self.channel_parser = MarkerParser(strict=strict, logger=self.logger)
+        self.channel_parser.parse(marker_list_path)
+        self.preprocessor = ImageProcessor(image_path, self.channel_parser, log_dir, device, batch_id, infer, normalize, blur, amax,
+                                           cell_size, self.logger, n_jobs=n_jobs)
+        self._loaded = False
+        self.n_jobs = n_jobs
+        self._n_images = 0
+        self.min_cells = min_cells
+        self.infer = infer
+        self.annotations: List[List[str]] = []
+        self.confidence: List[list] = []
+        self.immune_annotations, self.struct_annotations, self.nerve_annotations = [], [], []
+        self.immune_base_pred, self.immune_extended_pred, self.immune_full_pred = [], [], []
+        self.struct_pred, self.nerve_pred = [], []
+        self.confidence_thresh = confidence
+        self.extra_cell_types = self.min_cells > 0
+        if self.extra_cell_types:
+            raise NotImplementedError("min_cells > 0 (UMAP/HDBSCAN re-clustering of 'Others', model.py:642-675) is post-analysis "
+                                      "outside the accelerated hot path")
+        self.n_regions = 0
+        self.temp_dir = os.path.join(log_dir, "tmp")
+        self.result_dir = os.path.join(main_dir, "results")
+        os.makedirs(self.result_dir, exist_ok=True)
+        if cell_type_confidence is None:
+            self.cell_type_confidence = {name: -1 for name in self.cell_types}
+        else:
+            self.cell_type_confidence = cell_type_confidence
+        self.models: Dict[str, ops.VitModel] = {}
+        self._weights: Dict[str, Dict[str, torch.Tensor]] = {}
+        self.probs: List[Dict[str, np.ndarray]] = []       # per image: model -> (n, K) fp32 host table
+        self.label_ids: List[np.ndarray] = []
+        self.chunk_cells = int(os.environ.get("RIBCA_CHUNK_CELLS", "256"))
+
+    # ---- weights ---------------------------------------------------------------------------------------------------
+    def set_weights(self, weights: Dict[str, Dict[str, torch.Tensor]]) -> None:
+        """Provide state dicts directly (timm key names) instead of the CWD-relative ``.pth`` files."""
+        self._weights.update(weights)
+
+    def load_models(self):
+        """model.py:188-239: every checkpoint that exists is loaded; a missing one is reported and skipped."""
+        dev = _lib.require_gpu()
+        for name in ("immune_base", "immune_extended", "immune_full", "struct", "nerve"):
+            sd = self._weights.get(name)
+            path = os.path.join(MODEL_DIR, name + ".pth")
+            if sd is None and os.path.exists(path):
+                sd = torch.load(path, map_location="cpu", weights_only=False)["model"]
+            if sd is None:
+                msg = {"immune_base": "Immune base", "immune_extended": "Immune extended", "immune_full": "Immune full",
+                       "struct": "Tissue structure", "nerve": "Nerve cell"}[name] + " model not found"
+                print(msg)
+                self.logger.log(msg)
+                continue
+            self.models[name] = ops.VitModel(sd, dev)
+        self._loaded = True
+
+    # ---- pipeline --------------------------------------------------------------------------------------------------
+    def preprocess(self):
+        rank, ws = self.rank, self.world_size
+        self.preprocessor.transform(shard_fn=(lambda n: dist.shard_bounds(n, rank, ws)) if ws > 1 else None,
+                                    gather_fn=(lambda t, n: dist.all_gather_rows(t, n)) if ws > 1 else None)
+        self._n_images = self.preprocessor._n_images
+
+    def clear(self):
+        self.immune_base_pred, self.immune_extended_pred, self.immune_full_pred = [], [], []
+        self.struct_pred, self.nerve_pred = [], []
+        self.annotations = []
+
+    def _active_models(self) -> Dict[str, Optional[str]]:
+        """model.py:241-349: one immune model (full > extended > base) plus struct / nerve when their panels apply."""
+        p = self.channel_parser
+        immune = "immune_full" if p.immune_full else ("immune_extended" if p.immune_extended else ("immune_base" if p.immune_base else None))
+        return {"immune": immune, "struct": "struct" if p.struct else None, "nerve": "nerve" if p.nerve else None}
+
+    def _predict_cell_types(self, image_idx, model_name, batch_size=None) -> np.ndarray:
+        """softmax(model(x), dim=1) for this rank's cells of one image, all-gathered to the full (n, K) table."""
+        pre = self.preprocessor
+        model = self.models[model_name]
+        index = self.channel_parser.indices[MODEL_PANEL[model_name]]
+        n = len(pre.cell_ids[image_idx])
+        lo, hi = pre.shards[image_idx]
+        c_img = pre.images_dev[image_idx].shape[0]
+        if self.infer and -1 in index and model_name not in ("struct",):
+            raise NotImplementedError("marker imputation (infer=True with missing markers, markerImputer.py) is not on the GPU path yet; "
+                                      "pass infer=False to use blank planes like the reference does without imputer weights")
+        src = ops.resolve_channels(index, c_img)
+        patches = pre.panel_patches(image_idx)
+        local = model.predict_proba(patches, src, chunk_cells=self.chunk_cells)
+        full = dist.all_gather_rows(local, n) if self.world_size > 1 else local
+        return full
+
+    def predict(self, batch_size=32):
+        self.logger.log("\nStart predicting cell types and tissue structures.")
+        if not self._loaded:
+            self.load_models()
+        active = self._active_models()
+        for role, name in active.items():
+            if name is not None and name not in self.models:
+                raise AttributeError(f"'Annotator' object has no attribute '{name}_model'")   # what the reference ends up raising
+        dev = _lib.require_gpu()
+        tc = [self.cell_type_confidence[n] for n in ops.GLOBAL_NAMES]
+        for image_idx in range(self._n_images):
+            tables: Dict[str, torch.Tensor] = {}
+            for role in ("immune", "struct", "nerve"):
+                name = active[role]
+                if name is None:
+                    msg = {"immune": "No immune cell model to predict", "struct": "No structure model to predict",
+                           "nerve": "No nerve cell model to predict"}[role]
+                    print(msg)
+                    self.logger.log(msg)
+                    continue
+                tables[name] = self._predict_cell_types(image_idx, name, batch_size)
+            if not tables:
+                raise ValueError("No predictions to merge")
+            imm, st, nv = active["immune"], active["struct"], active["nerve"]
+            if imm == "immune_full" and st and nv:
+                raise KeyError("Others")       # reference branch 1 (model.py:483-510) fails exactly like this
+            if imm and st:
+                pair = (imm, st)
+            elif st and nv:
+                pair = (st, nv)
+            elif imm and nv:
+                pair = (imm, nv)
+            else:
+                pair = (imm or st or nv, None)
+            pa = tables[pair[0]]
+            pb = tables[pair[1]] if pair[1] else None
+            lab, conf = ops.vote(pa, [_GID[c] for c in CLASS_NAMES[pair[0]]], pb, [_GID[c] for c in CLASS_NAMES[pair[1]]] if pair[1] else None,
+                                 tc, self.confidence_thresh)
+            host = {k: v.cpu().numpy() for k, v in tables.items()}
+            self.probs.append(host)
+            for name, table in host.items():
+                lazy = _LazyPredictions(name, table)
+                if name.startswith("immune"):
+                    getattr(self, name + "_pred").append(lazy)
+                    self.immune_annotations.append(lazy)
+                elif name == "struct":
+                    self.struct_pred.append(lazy)
+                    self.struct_annotations.append(lazy)
+                else:
+                    self.nerve_pred.append(lazy)
+                    self.nerve_annotations.append(lazy)
+            lab_h = lab.cpu().numpy().astype(np.int64)
+            conf_h = conf.cpu().numpy()
+            self.label_ids.append(lab_h)
+            names = np.array(ops.GLOBAL_NAMES, dtype=object)
+            self.annotations.append(names[lab_h].tolist())
+            self.confidence.append([-1 if c == -1 else c for c in conf_h])    # int -1 marks a thresholded cell, as in model.py:507
+        self.logger.log("Finished predicting cell types and tissue structures.")
+        self.cell_types = self._get_unique_cell_types()
+        self.cell_types = np.delete(self.cell_types, np.where(self.cell_types == "Others"))
+        self.cell_types = np.append(self.cell_types, "Others")
+        self.colors = _spread_colors(len(self.cell_types))
+        self._annotations_all = None
+
+    def merge_by_voting(self):
+        raise NotImplementedError("voting is fused into predict() (HIP vote kernel); call predict()")
+
+    @property
+    def annotations_all(self):
+        """model.py:464-478, built on first access (it copies every cell's pixel lists)."""
+        if getattr(self, "_annotations_all", None) is None:
+            out = []
+            for i in range(len(self.annotations)):
+                pos = self.preprocessor.cell_pos_dict[i]
+                rows = []
+                for j, key in enumerate(pos.keys()):
+                    cell_type_int = np.where(self.cell_types == self.annotations[i][j])[0][0]
+                    r, c = pos[key]
+                    rows.append({"Cell ID": key, "Cell type": cell_type_int, "Confidence": self.confidence[i][j], "Row": r, "Column": c})
+                out.append(rows)
+            self._annotations_all = out
+        return self._annotations_all
+
+    def _get_unique_cell_types(self):
+        seen = set()
+        for per_image in self.annotations:
+            seen.update(per_image)
+        return np.sort(np.array(list(seen)))
+
+    def get_cell_type_names(self):
+        txt = ""
+        for i in range(len(self.cell_types)):
+            txt += f"{i+1}: {self.cell_types[i]}"
+            txt += "\n" if i % 3 == 2 else "  "
+        return txt
+
+    def export_annotations(self):
+        """model.py:768-795: same header, columns, rounding and number formatting."""
+        if len(self.annotations) == 0:
+            raise ValueError("No annotations to export")
+        if self.rank != 0:
+            return
+        for i in range(len(self.annotations)):
+            path = os.path.join(self.result_dir, f"{self.batch_id}_annotation_{i}.csv")
+            ids = self.preprocessor.cell_ids[i]
+            tab = self.preprocessor.cell_tables[i]
+            conf = self.confidence[i]
+            rows = np.round(tab[:, 4].astype(np.float64) / tab[:, 6].astype(np.float64), 2)
+            cols = np.round(tab[:, 5].astype(np.float64) / tab[:, 6].astype(np.float64), 2)
+            regions = getattr(self, "tissue_regions", None)
+            with open(path, "w") as f:
+                f.write("Cell Index,Cell Type,Confidence,Row,Column,Tissue Region\n")
+                lines = []
+                for j, key in enumerate(ids.tolist()):
+                    c = round(conf[j], 3)
+                    region = "Region " + str(regions[i][key]) if regions is not None else None
+                    lines.append(f"{key},{self.annotations[i][j]},{c},{rows[j]},{cols[j]},{region}\n")
+                f.write("".join(lines))
+            self.logger.log(f"Exported annotations for image {i} to {path}")
+
+    def clear_tmp(self):
+        for f in os.listdir(self.temp_dir):
+            os.remove(os.path.join(self.temp_dir, f))
+        os.rmdir(self.temp_dir)
+        self.logger.log("Temporary files cleared")
+
+    # ---- outside the accelerated path ------------------------------------------------------------------------------
+    def _out_of_scope(self, *_a, **_k):
+        raise NotImplementedError("post-analysis / plotting of the reference (heatmaps, UMAP, neighbourhood, tissue regions, colourised "
+                                  "masks) is CPU work downstream of the CSV and outside this accelerated hot path")
+
+    generate_heatmap = umap_visualization = neighborhood_analysis = tissue_region_analysis = colorize = cell_type_composition = _out_of_scope
+
+
+def _spread_colors(n: int):
+    import colorsys
+    return [[int(255 * v) for v in colorsys.hsv_to_rgb(i / max(n, 1), 0.65, 0.95)] for i in range(n)]

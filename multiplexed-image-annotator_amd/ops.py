@@ -212,6 +212,10 @@ def normalize_image(raw, blur=0, amax=100) -> torch.Tensor:
             check(lib().ribca_u16_to_f32(ptr(src), ptr(img), src.numel(), stream_ptr()), "ribca_u16_to_f32")
         else:
             img = torch.from_numpy(raw.astype(np.float32)).to(dev)
+    elif raw.dtype in (torch.int16, torch.uint16):       # uint16 pixels already resident on the device (int16 = same bits)
+        src = raw.to(dev).contiguous()
+        img = torch.empty(tuple(raw.shape), dtype=torch.float32, device=dev)
+        check(lib().ribca_u16_to_f32(ptr(src), ptr(img), src.numel(), stream_ptr()), "ribca_u16_to_f32")
     else:
         img = raw.to(device=dev, dtype=torch.float32).contiguous().clone()
     c, h, w = img.shape

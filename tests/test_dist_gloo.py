@@ -1,0 +1,58 @@
+"""N>1 path on CPU: world_size-2 gloo group, sharding + the all-gather of per-cell rows (the only data-path exchange)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, golden_dir, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multiplexed_image_annotator_amd import dist as rd
+    arrs = np.load(os.path.join(golden_dir, "vote_cases.npz"))
+    ok = True
+    assert rd.world() == (rank, world)
+    for n in (0, 1, 2, 5, 64):
+        full = torch.from_numpy(arrs["b2_full_struct__p_immune_full"][:n].copy())
+        lo, hi = rd.shard_bounds(n, rank, world)
+        got = rd.all_gather_rows(full[lo:hi].contiguous(), n)
+        ok &= torch.equal(got, full)
+    f64 = torch.arange(7 * 3, dtype=torch.float64).reshape(7, 3) / 3
+    lo, hi = rd.shard_bounds(7, rank, world)
+    ok &= torch.equal(rd.all_gather_rows(f64[lo:hi].contiguous(), 7), f64)
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_shard_bounds_properties():
+    from multiplexed_image_annotator_amd.dist import shard_bounds
+    for n in (0, 1, 7, 8, 100000, 100003):
+        for ws in (1, 2, 3, 8):
+            cuts = [shard_bounds(n, r, ws) for r in range(ws)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(ws - 1))
+            sizes = [hi - lo for lo, hi in cuts]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(5, 2, 2)
+
+
+def test_all_gather_rows_gloo_world2(golden_dir):
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, golden_dir, out), nprocs=2, join=True)
+    assert dict(out) == {0: True, 1: True}

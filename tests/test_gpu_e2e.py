@@ -1,0 +1,133 @@
+"""End-to-end GPU parity through the drop-in ``Annotator`` API: against the reference's own Annotator outputs (golden)
+and against the CPU oracle pipeline at BASELINE config-2 size; plus size-independent properties at larger sizes."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from multiplexed_image_annotator_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def write_case(tmp_path, raw, mask, markers):
+    np.save(tmp_path / "img.npy", raw)
+    np.save(tmp_path / "mask.npy", mask)
+    (tmp_path / "markers.txt").write_text("\n".join(markers) + "\n")
+    (tmp_path / "images.csv").write_text(f"image_path,mask_path\n{tmp_path / 'img.npy'},{tmp_path / 'mask.npy'}\n")
+    return str(tmp_path / "markers.txt"), str(tmp_path / "images.csv")
+
+
+def csv_equal_up_to_conf(got: str, exp: str, tol: float):
+    g, e = got.splitlines(), exp.splitlines()
+    assert len(g) == len(e) and g[0] == e[0]
+    for a, b in zip(g[1:], e[1:]):
+        fa, fb = a.split(","), b.split(",")
+        assert fa[:2] == fb[:2] and fa[3:] == fb[3:], (a, b)
+        assert abs(float(fa[2]) - float(fb[2])) <= tol, (a, b)
+
+
+@pytest.mark.parametrize("name", ["basic", "two_model"])
+def test_annotator_matches_reference_golden(golden_dir, tmp_path, name):
+    from multiplexed_image_annotator_amd.annotator import Annotator
+    meta = json.load(open(os.path.join(golden_dir, "e2e.json")))[name]
+    arrs = np.load(os.path.join(golden_dir, "e2e.npz"))
+    mask, img = synth.make_mask_and_image(meta["h"], meta["w"], meta["cells"], len(meta["markers"]), meta["seed"])
+    mf, csv = write_case(tmp_path, img.numpy().astype(np.uint16), mask.numpy().astype(np.int32), meta["markers"])
+    weights = {}
+    for m in meta["models"]:
+        sd = synth.make_vit_state_dict(m, meta["seed"])
+        sd["head.bias"] = torch.from_numpy(arrs[f"{name}__head_bias_{m}"])
+        weights[m] = sd
+    a = Annotator(mf, csv, "cuda", str(tmp_path), "g", meta["strict"], False, -1, True, meta["blur"], meta["amax"], meta["conf"], 30, None)
+    a.set_weights(weights)
+    a.preprocess()
+    a.predict(8)
+    a.export_annotations()
+    assert list(a.preprocessor.cell_pos_dict[0].keys()) == meta["cell_ids"]
+    for m in meta["models"]:
+        got = a.probs[0][m]
+        assert np.abs(got - arrs[f"{name}__p_{m}"]).max() < 1e-3          # north-star tolerance (observed ~1e-5)
+        assert np.abs(got - arrs[f"{name}__p_{m}"]).max() < 2e-4
+    assert a.annotations[0] == meta["labels"]                             # cell-type assignments identical
+    assert [str(s) for s in a.cell_types] == meta["cell_types"]
+    assert [int(r["Cell type"]) for r in a.annotations_all[0]] == meta["type_ints"]
+    conf = np.array([np.float32(c) for c in a.confidence[0]])
+    assert np.abs(conf - arrs[f"{name}__conf"]).max() < 1e-3
+    assert [isinstance(c, int) for c in a.confidence[0]] == [c == -1 for c in arrs[f"{name}__conf"]]
+    np.testing.assert_allclose(a.preprocessor.intensity_full[0], arrs[f"{name}__intensity"], rtol=1e-12, atol=1e-14)
+    csv_equal_up_to_conf(open(tmp_path / "results" / "g_annotation_0.csv").read(), meta["csv"], 1.5e-3)
+    # pixel lists of the lazy cell_pos_dict agree with the mask
+    key = meta["cell_ids"][3]
+    r, c = a.preprocessor.cell_pos_dict[0][key]
+    assert (mask.numpy()[r, c] == key).all() and len(r) == int((mask.numpy() == key).sum())
+    a.clear_tmp()
+    assert not os.path.exists(tmp_path / "tmp")
+
+
+def test_config2_matches_oracle(tmp_path):
+    """BASELINE config 2: synthetic 7-channel 1024x1024 tile, 2k cells, Basic panel -> immune_base only."""
+    from multiplexed_image_annotator_amd.annotator import Annotator
+    from oracle import ref_pipeline, ref_vit
+    seed = synth.SEED_BASE + 2
+    mask, img = synth.make_mask_and_image(1024, 1024, 2000, 7, seed)
+    raw, mk = img.numpy().astype(np.uint16), mask.numpy().astype(np.int32)
+    mf, csv = write_case(tmp_path, raw, mk, synth.BASIC_PANEL_MARKERS)
+    sd = synth.make_vit_state_dict("immune_base", seed)
+    a = Annotator(mf, csv, "cuda", str(tmp_path), "c2", True, False, -1, True, 0.3, 99.8, 0.3, 30, None)
+    a.set_weights({"immune_base": sd})
+    a.preprocess()
+    # calibrate the head on the product's own (bit-exact) patches so labels spread over classes, then predict
+    x = a.preprocessor.panel_patches(0).cpu()[:, a.channel_parser.indices["immune_base"]]
+    with torch.no_grad():
+        sd["head.bias"] = synth.calibrate_head_bias(sd, ref_vit.forward_features(sd, x[:256]))
+    a.set_weights({"immune_base": sd})
+    a.predict(128)
+    a.export_annotations()
+    torch.set_num_threads(os.cpu_count() or 8)
+    ref = ref_pipeline.run_image(raw, mk, mf, {"immune_base": sd}, strict=True, normalize=True, blur=0.3, amax=99.8, confidence=0.3,
+                                 batch_size=128)
+    assert len(ref["ids"]) >= 1900
+    np.testing.assert_array_equal(a.preprocessor.images_dev[0].cpu().numpy(), ref["image"])                 # P1 bit-exact
+    np.testing.assert_array_equal(a.preprocessor.cell_tables[0], ref["table"])                              # P2 bit-exact
+    np.testing.assert_array_equal(x.numpy(), ref["patches"]["immune_base"])                                 # P3-P6 bit-exact
+    dp = np.abs(a.probs[0]["immune_base"] - ref["probs"]["immune_base"]).max()
+    assert dp < 1e-3, dp
+    assert a.annotations[0] == ref["labels"]
+    assert len(set(ref["labels"])) >= 3                                                                      # not a degenerate case
+    csv_equal_up_to_conf(open(tmp_path / "results" / "c2_annotation_0.csv").read(), ref["csv"], 1.5e-3)
+
+
+def test_full_panel_properties():
+    """Config-3 shaped inputs (15 channels, full panel, 5 models) at 12k cells: size-independent properties."""
+    from multiplexed_image_annotator_amd import _lib, ops
+    dev = _lib.require_gpu()
+    seed = synth.SEED_BASE + 3
+    mask, img = synth.make_mask_and_image(1536, 1536, 12000, 15, seed, device=dev)
+    image = ops.normalize_image(img.to(torch.float32), blur=0.3, amax=99.8)
+    assert float(image.min()) >= -1.0 and float(image.max()) <= 1.0
+    ids, tab = ops.label_table(mask)
+    n = len(ids)
+    assert n >= 11000 and int(tab[:, 6].sum()) == int((mask > 0).sum())                     # every labelled pixel counted once
+    cmin = ops.channel_min(image)
+    ids_d = torch.from_numpy(ids.astype(np.int32)).to(dev)
+    bb_d = torch.from_numpy(tab[:, :4].astype(np.int32)).to(dev)
+    patches, _ = ops.extract_patches(image, mask, cmin, ids_d, bb_d)
+    # a shard of cells gives the same patches as the same rows of the full run (cells are independent units)
+    lo, hi = n // 3, n // 3 + 777
+    part, _ = ops.extract_patches(image, mask, cmin, ids_d[lo:hi].contiguous(), bb_d[lo:hi].contiguous())
+    assert torch.equal(part, patches[lo:hi])
+    assert float(patches.min()) >= float(cmin.min()) - 1e-6
+    for name, (d, c, k) in synth.VIT_CONFIGS.items():
+        model = ops.VitModel(synth.make_vit_state_dict(name, seed), dev)
+        src = list(range(c))
+        p_full = model.predict_proba(patches, src, chunk_cells=256)
+        assert torch.isfinite(p_full).all()
+        assert (p_full.sum(1) - 1).abs().max().item() < 1e-5                                # softmax rows sum to one
+        p_part = model.predict_proba(patches[lo:hi].contiguous(), src, chunk_cells=100)
+        assert torch.equal(p_part, p_full[lo:hi])                                           # shard == slice, bitwise
+        perm = torch.randperm(hi - lo, generator=torch.Generator().manual_seed(1)).to(dev)
+        p_perm = model.predict_proba(patches[lo:hi][perm].contiguous(), src, chunk_cells=64)
+        assert torch.equal(p_perm, p_part[perm])                                            # order of cells is irrelevant
