@@ -100,13 +100,20 @@ def main():
             tdist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    note(f"inputs ready: {len(models)} models, {flops_cell / 1e9:.3f} GFLOP/cell")
+    for i in range(args.warmup):
         one_pass()
+        note(f"warmup {i + 1}/{args.warmup} done")
     sync_all()
     t0 = time.perf_counter()
     n_cells = 0
-    for _ in range(args.steps):
+    for i in range(args.steps):
         n_cells, lab, conf = one_pass()
+        note(f"step {i + 1}/{args.steps} done at {time.perf_counter() - t0:.2f}s")
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -165,7 +172,7 @@ def cpu_baseline(args, raw_dev, mask_dev, markers, seed, n_cells):
     area), crop/soft-mask + the same five ViTs on 48 of its cells; per-cell times are combined into end-to-end cells/s."""
     from multiplexed_image_annotator_amd import synth
     from oracle import ref_preprocess as rp, ref_vit
-    threads = os.cpu_count() or 1
+    threads = min(16, len(os.sched_getaffinity(0)))      # the GPU box gives one GPU a 16-core share
     torch.set_num_threads(threads)
     side = min(1024, args.size)
     raw = raw_dev[:, :side, :side].cpu().numpy().view(np.uint16)

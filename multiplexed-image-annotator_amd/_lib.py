@@ -47,6 +47,7 @@ SIGNATURES = {
     "ribca_test_qkv_attention": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_int32, c_void_p]),
     "ribca_gemm_padded_n": (c_int32, [c_int32]),
+    "ribca_set_gemm_variant": (c_int32, [c_int32]),
 }
 
 
@@ -71,6 +72,8 @@ def lib() -> ctypes.CDLL:
             fn.restype = res
             fn.argtypes = args
         _lib = handle
+        if os.environ.get("RIBCA_GEMM_VARIANT"):
+            handle.ribca_set_gemm_variant(int(os.environ["RIBCA_GEMM_VARIANT"]))
     return _lib
 
 

@@ -91,16 +91,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     bf16x8 phi[4], plo[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      uint16_t h[8], l[8];
+      float pa[4], pb[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) split_bf16(s[2 * t + (j >> 2)][j & 3] * inv, h[j], l[j]);
-      uint4 vh, vl;
-      vh.x = h[0] | ((uint32_t)h[1] << 16); vh.y = h[2] | ((uint32_t)h[3] << 16);
-      vh.z = h[4] | ((uint32_t)h[5] << 16); vh.w = h[6] | ((uint32_t)h[7] << 16);
-      vl.x = l[0] | ((uint32_t)l[1] << 16); vl.y = l[2] | ((uint32_t)l[3] << 16);
-      vl.z = l[4] | ((uint32_t)l[5] << 16); vl.w = l[6] | ((uint32_t)l[7] << 16);
-      phi[t] = __builtin_bit_cast(bf16x8, vh);
-      plo[t] = __builtin_bit_cast(bf16x8, vl);
+      for (int r = 0; r < 4; ++r) { pa[r] = s[2 * t][r] * inv; pb[r] = s[2 * t + 1][r] * inv; }
+      uint2 ha, la, hb, lb;
+      split4(pa, ha, la);
+      split4(pb, hb, lb);
+      phi[t] = __builtin_bit_cast(bf16x8, uint4{ha.x, ha.y, hb.x, hb.y});
+      plo[t] = __builtin_bit_cast(bf16x8, uint4{la.x, la.y, lb.x, lb.y});
     }
     const int qtok = qt * 16 + r16;
     uint16_t* orow = out + ((size_t)cell * kTokens + qtok) * ldo;

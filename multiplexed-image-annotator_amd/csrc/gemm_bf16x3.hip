@@ -4,19 +4,22 @@
 //   C[m][n] = sum_k A[m][k] * W[n][k]        A: activations  [M ][2*Kp] packed-split bf16 (ribca_common.h)
 //                                            W: nn.Linear wt [Np][2*Kp] packed-split bf16, Np = N padded to the tile
 //
-// Shape regime: M = cells*101 is huge (1e4..1e6), N in {144..2304}, K in {64..2304}: short K loops, so the tile is
-// 128 x {64,96,128} with BK = 32 and two blocks per CU covering each other's prologue/epilogue.
+// Shape regime: M = cells*101 is huge (1e4..1e6), N in {144..2304}, K in {160..2304}: short K loops and a weight matrix
+// that is L2-resident, so the kernel is built around keeping the MFMA pipe fed from a deep LDS ring:
 //
-// * 256 threads = 4 waves as 2(M) x 2(N); each wave owns 64 x BN/2 outputs = 4 x TN tiles of 16x16.
+// * tile 256 x {64,96,128}, BK = 32; 512 threads = 8 waves as 4(M) x 2(N), two waves per SIMD; each wave owns
+//   64 x BN/2 outputs = 4 x TN tiles of 16x16.  (A 128-row tile needs ~64 B/clk/CU from L2 at full MFMA rate; 256 rows halve it.)
 // * Tiles are computed TRANSPOSED: acc = mfma(Wfrag, Afrag) so a lane holds 4 consecutive output columns n of one row m
 //   (C/D map: col = lane&15 -> m, row = 4*(lane>>4)+r -> n).  Epilogues then issue one 8/16-byte store per tile
 //   instead of four 2-byte ones (residual RMW on fp32 z is one float4).
 // * Each (Afrag, Wfrag) pair feeds three MFMAs (hi*hi, lo*hi, hi*lo): LDS bytes per MFMA are 2/3 of a plain bf16 GEMM.
+// * 3-stage LDS ring (3 x 48 KB) filled by direct-to-LDS loads (global_load_lds_dwordx4, no staging registers, no
+//   ds_write): K-step k+2 is issued right after the barrier that opens step k, so two steps of loads are always in flight;
+//   completion is tracked with a counted s_waitcnt vmcnt(G) (G = loads per wave per stage) + one raw s_barrier per step.
 // * LDS tile = rows of 128 B (one 32-deep K step of a PS row: 4 x [16 B hi | 16 B lo]).  16-byte chunk c of row r lives at
 //   chunk c ^ f(r),  f(r) = ((r>>1)&7) ^ (4 <= (r&15) < 12 ? 2 : 0):  every hardware ds_read_b128 lane group
 //   ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) then touches 16 distinct 16-byte slots of the 256-byte bank row.
-// * global -> register -> LDS staging, double buffered: loads of K-step k+1 are issued before the MFMAs of step k and
-//   written to the other LDS stage after them; one barrier per K step.
+//   The LDS-DMA destination is linear (wave base + lane*16), so the swizzle is applied to each lane's GLOBAL source address.
 // * block id -> tile map is XCD-aware (blocks b, b+8, ... share an L2): every XCD walks whole rows of n-tiles of one
 //   m-tile, so an A tile is fetched into one L2 once and reused by all its n-tiles.
 #include "ribca_common.h"
@@ -24,7 +27,7 @@
 
 namespace ribca {
 
-constexpr int BM = 128;
+
 constexpr int BK = 32;
 constexpr int ROWB = 128;  // bytes per LDS tile row
 
@@ -34,23 +37,36 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 }
 
 // ---------------------------------------------------------------------------------------------- epilogues
+// Every epilogue runs in two sweeps over the wave's 4 x TN accumulator tiles: `fetch` issues ALL the loads it needs
+// (bias once per column group, the residual z tile) back to back, `apply` then computes and stores.  A single sweep
+// that loads, waits and stores per tile costs one L2/HBM round trip per tile (16 dependent round trips ~ 11 us per
+// 256 x 128 tile, as much as 14 K-steps of MFMAs).
 struct EpiResid {
   float* z; int ldz; const float* bias; int M, N;
-  __device__ __forceinline__ void operator()(int m, int n, const f32x4& v) const {
+  struct Ctx { float4 zv; };
+  __device__ __forceinline__ float4 fetch_bias(int n) const {
+    return n < N ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  __device__ __forceinline__ void fetch(int m, int n, Ctx& c) const {
+    c.zv = (m < M && n < N) ? *reinterpret_cast<const float4*>(z + (size_t)m * ldz + n) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx& c) const {
     if (m >= M || n >= N) return;
-    float4* p = reinterpret_cast<float4*>(z + (size_t)m * ldz + n);
-    const float4 b = *reinterpret_cast<const float4*>(bias + n);
-    float4 o = *p;
-    o.x += v[0] + b.x; o.y += v[1] + b.y; o.z += v[2] + b.z; o.w += v[3] + b.w;
-    *p = o;
+    float4 o;
+    o.x = c.zv.x + (v[0] + b.x); o.y = c.zv.y + (v[1] + b.y); o.z = c.zv.z + (v[2] + b.z); o.w = c.zv.w + (v[3] + b.w);
+    *reinterpret_cast<float4*>(z + (size_t)m * ldz + n) = o;
   }
 };
 
 struct EpiGelu {
   uint16_t* out; int ldo; const float* bias; int M, N;
-  __device__ __forceinline__ void operator()(int m, int n, const f32x4& v) const {
+  struct Ctx {};
+  __device__ __forceinline__ float4 fetch_bias(int n) const {
+    return n < N ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  __device__ __forceinline__ void fetch(int, int, Ctx&) const {}
+  __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx&) const {
     if (m >= M || n >= N) return;
-    const float4 b = *reinterpret_cast<const float4*>(bias + n);
     float t[4] = {gelu_erf(v[0] + b.x), gelu_erf(v[1] + b.y), gelu_erf(v[2] + b.z), gelu_erf(v[3] + b.w)};
     ps_store4(out + (size_t)m * ldo, n, t);
   }
@@ -58,27 +74,37 @@ struct EpiGelu {
 
 struct EpiEmbed {
   float* z; int ldz; const float* bias; const float* pos; int D; int M, N;
-  __device__ __forceinline__ void operator()(int m, int n, const f32x4& v) const {
+  struct Ctx { float4 pe; };
+  __device__ __forceinline__ float4 fetch_bias(int n) const {
+    return n < N ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  __device__ __forceinline__ void fetch(int m, int n, Ctx& c) const {
+    const int cell = m / 100, t = m - cell * 100;
+    c.pe = (m < M && n < N) ? *reinterpret_cast<const float4*>(pos + (size_t)(1 + t) * D + n) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx& c) const {
     if (m >= M || n >= N) return;
     const int cell = m / 100, t = m - cell * 100;
-    const float4 b = *reinterpret_cast<const float4*>(bias + n);
-    const float4 pe = *reinterpret_cast<const float4*>(pos + (size_t)(1 + t) * D + n);
     float4 o;
-    o.x = v[0] + b.x + pe.x; o.y = v[1] + b.y + pe.y; o.z = v[2] + b.z + pe.z; o.w = v[3] + b.w + pe.w;
+    o.x = v[0] + b.x + c.pe.x; o.y = v[1] + b.y + c.pe.y; o.z = v[2] + b.z + c.pe.z; o.w = v[3] + b.w + c.pe.w;
     *reinterpret_cast<float4*>(z + ((size_t)cell * kTokens + 1 + t) * ldz + n) = o;
   }
 };
 
 struct EpiQKV {
   uint16_t* q; uint16_t* k; uint16_t* vt; const float* bias; int D, hd, hdp, hdv; float scale; int M, N;
-  __device__ __forceinline__ void operator()(int m, int n, const f32x4& v) const {
+  struct Ctx {};
+  __device__ __forceinline__ float4 fetch_bias(int n) const {
+    return n < N ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  __device__ __forceinline__ void fetch(int, int, Ctx&) const {}
+  __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx&) const {
     if (m >= M || n >= N) return;
     const int which = n / D;
     const int f = n - which * D;
     const int head = f / hd;
     const int d = f - head * hd;  // multiple of 4, d+3 < hd (hd % 4 == 0)
     const int cell = m / kTokens, t = m - cell * kTokens;
-    const float4 b = *reinterpret_cast<const float4*>(bias + n);
     float x[4] = {v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w};
     const size_t ch = (size_t)cell * kHeads + head;
     if (which < 2) {
@@ -105,14 +131,54 @@ struct EpiQKV {
   }
 };
 
+// two-sweep driver shared by the kernels: lane owns rows m_i = mbase + 16 i and column groups n_j = nbase + 16 j
+template <int TN, class Epi>
+__device__ __forceinline__ void run_epilogue(const Epi& epi, int mbase, int nbase, f32x4 (&acc)[4][TN]) {
+  float4 b4[TN];
+  typename Epi::Ctx ctx[4][TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) b4[j] = epi.fetch_bias(nbase + 16 * j);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) epi.fetch(mbase + 16 * i, nbase + 16 * j, ctx[i][j]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) epi.apply(mbase + 16 * i, nbase + 16 * j, acc[i][j], b4[j], ctx[i][j]);
+}
+
 // ---------------------------------------------------------------------------------------------- kernel
-template <int BN, class Epi>
-__global__ __launch_bounds__(256, 2) void gemm_ps_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw,
+__device__ __forceinline__ int swz_f(int row) { return ((row >> 1) & 7) ^ ((((row + 12) & 15) < 8) ? 2 : 0); }
+
+template <int CNT> __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(CNT >= 0 && CNT <= 12, "extend the immediate list");
+  if constexpr (CNT == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (CNT == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (CNT == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (CNT == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (CNT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (CNT == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (CNT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (CNT == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if constexpr (CNT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (CNT == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (CNT == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (CNT == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+
+// BM in {128, 256} rows per tile (BM/32 waves), NST = LDS ring depth (2: one K step in flight, two tiles per CU;
+// 3: two K steps in flight, one tile per CU).
+template <int BM, int BN, int NST, class Epi>
+__global__ __launch_bounds__(BM * 2) void gemm_ps_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw,
                                                          int M, int Kp, int mtiles, int ntiles, Epi epi) {
+  constexpr int NW = BM / 32;            // waves: (BM/64) along M x 2 along N
   constexpr int TN = BN / 32;
-  constexpr int A_CH = BM * 8 / 256;
-  constexpr int W_CH = BN * 8 / 256;
-  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int ROWS = BM + BN;
+  constexpr int STAGE = ROWS * ROWB;
+  constexpr int NGRP = ROWS / 8;         // 1 KB (8-row) DMA groups per stage
+  constexpr int GPW = (NGRP + NW - 1) / NW;   // groups each wave issues per stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   // XCD-aware bijective remap (cdna guide T1): blocks with equal (bid % 8) share an L2
@@ -127,28 +193,29 @@ __global__ __launch_bounds__(256, 2) void gemm_ps_kernel(const uint16_t* __restr
   const int m0 = mt * BM, n0 = nt * BN;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int r16 = lane & 15, g = lane >> 4;
 
-  // staging assignment: chunk q = tid + 256*i -> (row = q>>3, 16-byte chunk = q&7)
-  const uint16_t* a_src[A_CH];
-  int a_dst[A_CH];
+  // LDS-DMA plan: group grp = 8 consecutive tile rows = 1 KB; lane -> (row = 8*grp + lane/8, physical chunk = lane%8).
+  // The logical chunk that must land there is phys ^ f(row): fetch THAT chunk from global.
+  const uint16_t* src[GPW];
+  int dst[GPW];
 #pragma unroll
-  for (int i = 0; i < A_CH; ++i) {
-    const int qd = tid + 256 * i, row = qd >> 3, ch = qd & 7;
-    int gm = m0 + row;
-    gm = gm < M ? gm : M - 1;  // tail rows re-read the last valid row; their outputs are never stored
-    a_src[i] = A + (size_t)gm * lda + ch * 8;
-    a_dst[i] = lds_off(row, ch);
-  }
-  const uint16_t* w_src[W_CH];
-  int w_dst[W_CH];
-#pragma unroll
-  for (int i = 0; i < W_CH; ++i) {
-    const int qd = tid + 256 * i, row = qd >> 3, ch = qd & 7;
-    w_src[i] = W + (size_t)(n0 + row) * ldw + ch * 8;
-    w_dst[i] = BM * ROWB + lds_off(row, ch);
+  for (int i = 0; i < GPW; ++i) {
+    int grp = wave + NW * i;
+    grp = grp < NGRP ? grp : NGRP - 1;   // surplus slots repeat the last group (same bytes to the same place)
+    const int row = grp * 8 + (lane >> 3);
+    const int ch = (lane & 7) ^ swz_f(row);
+    if (row < BM) {
+      int gm = m0 + row;
+      gm = gm < M ? gm : M - 1;          // tail rows re-read the last valid row; their outputs are never stored
+      src[i] = A + (size_t)gm * lda + ch * 8;
+    } else {
+      src[i] = W + (size_t)(n0 + row - BM) * ldw + ch * 8;
+    }
+    dst[i] = grp * 1024;
   }
 
   int a_rd[4], w_rd[TN];
@@ -163,18 +230,16 @@ __global__ __launch_bounds__(256, 2) void gemm_ps_kernel(const uint16_t* __restr
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  uint4 ra[A_CH], rw[W_CH];
   const int nk = Kp / BK;
 
+  auto issue = [&](int kk, int stage) {
+    char* st = smem + stage * STAGE;
+    const int ko = kk * (2 * BK);        // bf16 elements per K step in a PS row
 #pragma unroll
-  for (int i = 0; i < A_CH; ++i) ra[i] = *reinterpret_cast<const uint4*>(a_src[i]);
-#pragma unroll
-  for (int i = 0; i < W_CH; ++i) rw[i] = *reinterpret_cast<const uint4*>(w_src[i]);
-#pragma unroll
-  for (int i = 0; i < A_CH; ++i) *reinterpret_cast<uint4*>(smem + a_dst[i]) = ra[i];
-#pragma unroll
-  for (int i = 0; i < W_CH; ++i) *reinterpret_cast<uint4*>(smem + w_dst[i]) = rw[i];
-  __syncthreads();
+    for (int i = 0; i < GPW; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + ko),
+                                       (__attribute__((address_space(3))) void*)(st + dst[i]), 16, 0, 0);
+  };
 
   auto compute = [&](const char* st) {
     bf16x8 ahi[4], alo[4], whi[TN], wlo[TN];
@@ -202,30 +267,370 @@ __global__ __launch_bounds__(256, 2) void gemm_ps_kernel(const uint16_t* __restr
       for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(whi[j], ahi[i], acc[i][j]);
   };
 
-  // steady state: loads of step kk+1 in flight under the MFMAs of step kk, written to the other stage afterwards
-  for (int kk = 0; kk + 1 < nk; ++kk) {
-    const int ko = (kk + 1) * (2 * BK);  // bf16 elements per K step in a PS row
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) ra[i] = *reinterpret_cast<const uint4*>(a_src[i] + ko);
-#pragma unroll
-    for (int i = 0; i < W_CH; ++i) rw[i] = *reinterpret_cast<const uint4*>(w_src[i] + ko);
-    compute(smem + (kk & 1) * STAGE);
-    char* nx = smem + ((kk + 1) & 1) * STAGE;
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) *reinterpret_cast<uint4*>(nx + a_dst[i]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < W_CH; ++i) *reinterpret_cast<uint4*>(nx + w_dst[i]) = rw[i];
-    __syncthreads();
+  issue(0, 0);
+  if (NST > 2 && nk > 1) issue(1, 1);
+  int cur = 0;                            // ring slot of K step kk
+  for (int kk = 0; kk < nk; ++kk) {
+    // retire this wave's loads of step kk (with a 3-deep ring the newest stage may stay in flight), then meet the other
+    // waves: after the barrier every wave's part of slot `cur` has landed AND every wave has finished reading the slot the
+    // next issue overwrites (it was read during step kk-1).
+    if (NST > 2 && kk + 1 < nk) wait_vmcnt<GPW>();
+    else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kk + NST - 1 < nk) {
+      int nxt = cur + NST - 1;
+      nxt = nxt >= NST ? nxt - NST : nxt;
+      issue(kk + NST - 1, nxt);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    compute(smem + cur * STAGE);
+    cur = cur + 1 == NST ? 0 : cur + 1;
   }
-  compute(smem + ((nk - 1) & 1) * STAGE);
 
+  run_epilogue<TN>(epi, m0 + wm * 64 + r16, n0 + wn * (BN / 2) + 4 * g, acc);
+}
+
+// ---------------------------------------------------------------------------------------------- loader/consumer split
+// Same tile (256 x BN, BK 32, 3-deep ring) with ROLES: waves 0-7 only read LDS and issue MFMAs; waves 8-11 only issue the
+// direct-to-LDS loads.  An LDS-DMA instruction costs its wave ~100 issue cycles, and 6 of them per wave right after each
+// barrier (every wave at once, both SIMD partners) left the matrix pipe idle for a third of each K step; on dedicated waves
+// that cost overlaps the consumers' MFMAs (3 waves per SIMD: 2 consumers + 1 loader).  Consumers never touch vmcnt in the
+// loop, so their epilogue loads/stores cannot drain the ring.
+template <int BN, class Epi, int ABL = 0 /* timing ablations: 1 = no loads, 2 = no MFMA/LDS reads */, bool STAG = false>
+__global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw,
+                                                            int M, int Kp, int mtiles, int ntiles, Epi epi) {
+  constexpr int BM = 256, NST = 3, NLW = 4;
+  constexpr int TN = BN / 32;
+  constexpr int ROWS = BM + BN;
+  constexpr int STAGE = ROWS * ROWB;
+  constexpr int NGRP = ROWS / 8;
+  constexpr int GPL = (NGRP + NLW - 1) / NLW;   // DMA groups per loader wave per stage (10..12)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int nblk = mtiles * ntiles;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int mt = bid / ntiles, nt = bid - mt * ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nk = Kp / BK;
+
+  if (wave >= 8) {
+    // ------------------------------------------------------------------ loader
+    const int lw = wave - 8;
+    const uint16_t* src[GPL];
+    int dst[GPL];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + r16;
+    for (int i = 0; i < GPL; ++i) {
+      int grp = lw + NLW * i;
+      grp = grp < NGRP ? grp : NGRP - 1;
+      const int row = grp * 8 + (lane >> 3);
+      const int ch = (lane & 7) ^ swz_f(row);
+      if (row < BM) {
+        int gm = m0 + row;
+        gm = gm < M ? gm : M - 1;
+        src[i] = A + (size_t)gm * lda + ch * 8;
+      } else {
+        src[i] = W + (size_t)(n0 + row - BM) * ldw + ch * 8;
+      }
+      dst[i] = grp * 1024;
+    }
+    auto issue = [&](int kk, int stage) {
+      char* st = smem + stage * STAGE;
+      const int ko = kk * (2 * BK);
+#pragma unroll
+      for (int i = 0; i < GPL; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + ko),
+                                         (__attribute__((address_space(3))) void*)(st + dst[i]), 16, 0, 0);
+    };
+    if (ABL != 1) {
+      issue(0, 0);
+      if (nk > 1) issue(1, 1);
+    }
+    int cur = 0;
+    for (int kk = 0; kk < nk; ++kk) {
+      if (kk + 1 < nk) wait_vmcnt<GPL>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (ABL != 1 && kk + 2 < nk) {
+        int nxt = cur + 2;
+        nxt = nxt >= NST ? nxt - NST : nxt;
+        issue(kk + 2, nxt);
+      }
+      if (STAG) __builtin_amdgcn_s_barrier();   // phase 2kk+1
+      cur = cur + 1 == NST ? 0 : cur + 1;
+    }
+    if (STAG) __builtin_amdgcn_s_barrier();     // phase 2nk
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumer
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r16 = lane & 15, g = lane >> 4;
+  int a_rd[4], w_rd[TN];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_rd[i] = lds_off(wm * 64 + i * 16 + r16, 2 * g);
+#pragma unroll
+  for (int i = 0; i < TN; ++i) w_rd[i] = BM * ROWB + lds_off(wn * (BN / 2) + i * 16 + r16, 2 * g);
+  f32x4 acc[4][TN];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  bf16x8 ahi[4], alo[4], whi[TN], wlo[TN];
+  auto read_frags = [&](const char* st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ahi[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + a_rd[i]));
+      alo[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + (a_rd[i] ^ 16)));
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * (BN / 2) + j * 16 + 4 * g;
-      epi(m, n, acc[i][j]);
+      whi[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + w_rd[j]));
+      wlo[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + (w_rd[j] ^ 16)));
+    }
+  };
+  auto mfmas = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(wlo[j], ahi[i], acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(whi[j], alo[i], acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(whi[j], ahi[i], acc[i][j]);
+  };
+
+  int cur = 0;
+  if (!STAG) {
+    for (int kk = 0; kk < nk; ++kk) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (ABL != 2) {
+        read_frags(smem + cur * STAGE);
+        mfmas();
+      }
+      cur = cur + 1 == NST ? 0 : cur + 1;
+    }
+  } else {
+    // Two barriers per K step split it into a fragment-read phase and an MFMA phase; waves 4-7 (the SIMD partners of
+    // waves 0-3) run half a step late, so on every SIMD one wave's LDS burst overlaps the other wave's 48 MFMAs.
+    //   phase 2s   : waves 0-3 read(s)   | waves 4-7 mfma(s-1)
+    //   phase 2s+1 : waves 0-3 mfma(s)   | waves 4-7 read(s)
+    const bool late = wave >= 4;
+    if (late) __builtin_amdgcn_s_barrier();          // phase 0: nothing to multiply yet
+    for (int kk = 0; kk < nk; ++kk) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (ABL != 2) read_frags(smem + cur * STAGE);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (ABL != 2) mfmas();
+      cur = cur + 1 == NST ? 0 : cur + 1;
+    }
+    if (!late) __builtin_amdgcn_s_barrier();         // phase 2nk: partners finish their last MFMAs
+  }
+  run_epilogue<TN>(epi, m0 + wm * 64 + r16, n0 + wn * (BN / 2) + 4 * g, acc);
+}
+
+// ---------------------------------------------------------------------------------------------- persistent form
+// The split/staggered kernel made persistent: one workgroup per CU walks tiles rb, rb + G, rb + 2G, ... and the loader waves
+// run straight through tile boundaries (K steps are numbered globally), so a tile's first two stages are already in flight
+// while the previous tile is still multiplying and there is no per-tile launch + cold-ring prologue (~10 us per 256 x 128
+// tile, as much as 12 K steps).  Epilogues sit in the half-step where the partner group is multiplying:
+//   waves 0-3: ... mfma(last) | barrier | EPILOGUE, read(first of next tile) | barrier | mfma ...
+//   waves 4-7: ... read(last) | barrier | mfma(last), EPILOGUE             | barrier | read(first) ...
+template <int BN, class Epi>
+__global__ __launch_bounds__(768) void gemm_ps_persist_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W,
+                                                              int ldw, int M, int Kp, int mtiles, int ntiles, Epi epi) {
+  constexpr int BM = 256, NST = 3, NLW = 4;
+  constexpr int TN = BN / 32;
+  constexpr int ROWS = BM + BN;
+  constexpr int STAGE = ROWS * ROWB;
+  constexpr int NGRP = ROWS / 8;
+  constexpr int GPL = (NGRP + NLW - 1) / NLW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int nblk = mtiles * ntiles;
+  const int G = gridDim.x;                      // G <= nblk
+  int rb = blockIdx.x;
+  {
+    const int xcd = rb & 7, loc = rb >> 3;
+    const int q = G >> 3, r = G & 7;
+    rb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;   // blocks of one XCD take consecutive tiles
+  }
+  const int n_my = (nblk - rb + G - 1) / G;     // tiles this workgroup owns (>= 1)
+  const int nk = Kp / BK;
+  const int total = n_my * nk;                  // K steps over all owned tiles
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  if (wave >= 8) {
+    // ------------------------------------------------------------------ loader
+    const int lw = wave - 8;
+    const uint16_t* src[GPL];
+    int dst[GPL];
+    int lrow[GPL];
+#pragma unroll
+    for (int i = 0; i < GPL; ++i) {
+      int grp = lw + NLW * i;
+      grp = grp < NGRP ? grp : NGRP - 1;
+      lrow[i] = grp * 8 + (lane >> 3);
+      dst[i] = grp * 1024;
+    }
+    auto set_src = [&](int ti) {
+      const int tile = rb + ti * G;
+      const int mt = tile / ntiles, nt = tile - mt * ntiles;
+#pragma unroll
+      for (int i = 0; i < GPL; ++i) {
+        const int row = lrow[i];
+        const int ch = (lane & 7) ^ swz_f(row);
+        if (row < BM) {
+          int gm = mt * BM + row;
+          gm = gm < M ? gm : M - 1;
+          src[i] = A + (size_t)gm * lda + ch * 8;
+        } else {
+          src[i] = W + (size_t)(nt * BN + row - BM) * ldw + ch * 8;
+        }
+      }
+    };
+    int l_ti = 0, l_kk = 0;
+    auto issue_next = [&](int stage) {
+      char* st = smem + stage * STAGE;
+      const int ko = l_kk * (2 * BK);
+#pragma unroll
+      for (int i = 0; i < GPL; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + ko),
+                                         (__attribute__((address_space(3))) void*)(st + dst[i]), 16, 0, 0);
+      if (++l_kk == nk) {
+        l_kk = 0;
+        if (++l_ti < n_my) set_src(l_ti);
+      }
+    };
+    set_src(0);
+    issue_next(0);
+    if (total > 1) issue_next(1);
+    int cur = 0;
+    for (int s = 0; s < total; ++s) {
+      if (s + 1 < total) wait_vmcnt<GPL>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();               // phase 2s
+      asm volatile("" ::: "memory");
+      if (s + 2 < total) {
+        int nxt = cur + 2;
+        nxt = nxt >= NST ? nxt - NST : nxt;
+        issue_next(nxt);
+      }
+      __builtin_amdgcn_s_barrier();               // phase 2s+1
+      cur = cur + 1 == NST ? 0 : cur + 1;
+    }
+    __builtin_amdgcn_s_barrier();                 // phase 2*total
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumer
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r16 = lane & 15, g = lane >> 4;
+  int a_rd[4], w_rd[TN];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_rd[i] = lds_off(wm * 64 + i * 16 + r16, 2 * g);
+#pragma unroll
+  for (int i = 0; i < TN; ++i) w_rd[i] = BM * ROWB + lds_off(wn * (BN / 2) + i * 16 + r16, 2 * g);
+  f32x4 acc[4][TN];
+  bf16x8 ahi[4], alo[4], whi[TN], wlo[TN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto read_frags = [&](const char* st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ahi[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + a_rd[i]));
+      alo[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + (a_rd[i] ^ 16)));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      whi[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + w_rd[j]));
+      wlo[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + (w_rd[j] ^ 16)));
+    }
+  };
+  auto mfmas = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(wlo[j], ahi[i], acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(whi[j], alo[i], acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(whi[j], ahi[i], acc[i][j]);
+  };
+  auto tile_epilogue = [&](int ti) {
+    const int tile = rb + ti * G;
+    const int mt = tile / ntiles, nt = tile - mt * ntiles;
+    run_epilogue<TN>(epi, mt * BM + wm * 64 + r16, nt * BN + wn * (BN / 2) + 4 * g, acc);
+  };
+
+  int cur = 0;
+  if (wave < 4) {
+    for (int ti = 0; ti < n_my; ++ti) {
+      for (int kk = 0; kk < nk; ++kk) {
+        __builtin_amdgcn_s_barrier();             // even phase: partners multiply
+        asm volatile("" ::: "memory");
+        if (kk == 0) {
+          if (ti > 0) tile_epilogue(ti - 1);
+          zero_acc();
+        }
+        read_frags(smem + cur * STAGE);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();             // odd phase
+        asm volatile("" ::: "memory");
+        mfmas();
+        cur = cur + 1 == NST ? 0 : cur + 1;
+      }
+    }
+    __builtin_amdgcn_s_barrier();                 // phase 2*total: partners finish
+    tile_epilogue(n_my - 1);
+  } else {
+    __builtin_amdgcn_s_barrier();                 // phase 0
+    for (int ti = 0; ti < n_my; ++ti) {
+      zero_acc();
+      for (int kk = 0; kk < nk; ++kk) {
+        __builtin_amdgcn_s_barrier();             // odd phase: partners multiply
+        asm volatile("" ::: "memory");
+        read_frags(smem + cur * STAGE);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();             // even phase
+        asm volatile("" ::: "memory");
+        mfmas();
+        cur = cur + 1 == NST ? 0 : cur + 1;
+      }
+      tile_epilogue(ti);
     }
   }
 }
@@ -242,18 +647,76 @@ int gemm_padded_n(int N) {
   return (N + bn - 1) / bn * bn;
 }
 
-template <int BN, class Epi>
-static void launch_bn(const GemmArgs& g, const Epi& epi, hipStream_t s) {
+static int g_variant = 0;   // 0 auto, 1: 256-row tile / 3-deep ring, 2: 128-row tile / 2-deep ring, 3: 256-row tile with loader waves
+void gemm_set_variant(int v) { g_variant = v; }
+
+template <int BM, int BN, int NST, class Epi>
+static void launch_cfg(const GemmArgs& g, const Epi& epi, hipStream_t s) {
   const int mtiles = (g.M + BM - 1) / BM;
   const int ntiles = gemm_padded_n(g.N) / BN;
-  const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
+  const size_t lds = (size_t)NST * (BM + BN) * ROWB;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ps_kernel<BN, Epi>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ps_kernel<BM, BN, NST, Epi>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_ps_kernel<BN, Epi>), dim3(mtiles * ntiles), dim3(256), lds, s, g.A, g.lda, g.W, g.ldw, g.M, g.Kp, mtiles,
+  hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, NST, Epi>), dim3(mtiles * ntiles), dim3(BM * 2), lds, s, g.A, g.lda, g.W, g.ldw, g.M, g.Kp,
+                     mtiles, ntiles, epi);
+}
+
+template <int BN, class Epi, int ABL = 0, bool STAG = false>
+static void launch_split(const GemmArgs& g, const Epi& epi, hipStream_t s) {
+  const int mtiles = (g.M + 255) / 256;
+  const int ntiles = gemm_padded_n(g.N) / BN;
+  const size_t lds = (size_t)3 * (256 + BN) * ROWB;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ps_split_kernel<BN, Epi, ABL, STAG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_ps_split_kernel<BN, Epi, ABL, STAG>), dim3(mtiles * ntiles), dim3(768), lds, s, g.A, g.lda, g.W, g.ldw, g.M, g.Kp, mtiles,
                      ntiles, epi);
+}
+
+static int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <int BN, class Epi>
+static void launch_persist(const GemmArgs& g, const Epi& epi, hipStream_t s) {
+  const int mtiles = (g.M + 255) / 256;
+  const int ntiles = gemm_padded_n(g.N) / BN;
+  const int nblk = mtiles * ntiles;
+  const int grid = nblk < cu_count() ? nblk : cu_count();
+  const size_t lds = (size_t)3 * (256 + BN) * ROWB;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ps_persist_kernel<BN, Epi>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_ps_persist_kernel<BN, Epi>), dim3(grid), dim3(768), lds, s, g.A, g.lda, g.W, g.ldw, g.M, g.Kp, mtiles, ntiles,
+                     epi);
+}
+
+template <int BN, class Epi>
+static void launch_bn(const GemmArgs& g, const Epi& epi, hipStream_t s) {
+  if (g_variant == 0 || g_variant == 6) launch_split<BN, Epi, 0, true>(g, epi, s);   // default: loader waves + half-step stagger
+  else if (g_variant == 2) launch_cfg<128, BN, 2>(g, epi, s);
+  else if (g_variant == 3) launch_split<BN>(g, epi, s);
+  else if (g_variant == 4) launch_split<BN, Epi, 1>(g, epi, s);
+  else if (g_variant == 5) launch_split<BN, Epi, 2>(g, epi, s);
+  else if (g_variant == 8) launch_persist<BN>(g, epi, s);
+  else if (g_variant == 7) launch_split<BN, Epi, 1, true>(g, epi, s);
+  else launch_cfg<256, BN, 3>(g, epi, s);
 }
 
 template <class Epi>

@@ -36,15 +36,20 @@ __device__ __forceinline__ void split_bf16(float x, uint16_t& hi, uint16_t& lo) 
   hi = bf16_bits(x);
   lo = bf16_bits(x - bf16_to_f32(hi));
 }
-// four consecutive values -> 8 bytes of hi and 8 bytes of lo
+// four consecutive values -> 8 bytes of hi and 8 bytes of lo.  Packed conversions: one v_cvt_pk_bf16_f32 per value pair.
+typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 bf16x2;
+typedef __attribute__((__vector_size__(2 * sizeof(float)))) float f32x2;
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
 __device__ __forceinline__ void split4(const float v[4], uint2& hi, uint2& lo) {
-  uint16_t h[4], l[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) split_bf16(v[i], h[i], l[i]);
-  hi.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
-  hi.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
-  lo.x = (uint32_t)l[0] | ((uint32_t)l[1] << 16);
-  lo.y = (uint32_t)l[2] | ((uint32_t)l[3] << 16);
+  hi.x = cvt_pk_bf16(v[0], v[1]);
+  hi.y = cvt_pk_bf16(v[2], v[3]);
+  const float r0 = v[0] - __uint_as_float(hi.x << 16), r1 = v[1] - __uint_as_float(hi.x & 0xFFFF0000u);
+  const float r2 = v[2] - __uint_as_float(hi.y << 16), r3 = v[3] - __uint_as_float(hi.y & 0xFFFF0000u);
+  lo.x = cvt_pk_bf16(r0, r1);
+  lo.y = cvt_pk_bf16(r2, r3);
 }
 // element offset (in bf16 units) of the hi part of logical column k in a PS row; lo part is +8
 __device__ __host__ __forceinline__ int ps_off(int k) { return ((k >> 3) << 4) + (k & 7); }
@@ -73,7 +78,22 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// exact (erf) GELU, as nn.GELU() default used by timm Mlp
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf to ~2e-7 absolute (Abramowitz & Stegun 7.1.26 evaluated in fp32): 1 rcp + 1 exp2 + 7 fma, branch-free.  The GELU
+// output is re-quantised to a bf16 hi/lo pair (2^-17 relative) right after, so the libm erff's last bits would be
+// discarded anyway while costing ~3x the instructions in the fc1 epilogue.
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+  const float r = fmaf(-p, e, 1.0f);
+  return copysignf(r, x);
+}
+// exact-erf GELU (nn.GELU() default used by timm Mlp): 0.5 x (1 + erf(x / sqrt(2)))
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
 }  // namespace ribca

@@ -8,7 +8,8 @@ namespace ribca {
 
 // ----- GEMM (gemm_bf16x3.hip): C = A * W^T with A [M][2*Kp] and W [Np][2*Kp] in packed-split bf16 ---------------
 int gemm_pick_bn(int N);            // column-tile width used for an N-wide weight (64 / 96 / 128)
-int gemm_padded_n(int N);           // N rounded up to that tile width (rows the packed weight must have)
+int gemm_padded_n(int N);
+void gemm_set_variant(int v);      // tuning hook: 0 auto, 1 = 256-row tile / 3-deep ring, 2 = 128-row tile / 2-deep ring           // N rounded up to that tile width (rows the packed weight must have)
 
 struct GemmArgs {
   const uint16_t* A; int lda;       // activations, row stride in bf16 elements (= 2*Kp)
