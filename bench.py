@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--cells", type=int, default=100000)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--channels", type=int, default=15)
-    ap.add_argument("--chunk", type=int, default=int(os.environ.get("RIBCA_CHUNK_CELLS", "256")))
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("RIBCA_CHUNK_CELLS", "1024")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()

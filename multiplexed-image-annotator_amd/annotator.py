@@ -105,7 +105,7 @@ class Annotator(object):
         self._weights: Dict[str, Dict[str, torch.Tensor]] = {}
         self.probs: List[Dict[str, np.ndarray]] = []       # per image: model -> (n, K) fp32 host table
         self.label_ids: List[np.ndarray] = []
-        self.chunk_cells = int(os.environ.get("RIBCA_CHUNK_CELLS", "256"))
+        self.chunk_cells = int(os.environ.get("RIBCA_CHUNK_CELLS", "1024"))
 
     # ---- weights ---------------------------------------------------------------------------------------------------
     def set_weights(self, weights: Dict[str, Dict[str, torch.Tensor]]) -> None:

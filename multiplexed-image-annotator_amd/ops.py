@@ -289,7 +289,7 @@ class VitModel:
                 pass
             self._h = None
 
-    def predict_proba(self, patches: torch.Tensor, src_chan: Sequence[int], chunk_cells: int = 256) -> torch.Tensor:
+    def predict_proba(self, patches: torch.Tensor, src_chan: Sequence[int], chunk_cells: int = 1024) -> torch.Tensor:
         """softmax(model(x), dim=1) for full-channel patches (n, C_img, 40, 40); ``src_chan[c]`` = image channel of model
         channel c or -1 for a blank plane (reference preprocess.py:110-120, model.py:397-406)."""
         assert patches.is_cuda and patches.dtype == torch.float32 and patches.dim() == 4 and patches.shape[2:] == (PATCH, PATCH)

@@ -142,3 +142,26 @@ def test_full_panel_properties():
         perm = torch.randperm(hi - lo, generator=torch.Generator().manual_seed(1)).to(dev)
         p_perm = model.predict_proba(patches[lo:hi][perm].contiguous(), src, chunk_cells=64)
         assert torch.equal(p_perm, p_part[perm])                                            # order of cells is irrelevant
+
+
+def test_cli_single_image(tmp_path, golden_dir):
+    """reference main.py surface: --image-path/--mask-path -> images.csv -> CSV in <main_dir>/results."""
+    import main as cli
+    meta = json.load(open(os.path.join(golden_dir, "e2e.json")))["basic"]
+    arrs = np.load(os.path.join(golden_dir, "e2e.npz"))
+    mask, img = synth.make_mask_and_image(meta["h"], meta["w"], meta["cells"], len(meta["markers"]), meta["seed"])
+    mf, _ = write_case(tmp_path, img.numpy().astype(np.uint16), mask.numpy().astype(np.int32), meta["markers"])
+    sd = synth.make_vit_state_dict("immune_base", meta["seed"])
+    sd["head.bias"] = torch.from_numpy(arrs["basic__head_bias_immune_base"])
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        mdir = "src/multiplexed_image_annotator/cell_type_annotation/models"      # CWD-relative, as in the reference
+        os.makedirs(mdir)
+        torch.save({"model": sd}, os.path.join(mdir, "immune_base.pth"))
+        args = cli.parse_args(["--marker-list-path", mf, "--image-path", str(tmp_path / "img.npy"), "--mask-path", str(tmp_path / "mask.npy"),
+                               "--batch-id", "g", "--main-dir", str(tmp_path / "out"), "--strict", "--no-infer", "--bs", "8"])
+        cli.run(args)
+    finally:
+        os.chdir(cwd)
+    csv_equal_up_to_conf(open(tmp_path / "out" / "results" / "g_annotation_0.csv").read(), meta["csv"], 1.5e-3)
