@@ -151,9 +151,14 @@ def main():
         g_ms = sum(prof[k][0] for k in ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2"))
         g_n = sum(prof[k][1] for k in ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2"))
         achieved = gemm_flops / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_ps_kernel (qkv/proj/fc1/fc2, bf16x3)", "achieved": round(achieved, 2),
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_final", "gemm_traffic.json")
+        if os.path.exists(tpath):                      # HBM/fabric bytes per launch from the committed rocprofv3 PMC passes
+            traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"])
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_ps_split_kernel (qkv/proj/fc1/fc2, bf16x3)", "achieved": round(achieved, 2),
                            "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 5),
-                           "traffic": None, "launches": int(g_n), "avg_launch_ms": round(g_ms / max(g_n, 1), 5),
+                           "traffic": traffic, "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r1_final/gemm_traffic.json)",
+                           "launches": int(g_n), "avg_launch_ms": round(g_ms / max(g_n, 1), 5),
                            "algorithmic_gflop_per_launch": round(gemm_flops / max(g_n, 1) / 1e9, 4), "mfma_passes_per_product": 3,
                            "per_kernel_ms": {k: round(v[0], 3) for k, v in prof.items() if v[1]}}
 

@@ -42,10 +42,13 @@ std::vector<ProfRec> g_prof;
 double g_prof_ms[P_COUNT] = {0};
 long long g_prof_n[P_COUNT] = {0};
 
+void prof_drain();
+
 struct ProfScope {
   hipStream_t s; int idx = -1;
   ProfScope(int cls, hipStream_t st) : s(st) {
     if (!g_prof_on) return;
+    if (g_prof.size() >= 2048) prof_drain();     // bound the number of live HIP events (profiling mode only)
     ProfRec r; r.cls = cls;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     (void)hipEventRecord(r.a, s);
