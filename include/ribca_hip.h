@@ -22,6 +22,7 @@ extern "C" {
 #endif
 
 typedef struct ribca_vit ribca_vit_t;
+typedef struct ribca_mae ribca_mae_t;
 
 int ribca_version(void);
 const char* ribca_last_error(void);
@@ -98,6 +99,25 @@ int ribca_vit_forward(const ribca_vit_t* m, const float* patches, int32_t c_img,
 
 /* Algorithmic FLOPs per cell of this model (BASELINE.md section 3 formula). */
 double ribca_vit_flops_per_cell(const ribca_vit_t* m);
+
+/* ---- marker imputer (MarkerImputer / MaskedAutoencoderViT, markerImputer.py:69-329) --------------------------------
+ * Tokens are the panel's L channels (each 40x40 plane = 1600 pixels); encoder 768 wide / 12 heads over the present
+ * channels + CLS, decoder 512 / 8 heads over all L + CLS, linear prediction of the missing planes.
+ * Blob order (state-dict keys of the *_impute.pth checkpoints): cls_token[768], pos_embed[(L+1)*768],
+ * patch_embed.proj.weight[768*1600], patch_embed.proj.bias[768], blocks.* (same 12 tensors per block as the classifier),
+ * norm.weight, norm.bias, decoder_embed.weight[512*768], decoder_embed.bias[512], mask_token[512],
+ * decoder_pos_embed[(L+1)*512], decoder_blocks.*, decoder_norm.weight, decoder_norm.bias,
+ * decoder_pred.weight[1600*512], decoder_pred.bias[1600]. */
+int64_t ribca_mae_blob_len(int32_t L, int32_t enc_depth, int32_t dec_depth);
+int ribca_mae_create(const float* blob, int64_t blob_len, int32_t L, int32_t enc_depth, int32_t dec_depth, void* stream,
+                     ribca_mae_t** out);
+void ribca_mae_destroy(ribca_mae_t* m);
+int64_t ribca_mae_workspace_bytes(const ribca_mae_t* m, int32_t chunk_cells, int32_t n_present);
+/* Replaces MarkerImputer.impute (markerImputer.py:294-329): patches (n_cells, L, 40, 40) fp32 in place -- every channel
+ * position NOT listed in present_host (HOST array, strictly increasing, n_present entries) is overwritten by the
+ * prediction; listed channels are left bit-for-bit untouched.  Synchronises the stream once (index tables upload). */
+int ribca_mae_impute(const ribca_mae_t* m, float* patches, const int32_t* present_host, int32_t n_present, int32_t n_cells,
+                     void* workspace, int64_t workspace_bytes, int32_t chunk_cells, void* stream);
 
 /* ---- vote (Annotator.merge_by_voting, model.py:481-633) ------------------------------------------------------ */
 /* Global class ids: 0..16 = key order of utils.get_void_vote (utils.py:143-146), 17 = "Others".

@@ -35,6 +35,11 @@ SIGNATURES = {
     "ribca_vit_workspace_bytes": (c_int64, [c_void_p, c_int32]),
     "ribca_vit_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "ribca_vit_flops_per_cell": (c_double, [c_void_p]),
+    "ribca_mae_blob_len": (c_int64, [c_int32, c_int32, c_int32]),
+    "ribca_mae_create": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, POINTER(c_void_p)]),
+    "ribca_mae_destroy": (None, [c_void_p]),
+    "ribca_mae_workspace_bytes": (c_int64, [c_void_p, c_int32, c_int32]),
+    "ribca_mae_impute": (c_int32, [c_void_p, c_void_p, POINTER(c_int32), c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p]),
     "ribca_vote": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_float, c_int32, c_void_p, c_void_p,
                              c_void_p]),
     "ribca_prof_enable": (c_int32, [c_int32]),

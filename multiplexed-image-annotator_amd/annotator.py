@@ -102,6 +102,7 @@ class Annotator(object):
         else:
             self.cell_type_confidence = cell_type_confidence
         self.models: Dict[str, ops.VitModel] = {}
+        self.imputers: Dict[str, ops.MaeModel] = {}
         self._weights: Dict[str, Dict[str, torch.Tensor]] = {}
         self.probs: List[Dict[str, np.ndarray]] = []       # per image: model -> (n, K) fp32 host table
         self.label_ids: List[np.ndarray] = []
@@ -129,6 +130,20 @@ class Annotator(object):
             self.models[name] = ops.VitModel(sd, dev)
         self._loaded = True
 
+    def _imputer(self, panel: str) -> "ops.MaeModel":
+        """markerImputer.py:258-287: ``<panel>_impute.pth`` next to the classifier checkpoints, else ValueError("Panel not found")."""
+        if panel not in self.imputers:
+            sd = self._weights.get(panel + "_impute")
+            path = os.path.join(MODEL_DIR, panel + "_impute.pth")
+            if sd is None and panel in ("immune_full", "immune_extended", "immune_base") and os.path.exists(path):
+                sd = torch.load(path, map_location="cpu", weights_only=False)["model"]
+            if sd is None:
+                raise ValueError("Panel not found")
+            self.imputers[panel] = ops.MaeModel(sd, _lib.require_gpu())
+            missing = [self.channel_parser.panels[panel][i] for i, c in enumerate(self.channel_parser.indices[panel]) if c == -1]
+            self.logger.log("Imputer for {} is created. Marker(s) {} are imputed.".format(panel, " ".join(missing)))
+        return self.imputers[panel]
+
     # ---- pipeline --------------------------------------------------------------------------------------------------
     def preprocess(self):
         rank, ws = self.rank, self.world_size
@@ -155,11 +170,16 @@ class Annotator(object):
         n = len(pre.cell_ids[image_idx])
         lo, hi = pre.shards[image_idx]
         c_img = pre.images_dev[image_idx].shape[0]
-        if self.infer and -1 in index and model_name not in ("struct",):
-            raise NotImplementedError("marker imputation (infer=True with missing markers, markerImputer.py) is not on the GPU path yet; "
-                                      "pass infer=False to use blank planes like the reference does without imputer weights")
         src = ops.resolve_channels(index, c_img)
         patches = pre.panel_patches(image_idx)
+        # preprocess.py:268-281: missing markers of an immune panel are imputed unless infer is off (never for structure / nerve)
+        if self.infer and -1 in index and MODEL_PANEL[model_name] not in ("structure", "nerve"):
+            imputer = self._imputer(MODEL_PANEL[model_name])
+            sel = torch.tensor([max(c, 0) for c in src], dtype=torch.long, device=patches.device)
+            panel = patches.index_select(1, sel).contiguous()           # channel gather (layout only); blanks are overwritten below
+            present = [i for i, c in enumerate(index) if c != -1]
+            imputer.impute(panel, present, chunk_cells=self.chunk_cells)
+            patches, src = panel, list(range(len(index)))
         local = model.predict_proba(patches, src, chunk_cells=self.chunk_cells)
         full = dist.all_gather_rows(local, n) if self.world_size > 1 else local
         return full

@@ -18,25 +18,27 @@
 
 namespace ribca {
 
-template <int KS /* hdp/32 */, int DT /* hdv/16 */>
+template <int KS /* hdp/32 */, int DT /* hdv/16 */, int NT /* 16-token tiles: 7 for the 101-token classifiers, 1 for the imputer */>
 __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K,
                                                         const uint16_t* __restrict__ Vt, uint16_t* __restrict__ out, int ldo,
-                                                        int n_pairs, int hd) {
+                                                        int n_pairs, int hd, int H, int T) {
   const int lane = threadIdx.x & 63;
   const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);  // (cell, head) index, wave-uniform
   if (pair >= n_pairs) return;
-  const int cell = pair / kHeads, head = pair - cell * kHeads;
+  const int cell = pair / H, head = pair - cell * H;
   const int r16 = lane & 15, g = lane >> 4;
+  constexpr int KST = (NT + 1) / 2;         // 32-key steps of the P*V product
+  constexpr int TP = 16 * NT;
   constexpr int ROW = 2 * KS * 32;          // bf16 per Q/K row
-  constexpr int VROW = 2 * kKeyPad;         // bf16 per V^T row
-  const uint16_t* qb = Q + (size_t)pair * kTokPad * ROW;
-  const uint16_t* kb = K + (size_t)pair * kTokPad * ROW;
+  constexpr int VROW = 2 * 32 * KST;        // bf16 per V^T row
+  const uint16_t* qb = Q + (size_t)pair * TP * ROW;
+  const uint16_t* kb = K + (size_t)pair * TP * ROW;
   const uint16_t* vb = Vt + (size_t)pair * (DT * 16) * VROW;
 
-  // K fragments stay in registers for all 7 query tiles
-  bf16x8 khi[7][KS], klo[7][KS];
+  // K fragments stay in registers for all query tiles
+  bf16x8 khi[NT][KS], klo[NT][KS];
 #pragma unroll
-  for (int kt = 0; kt < 7; ++kt)
+  for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const uint4* p = reinterpret_cast<const uint4*>(kb + (size_t)(kt * 16 + r16) * ROW + ks * 64 + g * 16);
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
       klo[kt][ks] = __builtin_bit_cast(bf16x8, p[1]);
     }
 
-  for (int qt = 0; qt < 7; ++qt) {
+  for (int qt = 0; qt < NT; ++qt) {
     bf16x8 qhi[KS], qlo[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -52,9 +54,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
       qhi[ks] = __builtin_bit_cast(bf16x8, p[0]);
       qlo[ks] = __builtin_bit_cast(bf16x8, p[1]);
     }
-    f32x4 s[8];
+    f32x4 s[2 * KST];
 #pragma unroll
-    for (int kt = 0; kt < 7; ++kt) {
+    for (int kt = 0; kt < NT; ++kt) {
       s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -63,20 +65,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
         s[kt] = mfma_bf16(khi[kt][ks], qhi[ks], s[kt]);
       }
     }
-    // keys 101..111 (tile 6, 4g+r >= 5) are padding
+    // keys >= T (only possible in the last tile) are padding
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (4 * g + r >= kTokens - 96) s[6][r] = -INFINITY;
+      if (16 * (NT - 1) + 4 * g + r >= T) s[NT - 1][r] = -INFINITY;
     float mx = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < 7; ++kt)
+    for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < 7; ++kt)
+    for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float e = __expf(s[kt][r] - mx);
@@ -86,11 +88,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
-    s[7] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (NT & 1) s[NT] = f32x4{0.f, 0.f, 0.f, 0.f};
     // P fragments: k-step t covers key tiles 2t (elements 0..3) and 2t+1 (elements 4..7)
-    bf16x8 phi[4], plo[4];
+    bf16x8 phi[KST], plo[KST];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < KST; ++t) {
       float pa[4], pb[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) { pa[r] = s[2 * t][r] * inv; pb[r] = s[2 * t + 1][r] * inv; }
@@ -101,12 +103,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
       plo[t] = __builtin_bit_cast(bf16x8, uint4{la.x, la.y, lb.x, lb.y});
     }
     const int qtok = qt * 16 + r16;
-    uint16_t* orow = out + ((size_t)cell * kTokens + qtok) * ldo;
+    uint16_t* orow = out + ((size_t)cell * T + qtok) * ldo;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < KST; ++t) {
         const uint4* p = reinterpret_cast<const uint4*>(vb + (size_t)(dt * 16 + r16) * VROW + (4 * t + g) * 16);
         const bf16x8 vhi = __builtin_bit_cast(bf16x8, p[0]);
         const bf16x8 vlo = __builtin_bit_cast(bf16x8, p[1]);
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
         o = mfma_bf16(vhi, phi[t], o);
       }
       const int d = dt * 16 + 4 * g;  // o[r] = O[query = qtok][head dim d + r]
-      if (qtok < kTokens && d < hd) {
+      if (qtok < T && d < hd) {
         float v[4] = {o[0], o[1], o[2], o[3]};
         ps_store4(orow, head * hd + d, v);
       }
@@ -123,22 +125,37 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
   }
 }
 
-void launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int ldo, int cells, int hd, int hdp,
-                      int hdv, hipStream_t s) {
-  const int pairs = cells * kHeads;
+AttnGeom make_attn_geom(int D, int H, int T) {
+  AttnGeom a;
+  a.D = D; a.H = H; a.hd = D / H; a.T = T;
+  a.hdp = (a.hd + 31) / 32 * 32;
+  a.hdv = (a.hd + 15) / 16 * 16;
+  a.NT = (T + 15) / 16;
+  a.TP = 16 * a.NT;
+  a.KP = 32 * ((a.NT + 1) / 2);
+  return a;
+}
+
+void launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int ldo, int cells, const AttnGeom& a,
+                      hipStream_t s) {
+  const int pairs = cells * a.H;
   if (pairs <= 0) return;
   const dim3 grid((pairs + 3) / 4), block(256);
-  const int ks = hdp / 32, dt = hdv / 16;
-#define RIBCA_ATT(KS_, DT_) \
-  hipLaunchKernelGGL((attention_kernel<KS_, DT_>), grid, block, 0, s, q, k, vt, out, ldo, pairs, hd)
-  if (ks == 1 && dt == 1) RIBCA_ATT(1, 1);
-  else if (ks == 1 && dt == 2) RIBCA_ATT(1, 2);
-  else if (ks == 2 && dt == 3) RIBCA_ATT(2, 3);
-  else if (ks == 2 && dt == 4) RIBCA_ATT(2, 4);
-  else if (ks == 1 && dt == 3) RIBCA_ATT(1, 3);
-  else if (ks == 1 && dt == 4) RIBCA_ATT(1, 4);
-  else abort();
+  const int ks = a.hdp / 32, dt = a.hdv / 16;
+#define RIBCA_ATT(KS_, DT_, NT_) \
+  hipLaunchKernelGGL((attention_kernel<KS_, DT_, NT_>), grid, block, 0, s, q, k, vt, out, ldo, pairs, a.hd, a.H, a.T)
+  if (a.NT == 7 && ks == 1 && dt == 1) RIBCA_ATT(1, 1, 7);
+  else if (a.NT == 7 && ks == 1 && dt == 2) RIBCA_ATT(1, 2, 7);
+  else if (a.NT == 7 && ks == 2 && dt == 3) RIBCA_ATT(2, 3, 7);
+  else if (a.NT == 1 && ks == 2 && dt == 4) RIBCA_ATT(2, 4, 1);
+  else if (a.NT == 1 && ks == 1 && dt == 2) RIBCA_ATT(1, 2, 1);
+  else abort();   // geometry is validated by the C ABI before any launch
 #undef RIBCA_ATT
+}
+
+bool attention_supported(const AttnGeom& a) {
+  const int ks = a.hdp / 32, dt = a.hdv / 16;
+  return (a.NT == 7 && ((ks == 1 && (dt == 1 || dt == 2)) || (ks == 2 && dt == 3))) || (a.NT == 1 && ((ks == 2 && dt == 4) || (ks == 1 && dt == 2)));
 }
 
 }  // namespace ribca

@@ -93,6 +93,7 @@ struct EpiEmbed {
 
 struct EpiQKV {
   uint16_t* q; uint16_t* k; uint16_t* vt; const float* bias; int D, hd, hdp, hdv; float scale; int M, N;
+  int T, TP, H, KP;   // tokens per cell, padded token rows of Q/K, heads, padded keys per V^T row
   struct Ctx {};
   __device__ __forceinline__ float4 fetch_bias(int n) const {
     return n < N ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
@@ -104,30 +105,54 @@ struct EpiQKV {
     const int f = n - which * D;
     const int head = f / hd;
     const int d = f - head * hd;  // multiple of 4, d+3 < hd (hd % 4 == 0)
-    const int cell = m / kTokens, t = m - cell * kTokens;
+    const int cell = m / T, t = m - cell * T;
     float x[4] = {v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w};
-    const size_t ch = (size_t)cell * kHeads + head;
+    const size_t ch = (size_t)cell * H + head;
     if (which < 2) {
       if (which == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) x[i] *= scale;
       }
-      uint16_t* row = (which == 0 ? q : k) + (ch * kTokPad + t) * (size_t)(2 * hdp);
+      uint16_t* row = (which == 0 ? q : k) + (ch * TP + t) * (size_t)(2 * hdp);
       ps_store4(row, d, x);
     } else {
       // V^T[d][key], key order permuted inside each 32-key block so that the 8 keys a lane group owns after the
       // K*Q^T MFMA (two 16-key tiles, rows 4g..4g+3 of each) are contiguous: key = 32s+16u+4g+r -> 32s+8g+4u+r
       const int pos = (t & ~31) | (((t >> 2) & 3) << 3) | (((t >> 4) & 1) << 2) | (t & 3);
-      uint16_t* base = vt + ch * (size_t)hdv * (2 * kKeyPad) + ps_off(pos);
+      uint16_t* base = vt + ch * (size_t)hdv * (2 * KP) + ps_off(pos);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         uint16_t hi, lo;
         split_bf16(x[i], hi, lo);
-        uint16_t* p = base + (size_t)(d + i) * (2 * kKeyPad);
+        uint16_t* p = base + (size_t)(d + i) * (2 * KP);
         p[0] = hi;
         p[8] = lo;
       }
     }
+  }
+};
+
+// fp32 output with a per-cell row map (marker imputer): GEMM row m = cell * R + j is written to row
+// cell * dst_per_cell + slot[j] of `out`, plus bias and an optional table row add[addrow[j]] (positional embeddings).
+struct EpiRowMap {
+  float* out; int ldo; const float* bias; const float* add; int ldadd; const int* slot; const int* addrow; int R, dst_per_cell; int M, N;
+  struct Ctx { float4 a; };
+  __device__ __forceinline__ float4 fetch_bias(int n) const {
+    return n < N ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  __device__ __forceinline__ void fetch(int m, int n, Ctx& c) const {
+    c.a = float4{0.f, 0.f, 0.f, 0.f};
+    if (add != nullptr && m < M && n < N) {
+      const int cell = m / R, j = m - cell * R;
+      c.a = *reinterpret_cast<const float4*>(add + (size_t)addrow[j] * ldadd + n);
+    }
+  }
+  __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx& c) const {
+    if (m >= M || n >= N) return;
+    const int cell = m / R, j = m - cell * R;
+    float4 o;
+    o.x = v[0] + b.x + c.a.x; o.y = v[1] + b.y + c.a.y; o.z = v[2] + b.z + c.a.z; o.w = v[3] + b.w + c.a.w;
+    *reinterpret_cast<float4*>(out + ((size_t)cell * dst_per_cell + slot[j]) * ldo + n) = o;
   }
 };
 
@@ -738,9 +763,12 @@ void launch_gemm_gelu(const GemmArgs& g, uint16_t* out, int ldo, hipStream_t s) 
 void launch_gemm_embed(const GemmArgs& g, float* z, int ldz, const float* pos, int D, hipStream_t s) {
   launch_any(g, EpiEmbed{z, ldz, g.bias, pos, D, g.M, g.N}, s);
 }
-void launch_gemm_qkv(const GemmArgs& g, uint16_t* q, uint16_t* k, uint16_t* vt, int D, int hd, int hdp, int hdv, float scale,
-                     hipStream_t s) {
-  launch_any(g, EpiQKV{q, k, vt, g.bias, D, hd, hdp, hdv, scale, g.M, g.N}, s);
+void launch_gemm_qkv(const GemmArgs& g, uint16_t* q, uint16_t* k, uint16_t* vt, const AttnGeom& a, float scale, hipStream_t s) {
+  launch_any(g, EpiQKV{q, k, vt, g.bias, a.D, a.hd, a.hdp, a.hdv, scale, g.M, g.N, a.T, a.TP, a.H, a.KP}, s);
+}
+void launch_gemm_rowmap(const GemmArgs& g, float* out, int ldo, const float* add, int ldadd, const int* slot, const int* addrow, int R,
+                        int dst_per_cell, hipStream_t s) {
+  launch_any(g, EpiRowMap{out, ldo, g.bias, add, ldadd, slot, addrow, R, dst_per_cell, g.M, g.N}, s);
 }
 
 }  // namespace ribca

@@ -71,21 +71,35 @@ void prof_drain() {
 
 }  // namespace
 
-// ----------------------------------------------------------------------------------------------- model handle
+// ----------------------------------------------------------------------------------------------- model handles
+// weights of one pre-LN transformer block (timm Block): fp32 vectors + packed-split matrices
+struct BlockW {
+  const float *ln1w, *ln1b, *qkvb, *projb, *ln2w, *ln2b, *fc1b, *fc2b;
+  const uint16_t *qkvw, *projw, *fc1w, *fc2w;
+};
+
 struct ribca_vit {
-  int D, C, K, depth, hd, hdp, hdv, Dp, Kpe, H4;
+  int D, C, K, depth, hd, hdp, hdv, Dp, H4;
   char* arena = nullptr;
   size_t arena_bytes = 0;
   const float *cls, *pos, *pe_b, *norm_w, *norm_b, *head_w, *head_b;
   const float* pe_w;   // fp32 [D][16*C]: the patch embedding stays in fp32 (vit_misc.hip embed_f32_kernel)
-  struct Layer {
-    const float *ln1w, *ln1b, *qkvb, *projb, *ln2w, *ln2b, *fc1b, *fc2b;
-    const uint16_t *qkvw, *projw, *fc1w, *fc2w;
-  };
-  std::vector<Layer> layers;
+  std::vector<BlockW> layers;
+};
+
+// marker imputer (reference markerImputer.py:69-329): encoder 768 / 12 heads, decoder 512 / 8 heads, tokens = channels
+struct ribca_mae {
+  int L, enc_depth, dec_depth;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  const float *cls, *pos, *pe_b, *norm_w, *norm_b, *de_b, *mask_tok, *dpos, *dnorm_w, *dnorm_b, *pred_b;
+  const uint16_t *pe_w, *de_w, *pred_w;
+  std::vector<BlockW> enc, dec;
 };
 
 namespace {
+
+constexpr int kEncD = 768, kEncH = 12, kDecD = 512, kDecH = 8, kTokPix = 1600;
 
 struct Carver {
   char* base; size_t off = 0;
@@ -97,6 +111,18 @@ struct Carver {
   }
 };
 
+void layout_block(Carver& c, BlockW& L, int D) {
+  const int Dp = round_up(D, 32), H4 = 4 * D;
+  L.ln1w = c.take<float>(D); L.ln1b = c.take<float>(D);
+  L.qkvb = c.take<float>(3 * D); L.projb = c.take<float>(D);
+  L.ln2w = c.take<float>(D); L.ln2b = c.take<float>(D);
+  L.fc1b = c.take<float>(4 * D); L.fc2b = c.take<float>(D);
+  L.qkvw = c.take<uint16_t>((size_t)gemm_padded_n(3 * D) * 2 * Dp);
+  L.projw = c.take<uint16_t>((size_t)gemm_padded_n(D) * 2 * Dp);
+  L.fc1w = c.take<uint16_t>((size_t)gemm_padded_n(4 * D) * 2 * Dp);
+  L.fc2w = c.take<uint16_t>((size_t)gemm_padded_n(D) * 2 * H4);
+}
+
 // lays the arena out; with base == nullptr only measures
 size_t layout(ribca_vit* m, char* base) {
   Carver c(base);
@@ -106,40 +132,114 @@ size_t layout(ribca_vit* m, char* base) {
   m->pe_b = c.take<float>(D);
   m->pe_w = c.take<float>((size_t)D * 16 * m->C);
   m->layers.resize(m->depth);
-  for (auto& L : m->layers) {
-    L.ln1w = c.take<float>(D); L.ln1b = c.take<float>(D);
-    L.qkvb = c.take<float>(3 * D); L.projb = c.take<float>(D);
-    L.ln2w = c.take<float>(D); L.ln2b = c.take<float>(D);
-    L.fc1b = c.take<float>(4 * D); L.fc2b = c.take<float>(D);
-    L.qkvw = c.take<uint16_t>((size_t)gemm_padded_n(3 * D) * 2 * m->Dp);
-    L.projw = c.take<uint16_t>((size_t)gemm_padded_n(D) * 2 * m->Dp);
-    L.fc1w = c.take<uint16_t>((size_t)gemm_padded_n(4 * D) * 2 * m->Dp);
-    L.fc2w = c.take<uint16_t>((size_t)gemm_padded_n(D) * 2 * m->H4);
-  }
+  for (auto& L : m->layers) layout_block(c, L, D);
   m->norm_w = c.take<float>(D); m->norm_b = c.take<float>(D);
   m->head_w = c.take<float>((size_t)m->K * D); m->head_b = c.take<float>(m->K);
   return c.off;
 }
 
-struct Workspace {
-  float* z; uint16_t* xa; uint16_t* q; uint16_t* k; uint16_t* vt; uint16_t* h;
-  size_t qk_bytes, vt_bytes, xa_bytes, total;
-};
-Workspace carve_ws(const ribca_vit* m, int chunk, char* base) {
+size_t layout_mae(ribca_mae* m, char* base) {
   Carver c(base);
-  Workspace w;
-  const size_t Mc = (size_t)chunk * kTokens;
-  w.z = c.take<float>(Mc * m->D);
-  w.xa_bytes = Mc * 2 * m->Dp * sizeof(uint16_t);
-  w.xa = c.take<uint16_t>(Mc * 2 * m->Dp);
-  w.qk_bytes = (size_t)chunk * kHeads * kTokPad * 2 * m->hdp * sizeof(uint16_t);
-  w.q = c.take<uint16_t>((size_t)chunk * kHeads * kTokPad * 2 * m->hdp);
-  w.k = c.take<uint16_t>((size_t)chunk * kHeads * kTokPad * 2 * m->hdp);
-  w.vt_bytes = (size_t)chunk * kHeads * m->hdv * 2 * kKeyPad * sizeof(uint16_t);
-  w.vt = c.take<uint16_t>((size_t)chunk * kHeads * m->hdv * 2 * kKeyPad);
-  w.h = c.take<uint16_t>(Mc * 2 * m->H4);
-  w.total = c.off;
+  m->cls = c.take<float>(kEncD);
+  m->pos = c.take<float>((size_t)(m->L + 1) * kEncD);
+  m->pe_w = c.take<uint16_t>((size_t)gemm_padded_n(kEncD) * 2 * kTokPix);
+  m->pe_b = c.take<float>(kEncD);
+  m->enc.resize(m->enc_depth);
+  for (auto& L : m->enc) layout_block(c, L, kEncD);
+  m->norm_w = c.take<float>(kEncD); m->norm_b = c.take<float>(kEncD);
+  m->de_w = c.take<uint16_t>((size_t)gemm_padded_n(kDecD) * 2 * kEncD);
+  m->de_b = c.take<float>(kDecD);
+  m->mask_tok = c.take<float>(kDecD);
+  m->dpos = c.take<float>((size_t)(m->L + 1) * kDecD);
+  m->dec.resize(m->dec_depth);
+  for (auto& L : m->dec) layout_block(c, L, kDecD);
+  m->dnorm_w = c.take<float>(kDecD); m->dnorm_b = c.take<float>(kDecD);
+  m->pred_w = c.take<uint16_t>((size_t)gemm_padded_n(kTokPix) * 2 * kDecD);
+  m->pred_b = c.take<float>(kTokPix);
+  return c.off;
+}
+
+// copies / packs one block's parameters from the flat fp32 blob (state-dict order), advancing p
+struct BlobReader {
+  const float* p; hipStream_t s; hipError_t err = hipSuccess;
+  void copy(const float* dst, size_t n) {
+    hipError_t r = hipMemcpyAsync((void*)dst, p, n * sizeof(float), hipMemcpyDeviceToDevice, s);
+    if (err == hipSuccess) err = r;
+    p += n;
+  }
+  void pack(const uint16_t* dst, int N, int K, int Kp) {
+    launch_pack_weight(p, N, K, const_cast<uint16_t*>(dst), gemm_padded_n(N), Kp, s);
+    p += (size_t)N * K;
+  }
+  void block(const BlockW& L, int D) {
+    const int Dp = round_up(D, 32);
+    copy(L.ln1w, D); copy(L.ln1b, D);
+    pack(L.qkvw, 3 * D, D, Dp); copy(L.qkvb, 3 * D);
+    pack(L.projw, D, D, Dp); copy(L.projb, D);
+    copy(L.ln2w, D); copy(L.ln2b, D);
+    pack(L.fc1w, 4 * D, D, Dp); copy(L.fc1b, 4 * D);
+    pack(L.fc2w, D, 4 * D, 4 * D); copy(L.fc2b, D);
+  }
+};
+int64_t block_params(int64_t d) { return 2 * d + 3 * d * d + 3 * d + d * d + d + 2 * d + 4 * d * d + 4 * d + 4 * d * d + d; }
+
+// scratch for a run of transformer blocks over `cells` cells of T tokens, width D
+struct BlockWs {
+  float* z; uint16_t* xa; uint16_t* q; uint16_t* k; uint16_t* vt; uint16_t* h;
+  size_t qk_bytes, vt_bytes, xa_bytes;
+};
+BlockWs carve_blocks(Carver& c, int cells, const AttnGeom& a) {
+  BlockWs w;
+  const size_t Mc = (size_t)cells * a.T;
+  const int Dp = round_up(a.D, 32);
+  w.z = c.take<float>(Mc * a.D);
+  w.xa_bytes = Mc * 2 * Dp * sizeof(uint16_t);
+  w.xa = c.take<uint16_t>(Mc * 2 * Dp);
+  const size_t qk = (size_t)cells * a.H * a.TP * 2 * a.hdp;
+  w.qk_bytes = qk * sizeof(uint16_t);
+  w.q = c.take<uint16_t>(qk);
+  w.k = c.take<uint16_t>(qk);
+  const size_t vt = (size_t)cells * a.H * a.hdv * 2 * a.KP;
+  w.vt_bytes = vt * sizeof(uint16_t);
+  w.vt = c.take<uint16_t>(vt);
+  w.h = c.take<uint16_t>(Mc * 2 * 4 * a.D);
   return w;
+}
+// pads (tokens >= T, head dims >= hd, feature columns >= D) are never written by any kernel: zero them once per call
+int zero_pads(const BlockWs& w, hipStream_t s) {
+  HIP_TRY(hipMemsetAsync(w.xa, 0, w.xa_bytes, s));
+  HIP_TRY(hipMemsetAsync(w.q, 0, w.qk_bytes, s));
+  HIP_TRY(hipMemsetAsync(w.k, 0, w.qk_bytes, s));
+  HIP_TRY(hipMemsetAsync(w.vt, 0, w.vt_bytes, s));
+  return 0;
+}
+// one pre-LN block on z (cells*T rows): z += proj(attn(LN1 z)); z += fc2(gelu(fc1(LN2 z)))
+void run_block(const BlockW& L, const BlockWs& w, int cells, const AttnGeom& a, hipStream_t s) {
+  const int D = a.D, Dp = round_up(D, 32), ld_x = 2 * Dp, ld_h = 2 * 4 * D, Mc = cells * a.T;
+  const float scale = 1.0f / sqrtf((float)a.hd);
+  { ProfScope ps(P_LN, s); launch_layernorm_ps(w.z, D, L.ln1w, L.ln1b, w.xa, ld_x, Mc, D, s); }
+  {
+    ProfScope ps(P_QKV, s);
+    GemmArgs g{w.xa, ld_x, L.qkvw, ld_x, Mc, 3 * D, Dp, L.qkvb};
+    launch_gemm_qkv(g, w.q, w.k, w.vt, a, scale, s);
+  }
+  { ProfScope ps(P_ATTN, s); launch_attention(w.q, w.k, w.vt, w.xa, ld_x, cells, a, s); }
+  {
+    ProfScope ps(P_PROJ, s);
+    GemmArgs g{w.xa, ld_x, L.projw, ld_x, Mc, D, Dp, L.projb};
+    launch_gemm_resid(g, w.z, D, s);
+  }
+  { ProfScope ps(P_LN, s); launch_layernorm_ps(w.z, D, L.ln2w, L.ln2b, w.xa, ld_x, Mc, D, s); }
+  {
+    ProfScope ps(P_FC1, s);
+    GemmArgs g{w.xa, ld_x, L.fc1w, ld_x, Mc, 4 * D, Dp, L.fc1b};
+    launch_gemm_gelu(g, w.h, ld_h, s);
+  }
+  {
+    ProfScope ps(P_FC2, s);
+    GemmArgs g{w.h, ld_h, L.fc2w, ld_h, Mc, D, 4 * D, L.fc2b};
+    launch_gemm_resid(g, w.z, D, s);
+  }
 }
 
 }  // namespace
@@ -162,6 +262,7 @@ int ribca_vit_create(const float* blob, int64_t blob_len, int32_t D, int32_t C, 
   *out = nullptr;
   if (D <= 0 || D % 48 != 0 || D > 768) return fail("ribca_vit_create: D must be a multiple of 48 and <= 768");
   if (C <= 0 || C > 64 || K <= 0 || K > 16 || depth <= 0) return fail("ribca_vit_create: bad C/K/depth");
+  if (!attention_supported(make_attn_geom(D, kHeads, kTokens))) return fail("ribca_vit_create: unsupported head dimension");
   if (blob_len != ribca_vit_blob_len(D, C, K, depth)) return fail("ribca_vit_create: blob length does not match (D, C, K, depth)");
   hipStream_t s = (hipStream_t)stream;
   ribca_vit* m = new ribca_vit();
@@ -170,45 +271,21 @@ int ribca_vit_create(const float* blob, int64_t blob_len, int32_t D, int32_t C, 
   m->hdp = round_up(m->hd, 32);
   m->hdv = round_up(m->hd, 16);
   m->Dp = round_up(D, 32);
-  m->Kpe = round_up(16 * C, 32);
   m->H4 = 4 * D;  // multiple of 32 because D % 8 == 0
   m->arena_bytes = layout(m, nullptr);
   hipError_t e = hipMalloc((void**)&m->arena, m->arena_bytes);
   if (e != hipSuccess) { delete m; return hip_fail(e, "hipMalloc(weights)"); }
   layout(m, m->arena);
-
-  const float* p = blob;
-  auto copyf = [&](const float* dst, size_t n) -> hipError_t {
-    hipError_t r = hipMemcpyAsync((void*)dst, p, n * sizeof(float), hipMemcpyDeviceToDevice, s);
-    p += n;
-    return r;
-  };
-  auto pack = [&](const uint16_t* dst, int N, int Kdim, int Kp) {
-    launch_pack_weight(p, N, Kdim, const_cast<uint16_t*>(dst), gemm_padded_n(N), Kp, s);
-    p += (size_t)N * Kdim;
-  };
-#define CP(dst, n) do { hipError_t r_ = copyf(dst, n); if (r_ != hipSuccess) { ribca_vit_destroy(m); return hip_fail(r_, "hipMemcpyAsync(param)"); } } while (0)
-  CP(m->cls, D);
-  CP(m->pos, (size_t)kTokens * D);
-  CP(m->pe_w, (size_t)D * 16 * C);
-  CP(m->pe_b, D);
-  for (auto& L : m->layers) {
-    CP(L.ln1w, D); CP(L.ln1b, D);
-    pack(L.qkvw, 3 * D, D, m->Dp);
-    CP(L.qkvb, 3 * D);
-    pack(L.projw, D, D, m->Dp);
-    CP(L.projb, D);
-    CP(L.ln2w, D); CP(L.ln2b, D);
-    pack(L.fc1w, 4 * D, D, m->Dp);
-    CP(L.fc1b, 4 * D);
-    pack(L.fc2w, D, 4 * D, m->H4);
-    CP(L.fc2b, D);
-  }
-  CP(m->norm_w, D); CP(m->norm_b, D);
-  CP(m->head_w, (size_t)K * D); CP(m->head_b, K);
-#undef CP
-  e = hipGetLastError();
-  if (e != hipSuccess) { ribca_vit_destroy(m); return hip_fail(e, "weight packing launch"); }
+  BlobReader r{blob, s};
+  r.copy(m->cls, D);
+  r.copy(m->pos, (size_t)kTokens * D);
+  r.copy(m->pe_w, (size_t)D * 16 * C);
+  r.copy(m->pe_b, D);
+  for (auto& L : m->layers) r.block(L, D);
+  r.copy(m->norm_w, D); r.copy(m->norm_b, D);
+  r.copy(m->head_w, (size_t)K * D); r.copy(m->head_b, K);
+  e = r.err != hipSuccess ? r.err : hipGetLastError();
+  if (e != hipSuccess) { ribca_vit_destroy(m); return hip_fail(e, "weight packing"); }
   *out = m;
   return 0;
 }
@@ -226,7 +303,9 @@ double ribca_vit_flops_per_cell(const ribca_vit_t* m) {
 
 int64_t ribca_vit_workspace_bytes(const ribca_vit_t* m, int32_t chunk_cells) {
   if (!m || chunk_cells <= 0) return 0;
-  return (int64_t)carve_ws(m, chunk_cells, nullptr).total;
+  Carver c(nullptr);
+  carve_blocks(c, chunk_cells, make_attn_geom(m->D, kHeads, kTokens));
+  return (int64_t)c.off;
 }
 
 int ribca_vit_forward(const ribca_vit_t* m, const float* patches, int32_t c_img, const int32_t* src_chan, int32_t n_cells, float* probs,
@@ -236,59 +315,160 @@ int ribca_vit_forward(const ribca_vit_t* m, const float* patches, int32_t c_img,
   if (n_cells == 0) return 0;
   if (!patches || !src_chan || !probs || !workspace) return fail("ribca_vit_forward: NULL buffer");
   if (((uintptr_t)workspace & 255) != 0) return fail("ribca_vit_forward: workspace must be 256-byte aligned");
-  const Workspace w = carve_ws(m, chunk_cells, (char*)workspace);
-  if ((int64_t)w.total > workspace_bytes) return fail("ribca_vit_forward: workspace too small");
+  const AttnGeom geom = make_attn_geom(m->D, kHeads, kTokens);
+  Carver c((char*)workspace);
+  const BlockWs w = carve_blocks(c, chunk_cells, geom);
+  if ((int64_t)c.off > workspace_bytes) return fail("ribca_vit_forward: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  const int D = m->D, Dp = m->Dp, ld_x = 2 * Dp, ld_h = 2 * m->H4;
-  const float scale = 1.0f / sqrtf((float)m->hd);
-
-  // pads (tokens >= 101, head dims >= hd, feature columns >= D) are never written by any kernel: zero them once per call
+  const int D = m->D;
   {
     ProfScope ps(P_OTHER, s);
-    HIP_TRY(hipMemsetAsync(w.xa, 0, w.xa_bytes, s));
-    HIP_TRY(hipMemsetAsync(w.q, 0, w.qk_bytes, s));
-    HIP_TRY(hipMemsetAsync(w.k, 0, w.qk_bytes, s));
-    HIP_TRY(hipMemsetAsync(w.vt, 0, w.vt_bytes, s));
+    if (zero_pads(w, s)) return 1;
   }
   for (int c0 = 0; c0 < n_cells; c0 += chunk_cells) {
     const int bc = n_cells - c0 < chunk_cells ? n_cells - c0 : chunk_cells;
-    const int Mc = bc * kTokens;
     {
       ProfScope ps(P_EMBED, s);
       launch_embed_f32(patches + (size_t)c0 * c_img * 1600, c_img, src_chan, m->C, m->pe_w, m->pe_b, m->pos, w.z, D, D, bc, s);
     }
     {
       ProfScope ps(P_OTHER, s);
-      launch_cls_rows(w.z, D, m->cls, m->pos, D, bc, s);
+      launch_cls_rows(w.z, D, m->cls, m->pos, D, bc, kTokens, s);
     }
-    for (const auto& L : m->layers) {
-      { ProfScope ps(P_LN, s); launch_layernorm_ps(w.z, D, L.ln1w, L.ln1b, w.xa, ld_x, Mc, D, s); }
-      {
-        ProfScope ps(P_QKV, s);
-        GemmArgs g{w.xa, ld_x, L.qkvw, ld_x, Mc, 3 * D, Dp, L.qkvb};
-        launch_gemm_qkv(g, w.q, w.k, w.vt, D, m->hd, m->hdp, m->hdv, scale, s);
-      }
-      { ProfScope ps(P_ATTN, s); launch_attention(w.q, w.k, w.vt, w.xa, ld_x, bc, m->hd, m->hdp, m->hdv, s); }
-      {
-        ProfScope ps(P_PROJ, s);
-        GemmArgs g{w.xa, ld_x, L.projw, ld_x, Mc, D, Dp, L.projb};
-        launch_gemm_resid(g, w.z, D, s);
-      }
-      { ProfScope ps(P_LN, s); launch_layernorm_ps(w.z, D, L.ln2w, L.ln2b, w.xa, ld_x, Mc, D, s); }
-      {
-        ProfScope ps(P_FC1, s);
-        GemmArgs g{w.xa, ld_x, L.fc1w, ld_x, Mc, 4 * D, Dp, L.fc1b};
-        launch_gemm_gelu(g, w.h, ld_h, s);
-      }
-      {
-        ProfScope ps(P_FC2, s);
-        GemmArgs g{w.h, ld_h, L.fc2w, ld_h, Mc, D, m->H4, L.fc2b};
-        launch_gemm_resid(g, w.z, D, s);
-      }
-    }
+    for (const auto& L : m->layers) run_block(L, w, bc, geom, s);
     {
       ProfScope ps(P_HEAD, s);
       launch_head_softmax(w.z, D, m->norm_w, m->norm_b, m->head_w, m->head_b, probs + (size_t)c0 * m->K, D, m->K, bc, s);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------- marker imputer
+int64_t ribca_mae_blob_len(int32_t L, int32_t enc_depth, int32_t dec_depth) {
+  const int64_t e = kEncD, d = kDecD;
+  return e + (int64_t)(L + 1) * e + e * kTokPix + e + enc_depth * block_params(e) + 2 * e + d * e + d + d + (int64_t)(L + 1) * d +
+         dec_depth * block_params(d) + 2 * d + (int64_t)kTokPix * d + kTokPix;
+}
+
+int ribca_mae_create(const float* blob, int64_t blob_len, int32_t L, int32_t enc_depth, int32_t dec_depth, void* stream, ribca_mae_t** out) {
+  if (!out) return fail("ribca_mae_create: out is NULL");
+  *out = nullptr;
+  if (L < 2 || L > 15 || enc_depth <= 0 || dec_depth <= 0) return fail("ribca_mae_create: L must be in [2, 15] (tokens incl. CLS <= 16)");
+  if (blob_len != ribca_mae_blob_len(L, enc_depth, dec_depth)) return fail("ribca_mae_create: blob length does not match (L, depths)");
+  hipStream_t s = (hipStream_t)stream;
+  ribca_mae* m = new ribca_mae();
+  m->L = L; m->enc_depth = enc_depth; m->dec_depth = dec_depth;
+  m->arena_bytes = layout_mae(m, nullptr);
+  hipError_t e = hipMalloc((void**)&m->arena, m->arena_bytes);
+  if (e != hipSuccess) { delete m; return hip_fail(e, "hipMalloc(imputer weights)"); }
+  layout_mae(m, m->arena);
+  BlobReader r{blob, s};
+  r.copy(m->cls, kEncD);
+  r.copy(m->pos, (size_t)(L + 1) * kEncD);
+  r.pack(m->pe_w, kEncD, kTokPix, kTokPix);
+  r.copy(m->pe_b, kEncD);
+  for (auto& B : m->enc) r.block(B, kEncD);
+  r.copy(m->norm_w, kEncD); r.copy(m->norm_b, kEncD);
+  r.pack(m->de_w, kDecD, kEncD, kEncD);
+  r.copy(m->de_b, kDecD);
+  r.copy(m->mask_tok, kDecD);
+  r.copy(m->dpos, (size_t)(L + 1) * kDecD);
+  for (auto& B : m->dec) r.block(B, kDecD);
+  r.copy(m->dnorm_w, kDecD); r.copy(m->dnorm_b, kDecD);
+  r.pack(m->pred_w, kTokPix, kDecD, kDecD);
+  r.copy(m->pred_b, kTokPix);
+  e = r.err != hipSuccess ? r.err : hipGetLastError();
+  if (e != hipSuccess) { ribca_mae_destroy(m); return hip_fail(e, "imputer weight packing"); }
+  *out = m;
+  return 0;
+}
+
+void ribca_mae_destroy(ribca_mae_t* m) {
+  if (!m) return;
+  if (m->arena) (void)hipFree(m->arena);
+  delete m;
+}
+
+namespace {
+struct MaeWs {
+  BlockWs enc, dec;
+  uint16_t* tok_ps;     // present channel tiles as packed-split rows [cells*P][2*1600]; reused for decoder_norm rows [cells*Mi][2*512]
+  int* tables;          // device int tables (6 x 16)
+  size_t total;
+};
+MaeWs carve_mae(const ribca_mae* m, int chunk, int P, char* base) {
+  Carver c(base);
+  MaeWs w;
+  w.enc = carve_blocks(c, chunk, make_attn_geom(kEncD, kEncH, P + 1));
+  w.dec = carve_blocks(c, chunk, make_attn_geom(kDecD, kDecH, m->L + 1));
+  w.tok_ps = c.take<uint16_t>((size_t)chunk * m->L * 2 * kTokPix);
+  w.tables = c.take<int>(6 * 16);
+  w.total = c.off;
+  return w;
+}
+}  // namespace
+
+int64_t ribca_mae_workspace_bytes(const ribca_mae_t* m, int32_t chunk_cells, int32_t n_present) {
+  if (!m || chunk_cells <= 0 || n_present <= 0 || n_present >= m->L) return 0;
+  return (int64_t)carve_mae(m, chunk_cells, n_present, nullptr).total;
+}
+
+int ribca_mae_impute(const ribca_mae_t* m, float* patches, const int32_t* present_host, int32_t n_present, int32_t n_cells, void* workspace,
+                     int64_t workspace_bytes, int32_t chunk_cells, void* stream) {
+  if (!m) return fail("ribca_mae_impute: model is NULL");
+  if (n_cells < 0 || chunk_cells <= 0) return fail("ribca_mae_impute: bad cell counts");
+  const int L = m->L, P = n_present, Mi = L - P;
+  if (!present_host || P <= 0 || P >= L) return fail("ribca_mae_impute: need 1 <= n_present < L");
+  if (n_cells == 0) return 0;
+  if (!patches || !workspace) return fail("ribca_mae_impute: NULL buffer");
+  if (((uintptr_t)workspace & 255) != 0) return fail("ribca_mae_impute: workspace must be 256-byte aligned");
+  // host tables: [0] present, [1] missing, [2] enc slot (1+j), [3] enc pos row (1+present[j]), [4] dec slot/pos (0, 1+present[..]),
+  // [5] dec mask rows (1+missing[j])
+  int tab[6][16] = {};
+  bool seen[16] = {};
+  for (int j = 0; j < P; ++j) {
+    const int c = present_host[j];
+    if (c < 0 || c >= L || seen[c] || (j > 0 && c <= present_host[j - 1])) return fail("ribca_mae_impute: present must be strictly increasing in [0, L)");
+    seen[c] = true;
+    tab[0][j] = c; tab[2][j] = 1 + j; tab[3][j] = 1 + c; tab[4][1 + j] = 1 + c;
+  }
+  for (int c = 0, j = 0; c < L; ++c)
+    if (!seen[c]) { tab[1][j] = c; tab[5][j] = 1 + c; ++j; }
+  const MaeWs w = carve_mae(m, chunk_cells, P, (char*)workspace);
+  if ((int64_t)w.total > workspace_bytes) return fail("ribca_mae_impute: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemcpyAsync(w.tables, tab, sizeof(tab), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));   // `tab` lives on this stack frame
+  const int *t_present = w.tables, *t_missing = w.tables + 16, *t_eslot = w.tables + 32, *t_epos = w.tables + 48, *t_dslot = w.tables + 64,
+            *t_dmask = w.tables + 80;
+  const AttnGeom ge = make_attn_geom(kEncD, kEncH, P + 1), gd = make_attn_geom(kDecD, kDecH, L + 1);
+  if (zero_pads(w.enc, s) || zero_pads(w.dec, s)) return 1;
+  for (int c0 = 0; c0 < n_cells; c0 += chunk_cells) {
+    const int bc = n_cells - c0 < chunk_cells ? n_cells - c0 : chunk_cells;
+    float* pch = patches + (size_t)c0 * L * kTokPix;
+    // encoder input: embed the present channel tiles (markerImputer.py:186-199)
+    launch_rows_to_ps(pch, kTokPix, w.tok_ps, 2 * kTokPix, kTokPix, bc, L, P, t_present, s);
+    {
+      GemmArgs g{w.tok_ps, 2 * kTokPix, m->pe_w, 2 * kTokPix, bc * P, kEncD, kTokPix, m->pe_b};
+      launch_gemm_rowmap(g, w.enc.z, kEncD, m->pos, kEncD, t_eslot, t_epos, P, P + 1, s);
+    }
+    launch_cls_rows(w.enc.z, kEncD, m->cls, m->pos, kEncD, bc, P + 1, s);
+    for (const auto& B : m->enc) run_block(B, w.enc, bc, ge, s);
+    // decoder input (markerImputer.py:208-219): project latents, mask tokens at the missing positions, + decoder pos
+    launch_layernorm_ps(w.enc.z, kEncD, m->norm_w, m->norm_b, w.enc.xa, 2 * kEncD, bc * (P + 1), kEncD, s);
+    {
+      GemmArgs g{w.enc.xa, 2 * kEncD, m->de_w, 2 * kEncD, bc * (P + 1), kDecD, kEncD, m->de_b};
+      launch_gemm_rowmap(g, w.dec.z, kDecD, m->dpos, kDecD, t_dslot, t_dslot, P + 1, L + 1, s);
+    }
+    launch_fill_rows(w.dec.z, kDecD, m->mask_tok, m->dpos, kDecD, bc, L + 1, Mi, t_dmask, s);
+    for (const auto& B : m->dec) run_block(B, w.dec, bc, gd, s);
+    // predict only the missing channels and write them into the patch tensor (blend, markerImputer.py:312-326)
+    launch_layernorm_gather_ps(w.dec.z, kDecD, m->dnorm_w, m->dnorm_b, w.tok_ps, 2 * kDecD, bc, L + 1, Mi, t_dmask, kDecD, s);
+    {
+      GemmArgs g{w.tok_ps, 2 * kDecD, m->pred_w, 2 * kDecD, bc * Mi, kTokPix, kDecD, m->pred_b};
+      launch_gemm_rowmap(g, pch, kTokPix, nullptr, 0, t_missing, t_missing, Mi, L, s);
     }
   }
   HIP_TRY(hipGetLastError());
@@ -428,10 +608,10 @@ int ribca_test_gemm(int32_t kind, const uint16_t* A, int32_t lda, const uint16_t
 }
 int ribca_test_qkv_attention(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t cells, int32_t D, int32_t Kp,
                              const float* bias, uint16_t* q, uint16_t* k, uint16_t* vt, uint16_t* out, int32_t ldo, void* stream) {
-  const int hd = D / kHeads, hdp = round_up(hd, 32), hdv = round_up(hd, 16);
+  const AttnGeom a = make_attn_geom(D, kHeads, kTokens);
   GemmArgs g{A, lda, W, ldw, cells * kTokens, 3 * D, Kp, bias};
-  launch_gemm_qkv(g, q, k, vt, D, hd, hdp, hdv, 1.0f / sqrtf((float)hd), (hipStream_t)stream);
-  launch_attention(q, k, vt, out, ldo, cells, hd, hdp, hdv, (hipStream_t)stream);
+  launch_gemm_qkv(g, q, k, vt, a, 1.0f / sqrtf((float)a.hd), (hipStream_t)stream);
+  launch_attention(q, k, vt, out, ldo, cells, a, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return 0;
 }

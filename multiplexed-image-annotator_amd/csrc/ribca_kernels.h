@@ -23,14 +23,23 @@ void launch_gemm_resid(const GemmArgs& g, float* z, int ldz, hipStream_t s);
 void launch_gemm_gelu(const GemmArgs& g, uint16_t* out, int ldo, hipStream_t s);
 // patch-embed: row m = cell*100 + t  ->  z[cell*101 + 1 + t][n] = acc + bias + pos[1+t][n]
 void launch_gemm_embed(const GemmArgs& g, float* z, int ldz, const float* pos, int D, hipStream_t s);
+// geometry of one attention problem: D = H*hd features, T tokens per cell; Q/K rows padded to TP = 16*NT tokens and hdp dims,
+// V^T rows = hdv head dims x KP keys (KP = 32*ceil(NT/2))
+struct AttnGeom {
+  int D, H, hd, hdp, hdv, T, NT, TP, KP;
+};
+AttnGeom make_attn_geom(int D, int H, int T);
+bool attention_supported(const AttnGeom& a);
 // qkv: scatter into per-head attention operands (Q pre-scaled by hd^-0.5, V transposed + key-permuted)
-void launch_gemm_qkv(const GemmArgs& g, uint16_t* q, uint16_t* k, uint16_t* vt, int D, int hd, int hdp, int hdv, float scale,
-                     hipStream_t s);
+void launch_gemm_qkv(const GemmArgs& g, uint16_t* q, uint16_t* k, uint16_t* vt, const AttnGeom& a, float scale, hipStream_t s);
+// fp32 output through a per-cell row map (imputer embeddings / predictions), see EpiRowMap
+void launch_gemm_rowmap(const GemmArgs& g, float* out, int ldo, const float* add, int ldadd, const int* slot, const int* addrow, int R,
+                        int dst_per_cell, hipStream_t s);
 
 // ----- attention (attention.hip) ---------------------------------------------------------------------------
-// q,k: [cells][12][112][2*hdp]  vt: [cells][12][hdv][2*128]  out: packed-split [cells*101][ldo]
-void launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int ldo, int cells, int hd,
-                      int hdp, int hdv, hipStream_t s);
+// q,k: [cells][H][TP][2*hdp]  vt: [cells][H][hdv][2*KP]  out: packed-split [cells*T][ldo]
+void launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int ldo, int cells, const AttnGeom& a,
+                      hipStream_t s);
 
 // ----- small ViT kernels (vit_misc.hip) ----------------------------------------------------------------------
 void launch_layernorm_ps(const float* z, int ldz, const float* gamma, const float* beta, uint16_t* out, int ldo, int M, int D,
@@ -39,7 +48,14 @@ void launch_im2col_ps(const float* patches, int c_img, const int* src_chan, int 
                       hipStream_t s);
 void launch_embed_f32(const float* patches, int c_img, const int* src_chan, int C, const float* w, const float* bias, const float* pos,
                       float* z, int ldz, int D, int cells, hipStream_t s);
-void launch_cls_rows(float* z, int ldz, const float* cls, const float* pos, int D, int cells, hipStream_t s);
+void launch_cls_rows(float* z, int ldz, const float* cls, const float* pos, int D, int cells, int tokens_per_cell, hipStream_t s);
+// out_ps row (cell*S + j) = LayerNorm(z row (cell*T + sel[j])): the rows a following GEMM actually needs
+void launch_layernorm_gather_ps(const float* z, int ldz, const float* gamma, const float* beta, uint16_t* out, int ldo, int cells, int T,
+                                int S, const int* sel, int D, hipStream_t s);
+// out_ps row (cell*S + j) = split(src fp32 row (cell*T + sel[j])) of K values, zero padded to Kp
+void launch_rows_to_ps(const float* src, int K, uint16_t* out, int ldo, int Kp, int cells, int T, int S, const int* sel, hipStream_t s);
+// z row (cell*T + sel[j]) = a[:] + table[sel[j]][:]   (mask tokens + positional embedding)
+void launch_fill_rows(float* z, int ldz, const float* a, const float* table, int D, int cells, int T, int S, const int* sel, hipStream_t s);
 void launch_head_softmax(const float* z, int ldz, const float* gamma, const float* beta, const float* hw, const float* hb,
                          float* probs, int D, int K, int cells, hipStream_t s);
 void launch_pack_weight(const float* w, int N, int K, uint16_t* out, int Np, int Kp, hipStream_t s);

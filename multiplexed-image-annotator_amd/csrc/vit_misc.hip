@@ -165,17 +165,106 @@ void launch_embed_f32(const float* patches, int c_img, const int* src_chan, int 
                      ldz, D, M);
 }
 
-// z[cell*101 + 0][:] = cls_token + pos_embed[0]   (model.py:49-51)
+// z[cell*T + 0][:] = cls_token + pos_embed[0]   (model.py:49-51; markerImputer.py:197-199)
 __global__ void cls_rows_kernel(float* __restrict__ z, int ldz, const float* __restrict__ cls, const float* __restrict__ pos, int D,
-                                int cells) {
+                                int cells, int T) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= cells * D) return;
   const int cell = idx / D, d = idx - cell * D;
-  z[(size_t)cell * kTokens * ldz + d] = cls[d] + pos[d];
+  z[(size_t)cell * T * ldz + d] = cls[d] + pos[d];
 }
-void launch_cls_rows(float* z, int ldz, const float* cls, const float* pos, int D, int cells, hipStream_t s) {
+void launch_cls_rows(float* z, int ldz, const float* cls, const float* pos, int D, int cells, int tokens_per_cell, hipStream_t s) {
   if (cells <= 0) return;
-  hipLaunchKernelGGL(cls_rows_kernel, dim3((cells * D + 255) / 256), dim3(256), 0, s, z, ldz, cls, pos, D, cells);
+  hipLaunchKernelGGL(cls_rows_kernel, dim3((cells * D + 255) / 256), dim3(256), 0, s, z, ldz, cls, pos, D, cells, tokens_per_cell);
+}
+
+// LayerNorm of selected rows: out_ps row (cell*S + j) = LN(z row (cell*T + sel[j])).  Same arithmetic as layernorm_ps_kernel.
+__global__ __launch_bounds__(256) void layernorm_gather_ps_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, uint16_t* __restrict__ out, int ldo,
+                                                                  int rows_out, int T, int S, const int* __restrict__ sel, int D) {
+  const int lane = threadIdx.x & 63;
+  const int ro = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ro >= rows_out) return;
+  const int cell = ro / S, j = ro - cell * S;
+  const int nv = D >> 2;
+  const float4* zr = reinterpret_cast<const float4*>(z + ((size_t)cell * T + sel[j]) * ldz);
+  float4 x[3];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int v = lane + 64 * i;
+    x[i] = v < nv ? zr[v] : float4{0.f, 0.f, 0.f, 0.f};
+    sum += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int v = lane + 64 * i;
+    if (v < nv) {
+      const float a = x[i].x - mean, b = x[i].y - mean, c = x[i].z - mean, d = x[i].w - mean;
+      sq += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + kLnEps);
+  uint16_t* orow = out + (size_t)ro * ldo;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int v = lane + 64 * i;
+    if (v < nv) {
+      const float4 gm = reinterpret_cast<const float4*>(gamma)[v];
+      const float4 bt = reinterpret_cast<const float4*>(beta)[v];
+      float y[4] = {(x[i].x - mean) * rstd * gm.x + bt.x, (x[i].y - mean) * rstd * gm.y + bt.y,
+                    (x[i].z - mean) * rstd * gm.z + bt.z, (x[i].w - mean) * rstd * gm.w + bt.w};
+      ps_store4(orow, 4 * v, y);
+    }
+  }
+}
+void launch_layernorm_gather_ps(const float* z, int ldz, const float* gamma, const float* beta, uint16_t* out, int ldo, int cells, int T,
+                                int S, const int* sel, int D, hipStream_t s) {
+  const int rows = cells * S;
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(layernorm_gather_ps_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, z, ldz, gamma, beta, out, ldo, rows, T, S, sel, D);
+}
+
+// out_ps row (cell*S + j) = hi/lo split of fp32 src row (cell*T + sel[j]) (K values, zero padded to Kp).  One thread per 4 values.
+__global__ __launch_bounds__(256) void rows_to_ps_kernel(const float* __restrict__ src, int K, uint16_t* __restrict__ out, int ldo, int Kp,
+                                                         long long total, int T, int S, const int* __restrict__ sel) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int kq = Kp >> 2;
+  const long long ro = idx / kq;
+  const int q = (int)(idx - ro * kq);
+  const long long cell = ro / S;
+  const int j = (int)(ro - cell * S);
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (4 * q < K) {
+    const float4 p = *reinterpret_cast<const float4*>(src + ((size_t)cell * T + sel[j]) * K + 4 * q);
+    v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w;
+  }
+  ps_store4(out + (size_t)ro * ldo, 4 * q, v);
+}
+void launch_rows_to_ps(const float* src, int K, uint16_t* out, int ldo, int Kp, int cells, int T, int S, const int* sel, hipStream_t s) {
+  const long long total = (long long)cells * S * (Kp >> 2);
+  if (total <= 0) return;
+  hipLaunchKernelGGL(rows_to_ps_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, K, out, ldo, Kp, total, T, S, sel);
+}
+
+// z row (cell*T + sel[j]) = a + table[sel[j]]     (decoder mask tokens: mask_token + decoder_pos_embed, markerImputer.py:213-219)
+__global__ void fill_rows_kernel(float* __restrict__ z, int ldz, const float* __restrict__ a, const float* __restrict__ table, int D,
+                                 long long total, int T, int S, const int* __restrict__ sel) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const long long ro = idx / D;
+  const int d = (int)(idx - ro * D);
+  const long long cell = ro / S;
+  const int t = sel[(int)(ro - cell * S)];
+  z[((size_t)cell * T + t) * ldz + d] = a[d] + table[(size_t)t * D + d];
+}
+void launch_fill_rows(float* z, int ldz, const float* a, const float* table, int D, int cells, int T, int S, const int* sel, hipStream_t s) {
+  const long long total = (long long)cells * S * D;
+  if (total <= 0) return;
+  hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, ldz, a, table, D, total, T, S, sel);
 }
 
 // final LayerNorm of the CLS row -> Linear(D, K) -> softmax(dim=1), all fp32.  One wave per cell, K <= 16.

@@ -312,6 +312,72 @@ class VitModel:
         return probs
 
 
+def mae_blob_keys(enc_depth: int, dec_depth: int) -> List[str]:
+    def blk(prefix, depth):
+        out = []
+        for i in range(depth):
+            p = f"{prefix}{i}."
+            out += [p + "norm1.weight", p + "norm1.bias", p + "attn.qkv.weight", p + "attn.qkv.bias", p + "attn.proj.weight",
+                    p + "attn.proj.bias", p + "norm2.weight", p + "norm2.bias", p + "mlp.fc1.weight", p + "mlp.fc1.bias",
+                    p + "mlp.fc2.weight", p + "mlp.fc2.bias"]
+        return out
+    return (["cls_token", "pos_embed", "patch_embed.proj.weight", "patch_embed.proj.bias"] + blk("blocks.", enc_depth)
+            + ["norm.weight", "norm.bias", "decoder_embed.weight", "decoder_embed.bias", "mask_token", "decoder_pos_embed"]
+            + blk("decoder_blocks.", dec_depth) + ["decoder_norm.weight", "decoder_norm.bias", "decoder_pred.weight", "decoder_pred.bias"])
+
+
+class MaeModel:
+    """Packed marker imputer on one device (replaces the ``MaskedAutoencoderViT`` inside the reference's
+    ``MarkerImputer``, markerImputer.py:258-287); ``state_dict`` = the ``["model"]`` entry of a ``*_impute.pth`` checkpoint."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device=None):
+        device = device or _lib.require_gpu()
+        self.device = torch.device(device)
+        self.L = int(state_dict["pos_embed"].shape[1]) - 1
+        enc = dec = 0
+        while f"blocks.{enc}.norm1.weight" in state_dict:
+            enc += 1
+        while f"decoder_blocks.{dec}.norm1.weight" in state_dict:
+            dec += 1
+        if state_dict["cls_token"].shape[-1] != 768 or state_dict["mask_token"].shape[-1] != 512 or \
+                tuple(state_dict["patch_embed.proj.weight"].shape) != (768, 1, 40, 40):
+            raise ValueError("expected the reference imputer geometry (768/512 wide, one 40x40 tile per token)")
+        blob = torch.cat([state_dict[k].detach().to(torch.float32).reshape(-1) for k in mae_blob_keys(enc, dec)]).to(self.device)
+        if blob.numel() != lib().ribca_mae_blob_len(self.L, enc, dec):
+            raise ValueError("imputer state dict does not match (L, depths)")
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().ribca_mae_create(ptr(blob), blob.numel(), self.L, enc, dec, stream_ptr(), ctypes.byref(handle)), "ribca_mae_create")
+            torch.cuda.current_stream().synchronize()
+        self._h = handle
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                lib().ribca_mae_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def impute(self, patches: torch.Tensor, present: Sequence[int], chunk_cells: int = 1024) -> torch.Tensor:
+        """In place: every channel of ``patches`` (n, L, 40, 40) not listed in ``present`` is replaced by its prediction."""
+        assert patches.is_cuda and patches.dtype == torch.float32 and patches.is_contiguous() and tuple(patches.shape[1:]) == (self.L, PATCH, PATCH)
+        n = patches.shape[0]
+        pres = sorted(int(c) for c in present)
+        if n == 0:
+            return patches
+        chunk = max(1, min(int(chunk_cells), n))
+        nbytes = lib().ribca_mae_workspace_bytes(self._h, chunk, len(pres))
+        if nbytes <= 0:
+            raise ValueError("need at least one present and one missing channel")
+        ws = workspace(nbytes + 256, patches.device)
+        aligned = (ws.data_ptr() + 255) & ~255
+        arr = (ctypes.c_int32 * len(pres))(*pres)
+        check(lib().ribca_mae_impute(self._h, ptr(patches), arr, len(pres), n, aligned, nbytes, chunk, stream_ptr()), "ribca_mae_impute")
+        return patches
+
+
 def resolve_channels(channel_index: Sequence[int], c_img: int) -> List[int]:
     """Reference channel-select semantics (preprocess.py:110-120): the FIRST -1 becomes a blank plane, every further -1
     stays in a numpy fancy index and therefore picks the LAST image channel."""

@@ -158,6 +158,64 @@ def make_vit_state_dict(name: str, seed: int, depth: int = VIT_DEPTH, head_gain:
     return sd
 
 
+#: imputer panels: name -> number of channel tokens L (reference markerImputer.py:260-274)
+MAE_PANELS: Dict[str, int] = {"immune_full": 15, "immune_extended": 10, "immune_base": 7}
+
+
+def make_mae_state_dict(panel: str, seed: int, enc_depth: int = 12, dec_depth: int = 8, lin_gain: float = 1.5) -> Dict[str, torch.Tensor]:
+    """Seeded fp32 state dict with the keys of the reference's ``MaskedAutoencoderViT`` checkpoints
+    (markerImputer.py:69-110): encoder 768/12 heads over 1600-pixel channel tokens, decoder 512/8 heads, pred 512->1600."""
+    L = MAE_PANELS[panel]
+    sd: Dict[str, torch.Tensor] = {}
+    tag = "mae/" + panel + "/"
+
+    def nrm(key_name, shape, std):
+        n = int(math.prod(shape))
+        return (approx_normal(stream_key(seed, tag + key_name), n) * std).to(torch.float32).reshape(shape)
+
+    def uni(key_name, shape, lo, hi):
+        n = int(math.prod(shape))
+        return (uniform(stream_key(seed, tag + key_name), n) * (hi - lo) + lo).to(torch.float32).reshape(shape)
+
+    def xavier(key_name, out_f, in_f, gain=lin_gain):
+        a = gain * math.sqrt(6.0 / (in_f + out_f))
+        return uni(key_name, (out_f, in_f), -a, a)
+
+    def blocks(prefix, depth, d):
+        for i in range(depth):
+            p = f"{prefix}{i}."
+            sd[p + "norm1.weight"] = uni(p + "norm1.weight", (d,), 0.9, 1.1)
+            sd[p + "norm1.bias"] = uni(p + "norm1.bias", (d,), -0.05, 0.05)
+            sd[p + "attn.qkv.weight"] = xavier(p + "attn.qkv.weight", 3 * d, d)
+            sd[p + "attn.qkv.bias"] = uni(p + "attn.qkv.bias", (3 * d,), -0.02, 0.02)
+            sd[p + "attn.proj.weight"] = xavier(p + "attn.proj.weight", d, d)
+            sd[p + "attn.proj.bias"] = uni(p + "attn.proj.bias", (d,), -0.02, 0.02)
+            sd[p + "norm2.weight"] = uni(p + "norm2.weight", (d,), 0.9, 1.1)
+            sd[p + "norm2.bias"] = uni(p + "norm2.bias", (d,), -0.05, 0.05)
+            sd[p + "mlp.fc1.weight"] = xavier(p + "mlp.fc1.weight", 4 * d, d)
+            sd[p + "mlp.fc1.bias"] = uni(p + "mlp.fc1.bias", (4 * d,), -0.02, 0.02)
+            sd[p + "mlp.fc2.weight"] = xavier(p + "mlp.fc2.weight", d, 4 * d)
+            sd[p + "mlp.fc2.bias"] = uni(p + "mlp.fc2.bias", (d,), -0.02, 0.02)
+
+    sd["cls_token"] = nrm("cls_token", (1, 1, 768), 0.02)
+    sd["pos_embed"] = uni("pos_embed", (1, L + 1, 768), -1.0, 1.0)            # sin-cos tables in the real checkpoints: O(1) values
+    sd["patch_embed.proj.weight"] = xavier("patch_embed.proj.weight", 768, 1600, 2.0).reshape(768, 1, 40, 40)
+    sd["patch_embed.proj.bias"] = uni("patch_embed.proj.bias", (768,), -0.02, 0.02)
+    blocks("blocks.", enc_depth, 768)
+    sd["norm.weight"] = uni("norm.weight", (768,), 0.9, 1.1)
+    sd["norm.bias"] = uni("norm.bias", (768,), -0.05, 0.05)
+    sd["decoder_embed.weight"] = xavier("decoder_embed.weight", 512, 768)
+    sd["decoder_embed.bias"] = uni("decoder_embed.bias", (512,), -0.02, 0.02)
+    sd["mask_token"] = nrm("mask_token", (1, 1, 512), 0.02)
+    sd["decoder_pos_embed"] = uni("decoder_pos_embed", (1, L + 1, 512), -1.0, 1.0)
+    blocks("decoder_blocks.", dec_depth, 512)
+    sd["decoder_norm.weight"] = uni("decoder_norm.weight", (512,), 0.9, 1.1)
+    sd["decoder_norm.bias"] = uni("decoder_norm.bias", (512,), -0.05, 0.05)
+    sd["decoder_pred.weight"] = xavier("decoder_pred.weight", 1600, 512, 1.0)
+    sd["decoder_pred.bias"] = uni("decoder_pred.bias", (1600,), -0.3, 0.3)
+    return sd
+
+
 def calibrate_head_bias(sd: Dict[str, torch.Tensor], features: torch.Tensor) -> torch.Tensor:
     """Head bias that centres the logits of a calibration batch (``features`` = LN(z)[:, 0], (n, D)):
     removes the cell-independent logit offset a random ViT has, so labels spread over several classes.

@@ -12,7 +12,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from . import ref_parser, ref_preprocess as rp, ref_vit, ref_vote
+from . import ref_mae, ref_parser, ref_preprocess as rp, ref_vit, ref_vote
 
 #: panel name (parser) -> model name, in the reference's panel iteration order (markerParse.py:8-17)
 PANEL_MODEL = {"immune_base": "immune_base", "immune_extended": "immune_extended", "immune_full": "immune_full",
@@ -32,7 +32,8 @@ def choose_models(parsed: dict) -> Dict[str, Optional[str]]:
 
 
 def run_image(raw: np.ndarray, mask: np.ndarray, marker_file: str, weights: Dict[str, Dict[str, torch.Tensor]], strict=True,
-              normalize=True, blur=0, amax=100, confidence=0.25, type_conf=None, batch_size=32, cell_size=30) -> dict:
+              normalize=True, blur=0, amax=100, confidence=0.25, type_conf=None, batch_size=32, cell_size=30, infer=False,
+              imputers: Optional[Dict[str, Dict[str, torch.Tensor]]] = None) -> dict:
     parsed = ref_parser.parse_marker_file(marker_file, strict=strict)
     mask = np.asarray(mask)
     if mask.ndim == 3:
@@ -54,6 +55,11 @@ def run_image(raw: np.ndarray, mask: np.ndarray, marker_file: str, weights: Dict
         if first:
             intensity = inten
             first = False
+        if infer and -1 in index and panel not in ("structure", "nerve"):          # preprocess.py:268-281
+            if imputers is None or panel not in imputers:
+                raise ValueError("Panel not found")                                 # markerImputer.py:276
+            present = [i for i, c in enumerate(index) if c != -1]
+            patches = ref_mae.impute(imputers[panel], torch.from_numpy(patches), present).numpy()
         patches_by_model[PANEL_MODEL[panel]] = patches
     for role, model in which.items():
         if model is None:

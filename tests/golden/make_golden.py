@@ -492,9 +492,48 @@ def golden_e2e():
     print("e2e", {k: len(v["labels"]) for k, v in meta.items()})
 
 
+# ---------------------------------------------------------------------------------------------- G6
+def mae_inputs(panel, n, seed):
+    L = synth.MAE_PANELS[panel]
+    u = synth.uniform(synth.stream_key(seed, "maex/" + panel), n * L * 1600).reshape(n, L, 40, 40).to(torch.float32)
+    x = u * 2 - 1
+    return torch.where(x > 0.0, x, torch.full_like(x, -1.0))
+
+
+MAE_CASES = {"immune_base": [0, 1, 3, 4, 5, 6], "immune_full": [0, 1, 2, 3, 4, 6, 7, 8, 9, 11, 12, 13]}   # present positions
+
+
+def golden_mae():
+    """Reference MarkerImputer.impute (markerImputer.py:258-329) with seeded full-depth weights, batch size 4 on 6 cells
+    (two full batches would hide the ragged-tail + empty-last-batch loop of the reference)."""
+    imp = ref("markerImputer")
+    out = {}
+    cwd = os.getcwd()
+    for panel, present in MAE_CASES.items():
+        seed = synth.SEED_BASE + 301
+        tmp = tempfile.mkdtemp()
+        os.chdir(tmp)
+        mdir = "src/multiplexed_image_annotator/cell_type_annotation/models"
+        os.makedirs(mdir)
+        torch.save({"model": synth.make_mae_state_dict(panel, seed)}, os.path.join(mdir, panel + "_impute.pth"))
+        m = imp.MarkerImputer(present, "cpu", panel)
+        x = mae_inputs(panel, 6, seed)
+        L = x.shape[1]
+        missing = [c for c in range(L) if c not in present]
+        x[:, missing] = -1.0
+        y = m.impute(x.clone(), 4)
+        assert torch.equal(y[:, present], x[:, present])
+        out[panel + "_present"] = np.array(present, np.int64)
+        out[panel + "_pred"] = y[:, missing].numpy()
+        os.chdir(cwd)
+        shutil.rmtree(tmp)
+    np.savez_compressed(os.path.join(HERE, "mae.npz"), **out)
+    print("mae.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["normalize", "cellpos", "patches", "parser", "vote", "vit", "e2e"]
+    which = sys.argv[1:] or ["normalize", "cellpos", "patches", "parser", "vote", "vit", "e2e", "mae"]
     for w in which:
         globals()["golden_" + w]()

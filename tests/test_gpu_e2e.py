@@ -165,3 +165,37 @@ def test_cli_single_image(tmp_path, golden_dir):
     finally:
         os.chdir(cwd)
     csv_equal_up_to_conf(open(tmp_path / "out" / "results" / "g_annotation_0.csv").read(), meta["csv"], 1.5e-3)
+
+
+def test_annotator_with_imputation_matches_oracle(tmp_path):
+    """infer=True with one missing marker of the full panel (BASELINE config 5 shape, small): imputer + classifier + vote."""
+    from multiplexed_image_annotator_amd.annotator import Annotator
+    from oracle import ref_pipeline
+    seed = synth.SEED_BASE + 5
+    markers = [m for m in synth.FULL_PANEL_MARKERS if m != "Trypase"] + ["CollagenIV"]      # index [0..13, -1]
+    mask, img = synth.make_mask_and_image(200, 240, 70, len(markers), seed)
+    raw, mk = img.numpy().astype(np.uint16), mask.numpy().astype(np.int32)
+    mf, csv = write_case(tmp_path, raw, mk, markers)
+    weights = {"immune_full": synth.make_vit_state_dict("immune_full", seed, depth=3),
+               "immune_extended": synth.make_vit_state_dict("immune_extended", seed, depth=1),
+               "immune_base": synth.make_vit_state_dict("immune_base", seed, depth=1)}
+    imp = synth.make_mae_state_dict("immune_full", seed, enc_depth=2, dec_depth=2)
+    a = Annotator(mf, csv, "cuda", str(tmp_path), "i", False, True, -1, True, 0.3, 99.8, 0.3, 30, None)
+    a.set_weights(dict(weights, immune_full_impute=imp))
+    a.preprocess()
+    a.predict(32)
+    a.export_annotations()
+    assert a.channel_parser.indices["immune_full"] == list(range(14)) + [-1]
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    ref = ref_pipeline.run_image(raw, mk, mf, weights, strict=False, normalize=True, blur=0.3, amax=99.8, confidence=0.3, batch_size=32,
+                                 infer=True, imputers={"immune_full": imp})
+    dp = np.abs(a.probs[0]["immune_full"] - ref["probs"]["immune_full"]).max()
+    assert dp < 1e-3, dp
+    assert a.annotations[0] == ref["labels"]
+    csv_equal_up_to_conf(open(tmp_path / "results" / "i_annotation_0.csv").read(), ref["csv"], 1.5e-3)
+    # without imputer weights the reference raises ValueError("Panel not found") (markerImputer.py:276)
+    b = Annotator(mf, csv, "cuda", str(tmp_path), "j", False, True, -1, True, 0.3, 99.8, 0.3, 30, None)
+    b.set_weights(weights)
+    b.preprocess()
+    with pytest.raises(ValueError, match="Panel not found"):
+        b.predict(32)

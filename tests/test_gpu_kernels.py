@@ -344,3 +344,41 @@ def test_normalize_large_matches_oracle(dev):
     raw = img.numpy().astype(np.uint16)
     got = ops.normalize_image(raw, blur=0.3, amax=99.8).cpu().numpy()
     np.testing.assert_array_equal(got, ref_preprocess.normalize_image(raw, blur=0.3, amax=99.8))
+
+
+# ------------------------------------------------------------------------------------------- marker imputer
+def _mae_inputs(panel, n, seed):
+    L = synth.MAE_PANELS[panel]
+    u = synth.uniform(synth.stream_key(seed, "maex/" + panel), n * L * 1600).reshape(n, L, 40, 40).to(torch.float32)
+    x = u * 2 - 1
+    return torch.where(x > 0.0, x, torch.full_like(x, -1.0))
+
+
+@pytest.mark.parametrize("panel", ["immune_base", "immune_full"])
+def test_mae_golden(dev, golden_dir, panel):
+    """HIP imputer vs the reference's own MarkerImputer.impute (full-depth seeded weights)."""
+    ops = _ops()
+    g = np.load(os.path.join(golden_dir, "mae.npz"))
+    present = g[panel + "_present"].tolist()
+    seed = synth.SEED_BASE + 301
+    model = ops.MaeModel(synth.make_mae_state_dict(panel, seed), dev)
+    x = _mae_inputs(panel, 6, seed)
+    missing = [c for c in range(x.shape[1]) if c not in present]
+    x[:, missing] = -1.0
+    y = model.impute(x.to(dev).contiguous(), present, chunk_cells=4).cpu()      # 2 chunks, ragged tail
+    assert torch.equal(y[:, present], x[:, present])                              # kept channels bit-for-bit untouched
+    err = np.abs(y[:, missing].numpy() - g[panel + "_pred"]).max()
+    assert err < 5e-4, err          # pixel values in [-1, 1] feed a classifier whose 1e-3 budget is on probabilities
+
+
+@pytest.mark.parametrize("panel,present", [("immune_extended", [0, 1, 2, 3, 5, 6, 7, 9]), ("immune_base", [1, 2, 3, 4, 5, 6]),
+                                           ("immune_full", list(range(14)))])
+def test_mae_vs_oracle(dev, panel, present):
+    from oracle import ref_mae
+    ops = _ops()
+    sd = synth.make_mae_state_dict(panel, 17, enc_depth=3, dec_depth=2)
+    x = _mae_inputs(panel, 37, 18)
+    ref = ref_mae.impute(sd, x, present)
+    got = ops.MaeModel(sd, dev).impute(x.to(dev).contiguous(), present, chunk_cells=16).cpu()
+    assert torch.equal(got[:, present], x[:, present])
+    assert (got - ref).abs().max().item() < 5e-4
