@@ -32,6 +32,7 @@ def parse():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--channels", type=int, default=15)
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("RIBCA_CHUNK_CELLS", "1024")))
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("RIBCA_STREAMS", "1")), help="classifiers run concurrently on this many HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -77,6 +78,8 @@ def main():
     tc = [-1.0] * 18
     vote_pair = ("immune_full", "struct") if "immune_full" in models and "struct" in models else (next(iter(models)), None)
 
+    side_streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else []
+
     def one_pass():
         image = ops.normalize_image(raw, blur=0.3, amax=99.8)
         ids, tab = ops.label_table(mask)
@@ -87,9 +90,24 @@ def main():
         bb_d = torch.from_numpy(tab[lo:hi, :4].astype(np.int32)).to(dev)
         patches, _ = ops.extract_patches(image, mask, cmin, ids_d, bb_d)
         probs = {}
-        for name, model in models.items():
-            local = model.predict_proba(patches, srcs[name], chunk_cells=args.chunk)
-            probs[name] = dist.all_gather_rows(local, n) if world > 1 else local
+        if args.streams > 1:
+            # the five classifiers are independent: spreading them over a few streams lets one model's HBM-bound epilogues
+            # and partially filled last tile rounds overlap another model's MFMA phase
+            cur = torch.cuda.current_stream()
+            order = sorted(models, key=lambda k: -models[k].flops_per_cell)
+            for i, name in enumerate(order):
+                st = side_streams[i % args.streams]
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    probs[name] = models[name].predict_proba(patches, srcs[name], chunk_cells=args.chunk, ws_slot=1 + i % args.streams)
+            for st in side_streams:
+                cur.wait_stream(st)
+            patches.record_stream(cur)
+        else:
+            for name, model in models.items():
+                probs[name] = model.predict_proba(patches, srcs[name], chunk_cells=args.chunk)
+        if world > 1:
+            probs = {k: dist.all_gather_rows(v, n) for k, v in probs.items()}
         a, b = vote_pair
         lab, conf = ops.vote(probs[a], [gid[c] for c in CLASS_NAMES[a]], probs[b] if b else None,
                              [gid[c] for c in CLASS_NAMES[b]] if b else None, tc, 0.3)
@@ -147,7 +165,8 @@ def main():
         gemm_flops = 0.0
         for name, model in models.items():
             d = model.D
-            gemm_flops += n_local * model.depth * 24.0 * 101 * d * d          # qkv + proj + fc1 + fc2 (algorithmic, unpadded)
+            # qkv + proj + fc1 + fc2 (algorithmic, unpadded); in the last block proj / fc1 / fc2 run on the CLS row only
+            gemm_flops += n_local * ((model.depth - 1) * 24.0 * 101 * d * d + 6.0 * 101 * d * d + 18.0 * d * d)
         g_ms = sum(prof[k][0] for k in ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2"))
         g_n = sum(prof[k][1] for k in ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2"))
         achieved = gemm_flops / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0

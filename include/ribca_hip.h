@@ -143,7 +143,8 @@ int ribca_test_gemm(int32_t kind, const uint16_t* A, int32_t lda, const uint16_t
 int ribca_test_qkv_attention(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t cells, int32_t D, int32_t Kp,
                              const float* bias, uint16_t* q, uint16_t* k, uint16_t* vt, uint16_t* out, int32_t ldo, void* stream);
 int32_t ribca_gemm_padded_n(int32_t N);
-/* Tuning hook: GEMM tile variant, 0 = auto, 1 = 256-row tile with a 3-deep LDS ring, 2 = 128-row tile with a 2-deep ring. */
+/* Measurement hook: 0 = production GEMM; 3 = without the half-step stagger; 4/5/7/9 = timing ablations (no loads / loads
+ * only / no loads + stagger / no epilogue) whose RESULTS ARE WRONG by construction -- used by tools/bench_gemm.py only. */
 int ribca_set_gemm_variant(int32_t v);
 
 #ifdef __cplusplus

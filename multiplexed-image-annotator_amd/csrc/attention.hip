@@ -21,7 +21,7 @@ namespace ribca {
 template <int KS /* hdp/32 */, int DT /* hdv/16 */, int NT /* 16-token tiles: 7 for the 101-token classifiers, 1 for the imputer */>
 __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K,
                                                         const uint16_t* __restrict__ Vt, uint16_t* __restrict__ out, int ldo,
-                                                        int n_pairs, int hd, int H, int T) {
+                                                        int n_pairs, int hd, int H, int T, int q_tiles) {
   const int lane = threadIdx.x & 63;
   const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);  // (cell, head) index, wave-uniform
   if (pair >= n_pairs) return;
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
       klo[kt][ks] = __builtin_bit_cast(bf16x8, p[1]);
     }
 
-  for (int qt = 0; qt < NT; ++qt) {
+  for (int qt = 0; qt < q_tiles; ++qt) {
     bf16x8 qhi[KS], qlo[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -137,13 +137,14 @@ AttnGeom make_attn_geom(int D, int H, int T) {
 }
 
 void launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int ldo, int cells, const AttnGeom& a,
-                      hipStream_t s) {
+                      hipStream_t s, int q_tiles) {
+  if (q_tiles <= 0 || q_tiles > a.NT) q_tiles = a.NT;
   const int pairs = cells * a.H;
   if (pairs <= 0) return;
   const dim3 grid((pairs + 3) / 4), block(256);
   const int ks = a.hdp / 32, dt = a.hdv / 16;
 #define RIBCA_ATT(KS_, DT_, NT_) \
-  hipLaunchKernelGGL((attention_kernel<KS_, DT_, NT_>), grid, block, 0, s, q, k, vt, out, ldo, pairs, a.hd, a.H, a.T)
+  hipLaunchKernelGGL((attention_kernel<KS_, DT_, NT_>), grid, block, 0, s, q, k, vt, out, ldo, pairs, a.hd, a.H, a.T, q_tiles)
   if (a.NT == 7 && ks == 1 && dt == 1) RIBCA_ATT(1, 1, 7);
   else if (a.NT == 7 && ks == 1 && dt == 2) RIBCA_ATT(1, 2, 7);
   else if (a.NT == 7 && ks == 2 && dt == 3) RIBCA_ATT(2, 3, 7);

@@ -5,23 +5,31 @@
 //                                            W: nn.Linear wt [Np][2*Kp] packed-split bf16, Np = N padded to the tile
 //
 // Shape regime: M = cells*101 is huge (1e4..1e6), N in {144..2304}, K in {160..2304}: short K loops and a weight matrix
-// that is L2-resident, so the kernel is built around keeping the MFMA pipe fed from a deep LDS ring:
+// that lives in L2 / Infinity Cache, so the kernel is built around keeping the MFMA pipe fed from a deep LDS ring:
 //
-// * tile 256 x {64,96,128}, BK = 32; 512 threads = 8 waves as 4(M) x 2(N), two waves per SIMD; each wave owns
-//   64 x BN/2 outputs = 4 x TN tiles of 16x16.  (A 128-row tile needs ~64 B/clk/CU from L2 at full MFMA rate; 256 rows halve it.)
+// * tile 256 x {64,96,128}, BK = 32; 768 threads = 8 CONSUMER waves as 4(M) x 2(N) (each owns 64 x BN/2 outputs = 4 x TN
+//   tiles of 16x16) + 4 LOADER waves that only issue the direct-to-LDS loads.  (A 128-row tile was measured 10-15 % slower:
+//   it needs 1/3 more L2->LDS bytes per MFMA.)
 // * Tiles are computed TRANSPOSED: acc = mfma(Wfrag, Afrag) so a lane holds 4 consecutive output columns n of one row m
 //   (C/D map: col = lane&15 -> m, row = 4*(lane>>4)+r -> n).  Epilogues then issue one 8/16-byte store per tile
 //   instead of four 2-byte ones (residual RMW on fp32 z is one float4).
 // * Each (Afrag, Wfrag) pair feeds three MFMAs (hi*hi, lo*hi, hi*lo): LDS bytes per MFMA are 2/3 of a plain bf16 GEMM.
-// * 3-stage LDS ring (3 x 48 KB) filled by direct-to-LDS loads (global_load_lds_dwordx4, no staging registers, no
-//   ds_write): K-step k+2 is issued right after the barrier that opens step k, so two steps of loads are always in flight;
-//   completion is tracked with a counted s_waitcnt vmcnt(G) (G = loads per wave per stage) + one raw s_barrier per step.
+// * 3-stage LDS ring (3 x 48 KB) filled by global_load_lds_dwordx4 (no staging registers, no ds_write): K-step k+2 is issued
+//   right after the barrier that opens step k, so two steps of loads are always in flight; completion is tracked with a
+//   counted s_waitcnt vmcnt(G) on the loader waves + raw s_barrier.
+// * Half-step stagger: two barriers per K step split it into a fragment-read phase and an MFMA phase, and consumer waves 4-7
+//   (the SIMD partners of waves 0-3) run one phase late, so each SIMD always has one wave multiplying while the other reads.
 // * LDS tile = rows of 128 B (one 32-deep K step of a PS row: 4 x [16 B hi | 16 B lo]).  16-byte chunk c of row r lives at
 //   chunk c ^ f(r),  f(r) = ((r>>1)&7) ^ (4 <= (r&15) < 12 ? 2 : 0):  every hardware ds_read_b128 lane group
-//   ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) then touches 16 distinct 16-byte slots of the 256-byte bank row.
-//   The LDS-DMA destination is linear (wave base + lane*16), so the swizzle is applied to each lane's GLOBAL source address.
+//   ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) then touches 16 distinct 16-byte slots of the 256-byte bank row
+//   (SQ_LDS_BANK_CONFLICT measured 0).  The LDS-DMA destination is linear (wave base + lane*16), so the swizzle is applied to
+//   each lane's GLOBAL source address.
 // * block id -> tile map is XCD-aware (blocks b, b+8, ... share an L2): every XCD walks whole rows of n-tiles of one
 //   m-tile, so an A tile is fetched into one L2 once and reused by all its n-tiles.
+// * Epilogues run in two sweeps (all loads, then compute + stores); they are NOT yet overlapped with the next tile's K loop
+//   and cost 25-45 % of the short-K launches (tools/bench_gemm.py variant 9) -- see DESIGN.md section 9.
+#include <type_traits>
+
 #include "ribca_common.h"
 #include "ribca_kernels.h"
 
@@ -95,39 +103,50 @@ struct EpiQKV {
   uint16_t* q; uint16_t* k; uint16_t* vt; const float* bias; int D, hd, hdp, hdv; float scale; int M, N;
   int T, TP, H, KP;   // tokens per cell, padded token rows of Q/K, heads, padded keys per V^T row
   struct Ctx {};
+  // row / column decompositions are computed once per accumulator row (4) and column group (TN), not once per tile
+  struct Row { int cell, t, vpos; };
+  struct Col { int which, head, d; };
+  __device__ __forceinline__ Row row(int m) const {
+    Row r;
+    r.cell = m / T;
+    r.t = m - r.cell * T;
+    // V^T key order permuted inside each 32-key block so that the 8 keys a lane group owns after the K*Q^T MFMA (two
+    // 16-key tiles, rows 4g..4g+3 of each) are contiguous: key = 32s+16u+4g+r -> 32s+8g+4u+r
+    r.vpos = ps_off((r.t & ~31) | (((r.t >> 2) & 3) << 3) | (((r.t >> 4) & 1) << 2) | (r.t & 3));
+    return r;
+  }
+  __device__ __forceinline__ Col col(int n) const {
+    Col c;
+    c.which = n / D;
+    const int f = n - c.which * D;
+    c.head = f / hd;
+    c.d = f - c.head * hd;   // multiple of 4, d+3 < hd (hd % 4 == 0)
+    return c;
+  }
   __device__ __forceinline__ float4 fetch_bias(int n) const {
     return n < N ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
   }
   __device__ __forceinline__ void fetch(int, int, Ctx&) const {}
-  __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx&) const {
+  __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx&, const Row& r, const Col& c) const {
     if (m >= M || n >= N) return;
-    const int which = n / D;
-    const int f = n - which * D;
-    const int head = f / hd;
-    const int d = f - head * hd;  // multiple of 4, d+3 < hd (hd % 4 == 0)
-    const int cell = m / T, t = m - cell * T;
     float x[4] = {v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w};
-    const size_t ch = (size_t)cell * H + head;
-    if (which < 2) {
-      if (which == 0) {
+    const size_t ch = (size_t)r.cell * H + c.head;
+    if (c.which < 2) {
+      if (c.which == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) x[i] *= scale;
       }
-      uint16_t* row = (which == 0 ? q : k) + (ch * TP + t) * (size_t)(2 * hdp);
-      ps_store4(row, d, x);
+      uint16_t* rowp = (c.which == 0 ? q : k) + (ch * TP + r.t) * (size_t)(2 * hdp);
+      ps_store4(rowp, c.d, x);
     } else {
-      // V^T[d][key], key order permuted inside each 32-key block so that the 8 keys a lane group owns after the
-      // K*Q^T MFMA (two 16-key tiles, rows 4g..4g+3 of each) are contiguous: key = 32s+16u+4g+r -> 32s+8g+4u+r
-      const int pos = (t & ~31) | (((t >> 2) & 3) << 3) | (((t >> 4) & 1) << 2) | (t & 3);
-      uint16_t* base = vt + ch * (size_t)hdv * (2 * KP) + ps_off(pos);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        uint16_t hi, lo;
-        split_bf16(x[i], hi, lo);
-        uint16_t* p = base + (size_t)(d + i) * (2 * KP);
-        p[0] = hi;
-        p[8] = lo;
-      }
+      uint2 hi, lo;
+      split4(x, hi, lo);
+      uint16_t* base = vt + (ch * hdv + c.d) * (size_t)(2 * KP) + r.vpos;
+      const size_t st = (size_t)(2 * KP);
+      base[0] = (uint16_t)hi.x;          base[8] = (uint16_t)lo.x;
+      base[st] = (uint16_t)(hi.x >> 16); base[st + 8] = (uint16_t)(lo.x >> 16);
+      base[2 * st] = (uint16_t)hi.y;     base[2 * st + 8] = (uint16_t)lo.y;
+      base[3 * st] = (uint16_t)(hi.y >> 16); base[3 * st + 8] = (uint16_t)(lo.y >> 16);
     }
   }
 };
@@ -157,6 +176,9 @@ struct EpiRowMap {
 };
 
 // two-sweep driver shared by the kernels: lane owns rows m_i = mbase + 16 i and column groups n_j = nbase + 16 j
+template <class Epi, class = void> struct has_rowcol : std::false_type {};
+template <class Epi> struct has_rowcol<Epi, std::void_t<typename Epi::Row>> : std::true_type {};
+
 template <int TN, class Epi>
 __device__ __forceinline__ void run_epilogue(const Epi& epi, int mbase, int nbase, f32x4 (&acc)[4][TN]) {
   float4 b4[TN];
@@ -167,10 +189,23 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, int mbase, int nbas
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) epi.fetch(mbase + 16 * i, nbase + 16 * j, ctx[i][j]);
+  if constexpr (has_rowcol<Epi>::value) {
+    typename Epi::Row rows[4];
+    typename Epi::Col cols[TN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) rows[i] = epi.row(mbase + 16 * i);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) epi.apply(mbase + 16 * i, nbase + 16 * j, acc[i][j], b4[j], ctx[i][j]);
+    for (int j = 0; j < TN; ++j) cols[j] = epi.col(nbase + 16 * j);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) epi.apply(mbase + 16 * i, nbase + 16 * j, acc[i][j], b4[j], ctx[i][j], rows[i], cols[j]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) epi.apply(mbase + 16 * i, nbase + 16 * j, acc[i][j], b4[j], ctx[i][j]);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- kernel
@@ -191,130 +226,6 @@ template <int CNT> __device__ __forceinline__ void wait_vmcnt() {
   else if constexpr (CNT == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   else if constexpr (CNT == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-}
-
-// BM in {128, 256} rows per tile (BM/32 waves), NST = LDS ring depth (2: one K step in flight, two tiles per CU;
-// 3: two K steps in flight, one tile per CU).
-template <int BM, int BN, int NST, class Epi>
-__global__ __launch_bounds__(BM * 2) void gemm_ps_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw,
-                                                         int M, int Kp, int mtiles, int ntiles, Epi epi) {
-  constexpr int NW = BM / 32;            // waves: (BM/64) along M x 2 along N
-  constexpr int TN = BN / 32;
-  constexpr int ROWS = BM + BN;
-  constexpr int STAGE = ROWS * ROWB;
-  constexpr int NGRP = ROWS / 8;         // 1 KB (8-row) DMA groups per stage
-  constexpr int GPW = (NGRP + NW - 1) / NW;   // groups each wave issues per stage
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  // XCD-aware bijective remap (cdna guide T1): blocks with equal (bid % 8) share an L2
-  const int nblk = mtiles * ntiles;
-  int bid = blockIdx.x;
-  {
-    const int xcd = bid & 7, loc = bid >> 3;
-    const int q = nblk >> 3, r = nblk & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  const int mt = bid / ntiles, nt = bid - mt * ntiles;
-  const int m0 = mt * BM, n0 = nt * BN;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int r16 = lane & 15, g = lane >> 4;
-
-  // LDS-DMA plan: group grp = 8 consecutive tile rows = 1 KB; lane -> (row = 8*grp + lane/8, physical chunk = lane%8).
-  // The logical chunk that must land there is phys ^ f(row): fetch THAT chunk from global.
-  const uint16_t* src[GPW];
-  int dst[GPW];
-#pragma unroll
-  for (int i = 0; i < GPW; ++i) {
-    int grp = wave + NW * i;
-    grp = grp < NGRP ? grp : NGRP - 1;   // surplus slots repeat the last group (same bytes to the same place)
-    const int row = grp * 8 + (lane >> 3);
-    const int ch = (lane & 7) ^ swz_f(row);
-    if (row < BM) {
-      int gm = m0 + row;
-      gm = gm < M ? gm : M - 1;          // tail rows re-read the last valid row; their outputs are never stored
-      src[i] = A + (size_t)gm * lda + ch * 8;
-    } else {
-      src[i] = W + (size_t)(n0 + row - BM) * ldw + ch * 8;
-    }
-    dst[i] = grp * 1024;
-  }
-
-  int a_rd[4], w_rd[TN];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) a_rd[i] = lds_off(wm * 64 + i * 16 + r16, 2 * g);
-#pragma unroll
-  for (int i = 0; i < TN; ++i) w_rd[i] = BM * ROWB + lds_off(wn * (BN / 2) + i * 16 + r16, 2 * g);
-  // chunk 2g+1 (the lo half) differs from chunk 2g only in bit 4 of the swizzled offset
-  f32x4 acc[4][TN];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = Kp / BK;
-
-  auto issue = [&](int kk, int stage) {
-    char* st = smem + stage * STAGE;
-    const int ko = kk * (2 * BK);        // bf16 elements per K step in a PS row
-#pragma unroll
-    for (int i = 0; i < GPW; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + ko),
-                                       (__attribute__((address_space(3))) void*)(st + dst[i]), 16, 0, 0);
-  };
-
-  auto compute = [&](const char* st) {
-    bf16x8 ahi[4], alo[4], whi[TN], wlo[TN];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ahi[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + a_rd[i]));
-      alo[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + (a_rd[i] ^ 16)));
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      whi[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + w_rd[j]));
-      wlo[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + (w_rd[j] ^ 16)));
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(wlo[j], ahi[i], acc[i][j]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(whi[j], alo[i], acc[i][j]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(whi[j], ahi[i], acc[i][j]);
-  };
-
-  issue(0, 0);
-  if (NST > 2 && nk > 1) issue(1, 1);
-  int cur = 0;                            // ring slot of K step kk
-  for (int kk = 0; kk < nk; ++kk) {
-    // retire this wave's loads of step kk (with a 3-deep ring the newest stage may stay in flight), then meet the other
-    // waves: after the barrier every wave's part of slot `cur` has landed AND every wave has finished reading the slot the
-    // next issue overwrites (it was read during step kk-1).
-    if (NST > 2 && kk + 1 < nk) wait_vmcnt<GPW>();
-    else wait_vmcnt<0>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (kk + NST - 1 < nk) {
-      int nxt = cur + NST - 1;
-      nxt = nxt >= NST ? nxt - NST : nxt;
-      issue(kk + NST - 1, nxt);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    compute(smem + cur * STAGE);
-    cur = cur + 1 == NST ? 0 : cur + 1;
-  }
-
-  run_epilogue<TN>(epi, m0 + wm * 64 + r16, n0 + wn * (BN / 2) + 4 * g, acc);
 }
 
 // ---------------------------------------------------------------------------------------------- loader/consumer split
@@ -472,192 +383,14 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
     }
     if (!late) __builtin_amdgcn_s_barrier();         // phase 2nk: partners finish their last MFMAs
   }
-  run_epilogue<TN>(epi, m0 + wm * 64 + r16, n0 + wn * (BN / 2) + 4 * g, acc);
-}
-
-// ---------------------------------------------------------------------------------------------- persistent form
-// The split/staggered kernel made persistent: one workgroup per CU walks tiles rb, rb + G, rb + 2G, ... and the loader waves
-// run straight through tile boundaries (K steps are numbered globally), so a tile's first two stages are already in flight
-// while the previous tile is still multiplying and there is no per-tile launch + cold-ring prologue (~10 us per 256 x 128
-// tile, as much as 12 K steps).  Epilogues sit in the half-step where the partner group is multiplying:
-//   waves 0-3: ... mfma(last) | barrier | EPILOGUE, read(first of next tile) | barrier | mfma ...
-//   waves 4-7: ... read(last) | barrier | mfma(last), EPILOGUE             | barrier | read(first) ...
-template <int BN, class Epi>
-__global__ __launch_bounds__(768) void gemm_ps_persist_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W,
-                                                              int ldw, int M, int Kp, int mtiles, int ntiles, Epi epi) {
-  constexpr int BM = 256, NST = 3, NLW = 4;
-  constexpr int TN = BN / 32;
-  constexpr int ROWS = BM + BN;
-  constexpr int STAGE = ROWS * ROWB;
-  constexpr int NGRP = ROWS / 8;
-  constexpr int GPL = (NGRP + NLW - 1) / NLW;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int nblk = mtiles * ntiles;
-  const int G = gridDim.x;                      // G <= nblk
-  int rb = blockIdx.x;
-  {
-    const int xcd = rb & 7, loc = rb >> 3;
-    const int q = G >> 3, r = G & 7;
-    rb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;   // blocks of one XCD take consecutive tiles
-  }
-  const int n_my = (nblk - rb + G - 1) / G;     // tiles this workgroup owns (>= 1)
-  const int nk = Kp / BK;
-  const int total = n_my * nk;                  // K steps over all owned tiles
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  if (wave >= 8) {
-    // ------------------------------------------------------------------ loader
-    const int lw = wave - 8;
-    const uint16_t* src[GPL];
-    int dst[GPL];
-    int lrow[GPL];
+  if (ABL == 3) {   // timing ablation: no epilogue (accumulators kept alive so the MFMAs are not dead code)
 #pragma unroll
-    for (int i = 0; i < GPL; ++i) {
-      int grp = lw + NLW * i;
-      grp = grp < NGRP ? grp : NGRP - 1;
-      lrow[i] = grp * 8 + (lane >> 3);
-      dst[i] = grp * 1024;
-    }
-    auto set_src = [&](int ti) {
-      const int tile = rb + ti * G;
-      const int mt = tile / ntiles, nt = tile - mt * ntiles;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < GPL; ++i) {
-        const int row = lrow[i];
-        const int ch = (lane & 7) ^ swz_f(row);
-        if (row < BM) {
-          int gm = mt * BM + row;
-          gm = gm < M ? gm : M - 1;
-          src[i] = A + (size_t)gm * lda + ch * 8;
-        } else {
-          src[i] = W + (size_t)(nt * BN + row - BM) * ldw + ch * 8;
-        }
-      }
-    };
-    int l_ti = 0, l_kk = 0;
-    auto issue_next = [&](int stage) {
-      char* st = smem + stage * STAGE;
-      const int ko = l_kk * (2 * BK);
-#pragma unroll
-      for (int i = 0; i < GPL; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + ko),
-                                         (__attribute__((address_space(3))) void*)(st + dst[i]), 16, 0, 0);
-      if (++l_kk == nk) {
-        l_kk = 0;
-        if (++l_ti < n_my) set_src(l_ti);
-      }
-    };
-    set_src(0);
-    issue_next(0);
-    if (total > 1) issue_next(1);
-    int cur = 0;
-    for (int s = 0; s < total; ++s) {
-      if (s + 1 < total) wait_vmcnt<GPL>();
-      else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();               // phase 2s
-      asm volatile("" ::: "memory");
-      if (s + 2 < total) {
-        int nxt = cur + 2;
-        nxt = nxt >= NST ? nxt - NST : nxt;
-        issue_next(nxt);
-      }
-      __builtin_amdgcn_s_barrier();               // phase 2s+1
-      cur = cur + 1 == NST ? 0 : cur + 1;
-    }
-    __builtin_amdgcn_s_barrier();                 // phase 2*total
+      for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
-
-  // -------------------------------------------------------------------- consumer
-  const int wm = wave >> 1, wn = wave & 1;
-  const int r16 = lane & 15, g = lane >> 4;
-  int a_rd[4], w_rd[TN];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) a_rd[i] = lds_off(wm * 64 + i * 16 + r16, 2 * g);
-#pragma unroll
-  for (int i = 0; i < TN; ++i) w_rd[i] = BM * ROWB + lds_off(wn * (BN / 2) + i * 16 + r16, 2 * g);
-  f32x4 acc[4][TN];
-  bf16x8 ahi[4], alo[4], whi[TN], wlo[TN];
-  auto zero_acc = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  };
-  auto read_frags = [&](const char* st) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ahi[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + a_rd[i]));
-      alo[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + (a_rd[i] ^ 16)));
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      whi[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + w_rd[j]));
-      wlo[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + (w_rd[j] ^ 16)));
-    }
-  };
-  auto mfmas = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(wlo[j], ahi[i], acc[i][j]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(whi[j], alo[i], acc[i][j]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(whi[j], ahi[i], acc[i][j]);
-  };
-  auto tile_epilogue = [&](int ti) {
-    const int tile = rb + ti * G;
-    const int mt = tile / ntiles, nt = tile - mt * ntiles;
-    run_epilogue<TN>(epi, mt * BM + wm * 64 + r16, nt * BN + wn * (BN / 2) + 4 * g, acc);
-  };
-
-  int cur = 0;
-  if (wave < 4) {
-    for (int ti = 0; ti < n_my; ++ti) {
-      for (int kk = 0; kk < nk; ++kk) {
-        __builtin_amdgcn_s_barrier();             // even phase: partners multiply
-        asm volatile("" ::: "memory");
-        if (kk == 0) {
-          if (ti > 0) tile_epilogue(ti - 1);
-          zero_acc();
-        }
-        read_frags(smem + cur * STAGE);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();             // odd phase
-        asm volatile("" ::: "memory");
-        mfmas();
-        cur = cur + 1 == NST ? 0 : cur + 1;
-      }
-    }
-    __builtin_amdgcn_s_barrier();                 // phase 2*total: partners finish
-    tile_epilogue(n_my - 1);
-  } else {
-    __builtin_amdgcn_s_barrier();                 // phase 0
-    for (int ti = 0; ti < n_my; ++ti) {
-      zero_acc();
-      for (int kk = 0; kk < nk; ++kk) {
-        __builtin_amdgcn_s_barrier();             // odd phase: partners multiply
-        asm volatile("" ::: "memory");
-        read_frags(smem + cur * STAGE);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();             // even phase
-        asm volatile("" ::: "memory");
-        mfmas();
-        cur = cur + 1 == NST ? 0 : cur + 1;
-      }
-      tile_epilogue(ti);
-    }
-  }
+  run_epilogue<TN>(epi, m0 + wm * 64 + r16, n0 + wn * (BN / 2) + 4 * g, acc);
 }
 
 // ---------------------------------------------------------------------------------------------- host side
@@ -672,23 +405,8 @@ int gemm_padded_n(int N) {
   return (N + bn - 1) / bn * bn;
 }
 
-static int g_variant = 0;   // 0 auto, 1: 256-row tile / 3-deep ring, 2: 128-row tile / 2-deep ring, 3: 256-row tile with loader waves
+static int g_variant = 0;   // 0 = production kernel; 3/4/5/7/9 = A/B and timing-ablation forms (tools/bench_gemm.py)
 void gemm_set_variant(int v) { g_variant = v; }
-
-template <int BM, int BN, int NST, class Epi>
-static void launch_cfg(const GemmArgs& g, const Epi& epi, hipStream_t s) {
-  const int mtiles = (g.M + BM - 1) / BM;
-  const int ntiles = gemm_padded_n(g.N) / BN;
-  const size_t lds = (size_t)NST * (BM + BN) * ROWB;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ps_kernel<BM, BN, NST, Epi>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, NST, Epi>), dim3(mtiles * ntiles), dim3(BM * 2), lds, s, g.A, g.lda, g.W, g.ldw, g.M, g.Kp,
-                     mtiles, ntiles, epi);
-}
 
 template <int BN, class Epi, int ABL = 0, bool STAG = false>
 static void launch_split(const GemmArgs& g, const Epi& epi, hipStream_t s) {
@@ -705,43 +423,16 @@ static void launch_split(const GemmArgs& g, const Epi& epi, hipStream_t s) {
                      ntiles, epi);
 }
 
-static int cu_count() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-  }
-  return n;
-}
-
-template <int BN, class Epi>
-static void launch_persist(const GemmArgs& g, const Epi& epi, hipStream_t s) {
-  const int mtiles = (g.M + 255) / 256;
-  const int ntiles = gemm_padded_n(g.N) / BN;
-  const int nblk = mtiles * ntiles;
-  const int grid = nblk < cu_count() ? nblk : cu_count();
-  const size_t lds = (size_t)3 * (256 + BN) * ROWB;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ps_persist_kernel<BN, Epi>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((gemm_ps_persist_kernel<BN, Epi>), dim3(grid), dim3(768), lds, s, g.A, g.lda, g.W, g.ldw, g.M, g.Kp, mtiles, ntiles,
-                     epi);
-}
-
 template <int BN, class Epi>
 static void launch_bn(const GemmArgs& g, const Epi& epi, hipStream_t s) {
-  if (g_variant == 0 || g_variant == 6) launch_split<BN, Epi, 0, true>(g, epi, s);   // default: loader waves + half-step stagger
-  else if (g_variant == 2) launch_cfg<128, BN, 2>(g, epi, s);
-  else if (g_variant == 3) launch_split<BN>(g, epi, s);
-  else if (g_variant == 4) launch_split<BN, Epi, 1>(g, epi, s);
-  else if (g_variant == 5) launch_split<BN, Epi, 2>(g, epi, s);
-  else if (g_variant == 8) launch_persist<BN>(g, epi, s);
-  else if (g_variant == 7) launch_split<BN, Epi, 1, true>(g, epi, s);
-  else launch_cfg<256, BN, 3>(g, epi, s);
+  switch (g_variant) {
+    case 3: launch_split<BN, Epi, 0, false>(g, epi, s); break;   // no stagger (A/B reference)
+    case 4: launch_split<BN, Epi, 1, false>(g, epi, s); break;   // ablation: no loads
+    case 5: launch_split<BN, Epi, 2, false>(g, epi, s); break;   // ablation: loads only
+    case 7: launch_split<BN, Epi, 1, true>(g, epi, s); break;    // ablation: no loads, staggered
+    case 9: launch_split<BN, Epi, 3, true>(g, epi, s); break;    // ablation: no epilogue
+    default: launch_split<BN, Epi, 0, true>(g, epi, s); break;   // production: loader waves + half-step stagger
+  }
 }
 
 template <class Epi>

@@ -242,6 +242,38 @@ void run_block(const BlockW& L, const BlockWs& w, int cells, const AttnGeom& a, 
   }
 }
 
+// Last block of a classifier: only the CLS row reaches the head (reference model.py:61-62 takes x[:, 0] after the final norm),
+// so after the attention (which still needs every token's K and V) the projection, the MLP and both residual updates run
+// on the CLS rows only: they are addressed in place with a row stride of T rows (M = cells).  Same values as the full block
+// on those rows; the other 100 rows of the last block are never read again.
+void run_last_block_cls(const BlockW& L, const BlockWs& w, int cells, const AttnGeom& a, hipStream_t s) {
+  const int D = a.D, Dp = round_up(D, 32), ld_x = 2 * Dp, ld_h = 2 * 4 * D, Mc = cells * a.T;
+  const float scale = 1.0f / sqrtf((float)a.hd);
+  { ProfScope ps(P_LN, s); launch_layernorm_ps(w.z, D, L.ln1w, L.ln1b, w.xa, ld_x, Mc, D, s); }
+  {
+    ProfScope ps(P_QKV, s);
+    GemmArgs g{w.xa, ld_x, L.qkvw, ld_x, Mc, 3 * D, Dp, L.qkvb};
+    launch_gemm_qkv(g, w.q, w.k, w.vt, a, scale, s);
+  }
+  { ProfScope ps(P_ATTN, s); launch_attention(w.q, w.k, w.vt, w.xa, ld_x, cells, a, s, 1); }
+  {
+    ProfScope ps(P_PROJ, s);
+    GemmArgs g{w.xa, a.T * ld_x, L.projw, ld_x, cells, D, Dp, L.projb};
+    launch_gemm_resid(g, w.z, a.T * D, s);
+  }
+  { ProfScope ps(P_LN, s); launch_layernorm_ps(w.z, a.T * D, L.ln2w, L.ln2b, w.xa, a.T * ld_x, cells, D, s); }
+  {
+    ProfScope ps(P_FC1, s);
+    GemmArgs g{w.xa, a.T * ld_x, L.fc1w, ld_x, cells, 4 * D, Dp, L.fc1b};
+    launch_gemm_gelu(g, w.h, ld_h, s);
+  }
+  {
+    ProfScope ps(P_FC2, s);
+    GemmArgs g{w.h, ld_h, L.fc2w, ld_h, cells, D, 4 * D, L.fc2b};
+    launch_gemm_resid(g, w.z, a.T * D, s);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -335,7 +367,8 @@ int ribca_vit_forward(const ribca_vit_t* m, const float* patches, int32_t c_img,
       ProfScope ps(P_OTHER, s);
       launch_cls_rows(w.z, D, m->cls, m->pos, D, bc, kTokens, s);
     }
-    for (const auto& L : m->layers) run_block(L, w, bc, geom, s);
+    for (size_t li = 0; li + 1 < m->layers.size(); ++li) run_block(m->layers[li], w, bc, geom, s);
+    run_last_block_cls(m->layers.back(), w, bc, geom, s);
     {
       ProfScope ps(P_HEAD, s);
       launch_head_softmax(w.z, D, m->norm_w, m->norm_b, m->head_w, m->head_b, probs + (size_t)c0 * m->K, D, m->K, bc, s);

@@ -9,7 +9,7 @@ namespace ribca {
 // ----- GEMM (gemm_bf16x3.hip): C = A * W^T with A [M][2*Kp] and W [Np][2*Kp] in packed-split bf16 ---------------
 int gemm_pick_bn(int N);            // column-tile width used for an N-wide weight (64 / 96 / 128)
 int gemm_padded_n(int N);
-void gemm_set_variant(int v);      // tuning hook: 0 auto, 1 = 256-row tile / 3-deep ring, 2 = 128-row tile / 2-deep ring           // N rounded up to that tile width (rows the packed weight must have)
+void gemm_set_variant(int v);      // 0 = production; 3/4/5/7/9 = A/B and timing-ablation forms of the same kernel           // N rounded up to that tile width (rows the packed weight must have)
 
 struct GemmArgs {
   const uint16_t* A; int lda;       // activations, row stride in bf16 elements (= 2*Kp)
@@ -38,8 +38,9 @@ void launch_gemm_rowmap(const GemmArgs& g, float* out, int ldo, const float* add
 
 // ----- attention (attention.hip) ---------------------------------------------------------------------------
 // q,k: [cells][H][TP][2*hdp]  vt: [cells][H][hdv][2*KP]  out: packed-split [cells*T][ldo]
+// q_tiles > 0 restricts the QUERY rows to the first q_tiles 16-token tiles (keys/values are always complete)
 void launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int ldo, int cells, const AttnGeom& a,
-                      hipStream_t s);
+                      hipStream_t s, int q_tiles = 0);
 
 // ----- small ViT kernels (vit_misc.hip) ----------------------------------------------------------------------
 void launch_layernorm_ps(const float* z, int ldz, const float* gamma, const float* beta, uint16_t* out, int ldo, int M, int D,

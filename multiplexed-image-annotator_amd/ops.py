@@ -62,9 +62,10 @@ def _taps(device) -> torch.Tensor:
     return _TAPS_DEV[key]
 
 
-def workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only scratch buffer shared by all models on a device (caller-owned memory of the C ABI)."""
-    key = device.index or 0
+def workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
+    """Grow-only scratch buffer per (device, slot) (caller-owned memory of the C ABI).  Work enqueued on different streams
+    at the same time must use different slots."""
+    key = (device.index or 0, slot)
     cur = _WS.get(key)
     if cur is None or cur.numel() < nbytes:
         _WS[key] = None
@@ -289,7 +290,7 @@ class VitModel:
                 pass
             self._h = None
 
-    def predict_proba(self, patches: torch.Tensor, src_chan: Sequence[int], chunk_cells: int = 1024) -> torch.Tensor:
+    def predict_proba(self, patches: torch.Tensor, src_chan: Sequence[int], chunk_cells: int = 1024, ws_slot: int = 0) -> torch.Tensor:
         """softmax(model(x), dim=1) for full-channel patches (n, C_img, 40, 40); ``src_chan[c]`` = image channel of model
         channel c or -1 for a blank plane (reference preprocess.py:110-120, model.py:397-406)."""
         assert patches.is_cuda and patches.dtype == torch.float32 and patches.dim() == 4 and patches.shape[2:] == (PATCH, PATCH)
@@ -304,7 +305,7 @@ class VitModel:
         chunk = max(1, min(int(chunk_cells), n))
         src = torch.tensor(list(src_chan), dtype=torch.int32, device=patches.device)
         nbytes = lib().ribca_vit_workspace_bytes(self._h, chunk)
-        ws = workspace(nbytes + 256, patches.device)
+        ws = workspace(nbytes + 256, patches.device, ws_slot)
         base = ws.data_ptr()
         aligned = (base + 255) & ~255
         check(lib().ribca_vit_forward(self._h, ptr(patches.contiguous()), c_img, ptr(src), n, ptr(probs), aligned, nbytes, chunk,
