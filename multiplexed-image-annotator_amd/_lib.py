@@ -53,6 +53,7 @@ SIGNATURES = {
                                            c_void_p, c_void_p, c_int32, c_void_p]),
     "ribca_gemm_padded_n": (c_int32, [c_int32]),
     "ribca_set_gemm_variant": (c_int32, [c_int32]),
+    "ribca_set_gemm_stamps": (c_int32, [c_void_p]),
 }
 
 

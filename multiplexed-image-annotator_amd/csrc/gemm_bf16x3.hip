@@ -28,6 +28,7 @@
 //   m-tile, so an A tile is fetched into one L2 once and reused by all its n-tiles.
 // * Epilogues run in two sweeps (all loads, then compute + stores); they are NOT yet overlapped with the next tile's K loop
 //   and cost 25-45 % of the short-K launches (tools/bench_gemm.py variant 9) -- see DESIGN.md section 9.
+#include <cstdlib>
 #include <type_traits>
 
 #include "ribca_common.h"
@@ -58,6 +59,7 @@ struct EpiResid {
   __device__ __forceinline__ void fetch(int m, int n, Ctx& c) const {
     c.zv = (m < M && n < N) ? *reinterpret_cast<const float4*>(z + (size_t)m * ldz + n) : float4{0.f, 0.f, 0.f, 0.f};
   }
+  template <int PX = 16>
   __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx& c) const {
     if (m >= M || n >= N) return;
     float4 o;
@@ -73,10 +75,11 @@ struct EpiGelu {
     return n < N ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
   }
   __device__ __forceinline__ void fetch(int, int, Ctx&) const {}
+  template <int PX = 16>
   __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx&) const {
     if (m >= M || n >= N) return;
     float t[4] = {gelu_erf(v[0] + b.x), gelu_erf(v[1] + b.y), gelu_erf(v[2] + b.z), gelu_erf(v[3] + b.w)};
-    ps_store4(out + (size_t)m * ldo, n, t);
+    ps_store4_pair<PX>(out + (size_t)m * ldo, n, t);      // N % 8 == 0: the partner lane (n ^ 4, same m) passed the same guard
   }
 };
 
@@ -90,6 +93,7 @@ struct EpiEmbed {
     const int cell = m / 100, t = m - cell * 100;
     c.pe = (m < M && n < N) ? *reinterpret_cast<const float4*>(pos + (size_t)(1 + t) * D + n) : float4{0.f, 0.f, 0.f, 0.f};
   }
+  template <int PX = 16>
   __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx& c) const {
     if (m >= M || n >= N) return;
     const int cell = m / 100, t = m - cell * 100;
@@ -127,6 +131,7 @@ struct EpiQKV {
     return n < N ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
   }
   __device__ __forceinline__ void fetch(int, int, Ctx&) const {}
+  template <int PX = 16>
   __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx&, const Row& r, const Col& c) const {
     if (m >= M || n >= N) return;
     float x[4] = {v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w};
@@ -137,7 +142,8 @@ struct EpiQKV {
         for (int i = 0; i < 4; ++i) x[i] *= scale;
       }
       uint16_t* rowp = (c.which == 0 ? q : k) + (ch * TP + r.t) * (size_t)(2 * hdp);
-      ps_store4(rowp, c.d, x);
+      if ((hd & 7) == 0) ps_store4_pair<PX>(rowp, c.d, x);   // the partner lane's 4 columns are in the same head
+      else ps_store4(rowp, c.d, x);
     } else {
       uint2 hi, lo;
       split4(x, hi, lo);
@@ -166,6 +172,7 @@ struct EpiRowMap {
       c.a = *reinterpret_cast<const float4*>(add + (size_t)addrow[j] * ldadd + n);
     }
   }
+  template <int PX = 16>
   __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx& c) const {
     if (m >= M || n >= N) return;
     const int cell = m / R, j = m - cell * R;
@@ -228,15 +235,83 @@ template <int CNT> __device__ __forceinline__ void wait_vmcnt() {
   else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 }
 
+// Diagnostic stamps (measurement builds only: variant 12): wave 0 of every workgroup writes s_memrealtime (100 MHz) at kernel
+// entry, after the first stage has landed, after the K loop and after its epilogue, plus the XCC/CU it ran on, into a
+// buffer nothing else reads.
+__device__ unsigned long long* g_stamps = nullptr;
+__device__ __forceinline__ unsigned long long stamp_now() { return __builtin_amdgcn_s_memrealtime(); }
+
+// ---------------------------------------------------------------------------------------------- epilogue through LDS
+// tools/store_bench.hip: what one CU can push to memory depends on the ADDRESS SHAPE of each store instruction, not on its
+// bytes: 16 rows x 64 B (what the accumulator layout gives: 16 rows m per lane group) drains at ~27 GB/s per CU, 16 rows x
+// 2 x 16 B pieces at ~15 GB/s, whole 256-512 B row segments at ~67 GB/s (the chip-wide write limit is ~5 TB/s, i.e. ~75 CUs
+// at that rate).  After the K loop the ring is dead, so the tile's 256 x BN fp32 accumulators are parked there (row pitch
+// 4 BN + 16 bytes: the 16 lanes of a ds_write_b128 group hit 16 different bank quads) and ALL 12 waves then walk the tile
+// in row-major 16-byte chunks: a wave instruction covers 1 KB = 2-4 whole row segments, loads of z are equally contiguous,
+// the GELU / split work is spread over 768 threads, and a chunk's PS partner (the other 4 columns of its 8-group) is the
+// neighbouring lane.  A V tile of the qkv product scatters 2-byte elements along V^T rows and keeps the register path.
+template <class Epi> __device__ __forceinline__ bool lepi_tile_uses_registers(const Epi&, int, int) { return false; }
+template <> __device__ __forceinline__ bool lepi_tile_uses_registers<EpiQKV>(const EpiQKV& e, int n0, int bn) { return n0 + bn > 2 * e.D; }
+
+template <int BN>
+__device__ __forceinline__ void lds_park(char* smem, const f32x4 (&acc)[4][BN / 32], int wm, int wn, int r16, int g) {
+  constexpr int SROW = BN * 4 + 16;          // staging row pitch in bytes
+  char* sb = smem + (wm * 64 + r16) * SROW + (wn * (BN / 2) + 4 * g) * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < BN / 32; ++j) *reinterpret_cast<f32x4*>(sb + i * 16 * SROW + j * 64) = acc[i][j];
+}
+
+template <int BN, class Epi>
+__device__ __forceinline__ void lds_drain(const Epi& epi, const char* smem, int m0, int n0, int tid) {
+  constexpr int SROW = BN * 4 + 16;
+  constexpr int CPR = BN / 4;                // 16-byte chunks per row
+  constexpr int RSTEP = 768 / CPR;           // rows covered by one pass of the workgroup
+  constexpr int NIT = (256 + RSTEP - 1) / RSTEP;
+  static_assert(768 % CPR == 0, "a thread keeps its column chunk across passes");
+  const int c = tid % CPR, row0 = tid / CPR;
+  const int n = n0 + 4 * c;
+  const float4 b4 = epi.fetch_bias(n);
+  typename Epi::Ctx ctx[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int row = row0 + it * RSTEP;
+    if (NIT * RSTEP == 256 || row < 256) epi.fetch(m0 + row, n, ctx[it]);
+  }
+  const char* src = smem + row0 * SROW + c * 16;
+  if constexpr (has_rowcol<Epi>::value) {
+    const typename Epi::Col col = epi.col(n);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = row0 + it * RSTEP;
+      if (NIT * RSTEP == 256 || row < 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + it * RSTEP * SROW);
+        epi.template apply<1>(m0 + row, n, v, b4, ctx[it], epi.row(m0 + row), col);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = row0 + it * RSTEP;
+      if (NIT * RSTEP == 256 || row < 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + it * RSTEP * SROW);
+        epi.template apply<1>(m0 + row, n, v, b4, ctx[it]);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- loader/consumer split
 // Same tile (256 x BN, BK 32, 3-deep ring) with ROLES: waves 0-7 only read LDS and issue MFMAs; waves 8-11 only issue the
 // direct-to-LDS loads.  An LDS-DMA instruction costs its wave ~100 issue cycles, and 6 of them per wave right after each
 // barrier (every wave at once, both SIMD partners) left the matrix pipe idle for a third of each K step; on dedicated waves
 // that cost overlaps the consumers' MFMAs (3 waves per SIMD: 2 consumers + 1 loader).  Consumers never touch vmcnt in the
 // loop, so their epilogue loads/stores cannot drain the ring.
-template <int BN, class Epi, int ABL = 0 /* timing ablations: 1 = no loads, 2 = no MFMA/LDS reads */, bool STAG = false>
+template <int BN, class Epi, int ABL = 0 /* timing ablations: 1 = no loads, 2 = no MFMA/LDS reads, 3 = no epilogue, 4 = stamps */,
+          bool STAG = false, bool LEPI = false /* epilogue through LDS: row-contiguous stores by all 12 waves */>
 __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw,
-                                                            int M, int Kp, int mtiles, int ntiles, Epi epi) {
+                                                            int M, int Kp, int mtiles, int ntiles, Epi epi, int deph) {
   constexpr int BM = 256, NST = 3, NLW = 4;
   constexpr int TN = BN / 32;
   constexpr int ROWS = BM + BN;
@@ -258,6 +333,15 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nk = Kp / BK;
+
+  // De-phasing: the first workgroup on every CU starts 0..31/32 of a tile time late (spread within each XCD), so that the
+  // CUs' epilogue bursts interleave instead of all hitting the memory system together (chip-wide write limit ~5 TB/s = ~20
+  // GB/s per CU when all 256 store at once, against ~67 GB/s that one CU can sustain with row-contiguous stores).  Later
+  // workgroups inherit the phase of the CU they land on.  Consumers wait; loaders prefetch and meet them at the barrier.
+  if (deph > 0 && blockIdx.x < 256 && wave < 8) {
+    const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(((blockIdx.x >> 3) & 31) * deph) / 32;
+    while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
+  }
 
   if (wave >= 8) {
     // ------------------------------------------------------------------ loader
@@ -306,10 +390,18 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
       cur = cur + 1 == NST ? 0 : cur + 1;
     }
     if (STAG) __builtin_amdgcn_s_barrier();     // phase 2nk
+    if constexpr (LEPI && STAG && ABL != 3) {
+      if (!lepi_tile_uses_registers(epi, n0, BN)) {
+        __syncthreads();                          // consumers have parked the tile
+        lds_drain<BN>(epi, smem, m0, n0, tid);
+      }
+    }
     return;
   }
 
   // -------------------------------------------------------------------- consumer
+  unsigned long long t0 = 0, t1 = 0, t2 = 0;
+  if (ABL == 4) t0 = stamp_now();
   const int wm = wave >> 1, wn = wave & 1;
   const int r16 = lane & 15, g = lane >> 4;
   int a_rd[4], w_rd[TN];
@@ -373,6 +465,7 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
     for (int kk = 0; kk < nk; ++kk) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      if (ABL == 4 && kk == 0) t1 = stamp_now();
       if (ABL != 2) read_frags(smem + cur * STAGE);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -383,6 +476,7 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
     }
     if (!late) __builtin_amdgcn_s_barrier();         // phase 2nk: partners finish their last MFMAs
   }
+  if (ABL == 4) t2 = stamp_now();
   if (ABL == 3) {   // timing ablation: no epilogue (accumulators kept alive so the MFMAs are not dead code)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -390,7 +484,26 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
       for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
-  run_epilogue<TN>(epi, m0 + wm * 64 + r16, n0 + wn * (BN / 2) + 4 * g, acc);
+  if constexpr (LEPI && STAG) {
+    if (lepi_tile_uses_registers(epi, n0, BN)) run_epilogue<TN>(epi, m0 + wm * 64 + r16, n0 + wn * (BN / 2) + 4 * g, acc);
+    else {
+      lds_park<BN>(smem, acc, wm, wn, r16, g);
+      __syncthreads();
+      lds_drain<BN>(epi, smem, m0, n0, tid);
+    }
+  } else {
+    run_epilogue<TN>(epi, m0 + wm * 64 + r16, n0 + wn * (BN / 2) + 4 * g, acc);
+  }
+  if (ABL == 4 && g_stamps != nullptr && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // epilogue stores of this wave have been accepted
+    const unsigned long long t3 = stamp_now();
+    unsigned long long* o = g_stamps + (size_t)blockIdx.x * 6;
+    o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3;
+    unsigned int xcc, hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    o[4] = xcc; o[5] = hwid;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- host side
@@ -407,20 +520,27 @@ int gemm_padded_n(int N) {
 
 static int g_variant = 0;   // 0 = production kernel; 3/4/5/7/9 = A/B and timing-ablation forms (tools/bench_gemm.py)
 void gemm_set_variant(int v) { g_variant = v; }
+int gemm_set_stamp_buffer(void* dev_ptr) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dev_ptr, sizeof(dev_ptr));
+}
 
-template <int BN, class Epi, int ABL = 0, bool STAG = false>
+template <int BN, class Epi, int ABL = 0, bool STAG = false, bool LEPI = false>
 static void launch_split(const GemmArgs& g, const Epi& epi, hipStream_t s) {
   const int mtiles = (g.M + 255) / 256;
   const int ntiles = gemm_padded_n(g.N) / BN;
   const size_t lds = (size_t)3 * (256 + BN) * ROWB;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ps_split_kernel<BN, Epi, ABL, STAG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ps_split_kernel<BN, Epi, ABL, STAG, LEPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_ps_split_kernel<BN, Epi, ABL, STAG>), dim3(mtiles * ntiles), dim3(768), lds, s, g.A, g.lda, g.W, g.ldw, g.M, g.Kp, mtiles,
-                     ntiles, epi);
+  // tile time in 10 ns ticks: K steps of ~0.65/0.87/1.15 us (BN 64/96/128) + pipeline fill + epilogue
+  int deph = 0;
+  static const bool env_deph = getenv("RIBCA_GEMM_DEPH") != nullptr;
+  if ((g_variant == 15 || env_deph) && mtiles * ntiles >= 1024) deph = (g.Kp / BK) * (BN == 128 ? 115 : BN == 96 ? 87 : 65) + 400;
+  hipLaunchKernelGGL((gemm_ps_split_kernel<BN, Epi, ABL, STAG, LEPI>), dim3(mtiles * ntiles), dim3(768), lds, s, g.A, g.lda, g.W, g.ldw, g.M, g.Kp, mtiles,
+                     ntiles, epi, deph);
 }
 
 template <int BN, class Epi>
@@ -431,7 +551,9 @@ static void launch_bn(const GemmArgs& g, const Epi& epi, hipStream_t s) {
     case 5: launch_split<BN, Epi, 2, false>(g, epi, s); break;   // ablation: loads only
     case 7: launch_split<BN, Epi, 1, true>(g, epi, s); break;    // ablation: no loads, staggered
     case 9: launch_split<BN, Epi, 3, true>(g, epi, s); break;    // ablation: no epilogue
-    default: launch_split<BN, Epi, 0, true>(g, epi, s); break;   // production: loader waves + half-step stagger
+    case 12: launch_split<BN, Epi, 4, true, true>(g, epi, s); break;   // production kernel + diagnostic time stamps
+    case 14: launch_split<BN, Epi, 0, true>(g, epi, s); break;   // A/B: epilogue straight from the accumulator registers
+    default: launch_split<BN, Epi, 0, true, true>(g, epi, s); break;   // production: loader waves + half-step stagger + LDS epilogue
   }
 }
 

@@ -282,6 +282,7 @@ int ribca_version(void) { return 100; }
 const char* ribca_last_error(void) { return g_err.c_str(); }
 int32_t ribca_gemm_padded_n(int32_t N) { return gemm_padded_n(N); }
 int ribca_set_gemm_variant(int32_t v) { gemm_set_variant(v); return 0; }
+int ribca_set_gemm_stamps(void* dev_buffer) { return gemm_set_stamp_buffer(dev_buffer); }
 
 int64_t ribca_vit_blob_len(int32_t D, int32_t C, int32_t K, int32_t depth) {
   const int64_t d = D;

@@ -63,6 +63,22 @@ __device__ __forceinline__ void ps_store4(uint16_t* row, int k, const float v[4]
   *reinterpret_cast<uint2*>(p + 8) = lo;
 }
 
+// same, for a lane pair (lane, lane ^ PX) that together owns the 8 columns of one PS group (k % 4 == 0; the even lane holds
+// k % 8 == 0): the pair swaps halves so that each lane writes ONE 16-byte vector (all 8 hi, or all 8 lo) instead of two
+// 8-byte pieces -- half the store instructions and 64 contiguous bytes per row and instruction.  Both lanes must be active.
+template <int PX>
+__device__ __forceinline__ void ps_store4_pair(uint16_t* row, int k, const float v[4]) {
+  uint2 hi, lo;
+  split4(v, hi, lo);
+  const bool odd = (k & 4) != 0;
+  const uint2 send = odd ? hi : lo;
+  uint2 recv;
+  recv.x = __shfl_xor(send.x, PX, 64);
+  recv.y = __shfl_xor(send.y, PX, 64);
+  const uint4 o = odd ? uint4{recv.x, recv.y, lo.x, lo.y} : uint4{hi.x, hi.y, recv.x, recv.y};
+  *reinterpret_cast<uint4*>(row + ps_off(k & ~7) + (odd ? 8 : 0)) = o;
+}
+
 __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }

@@ -9,6 +9,7 @@ namespace ribca {
 // ----- GEMM (gemm_bf16x3.hip): C = A * W^T with A [M][2*Kp] and W [Np][2*Kp] in packed-split bf16 ---------------
 int gemm_pick_bn(int N);            // column-tile width used for an N-wide weight (64 / 96 / 128)
 int gemm_padded_n(int N);
+int gemm_set_stamp_buffer(void* dev_ptr);   // diagnostics (variant 12): 6 x uint64 per workgroup
 void gemm_set_variant(int v);      // 0 = production; 3/4/5/7/9 = A/B and timing-ablation forms of the same kernel           // N rounded up to that tile width (rows the packed weight must have)
 
 struct GemmArgs {
