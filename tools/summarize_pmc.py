@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Reduce the rocprofv3 outputs of tools/collect_profiles.sh to the small files committed under profiles/<tag>/:
+kernel_stats.csv (per-kernel totals of the traced bench step) and gemm_traffic.json (HBM-side bytes per GEMM launch from the
+FETCH_SIZE / WRITE_SIZE passes, with the gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE tallies 128-byte requests at
+64 bytes, so it is doubled; both counters are in KiB... the guide's unit is KB = 1024 bytes)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out, tag = sys.argv[1], sys.argv[2]
+
+
+def find(sub, suffix):
+    hits = glob.glob(os.path.join(out, sub, "**", "*" + suffix), recursive=True)
+    return hits[0] if hits else None
+
+
+def counter_sums(sub, counter):
+    path = find(sub, "counter_collection.csv")
+    per_kernel = defaultdict(lambda: [0.0, 0])
+    if path is None:
+        return per_kernel
+    seen = set()
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if row.get("Counter_Name") != counter:
+                continue
+            name = row["Kernel_Name"]
+            per_kernel[name][0] += float(row["Counter_Value"])
+            key = (row.get("Dispatch_Id"), name)
+            if key not in seen:
+                seen.add(key)
+                per_kernel[name][1] += 1
+    return per_kernel
+
+
+fetch = counter_sums("fetch", "FETCH_SIZE")
+write = counter_sums("write", "WRITE_SIZE")
+gemm = [k for k in fetch if "gemm_ps_split_kernel" in k]
+res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 0 "
+                 "--no-cpu-baseline --no-roofline --cells 8000 --size 1280 (chunk 1024)",
+       "kernel_family": "gemm_ps_split_kernel (all instantiations)",
+       "correction": "gfx950: FETCH_SIZE tallies 128-B requests at 64 B -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact; "
+                     "unit KB = 1024 B",
+       "note": "counts L2 misses served by the Infinity Cache as well as HBM; per-launch figure (M = 103424 rows for full chunks)"}
+launches = sum(fetch[k][1] for k in gemm)
+f_kb = sum(fetch[k][0] for k in gemm)
+w_kb = sum(write[k][0] for k in gemm if k in write)
+res["launches"] = launches
+res["fetch_size_kb_sum"] = f_kb
+res["write_size_kb_sum"] = w_kb
+if launches:
+    res["traffic_bytes_per_launch"] = (2.0 * f_kb + w_kb) * 1024.0 / launches
+    res["per_kernel_bytes_per_launch"] = {
+        k.split("(")[0].replace("void ribca::", ""): (2.0 * fetch[k][0] + write.get(k, [0.0, 0])[0]) * 1024.0 / max(fetch[k][1], 1) for k in gemm}
+    other = {}
+    for k in fetch:
+        if k in gemm or fetch[k][1] == 0:
+            continue
+        other[k.split("(")[0].replace("void ribca::", "")[:90]] = {
+            "launches": fetch[k][1], "bytes_per_launch": (2.0 * fetch[k][0] + write.get(k, [0.0, 0])[0]) * 1024.0 / fetch[k][1]}
+    res["other_kernels"] = other
+dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "prof_" + tag)
+os.makedirs(dst, exist_ok=True)
+with open(os.path.join(dst, "gemm_traffic.json"), "w") as f:
+    json.dump(res, f, indent=1)
+stats = find("trace", "kernel_stats.csv")
+if stats:
+    with open(stats) as f, open(os.path.join(dst, "kernel_stats.csv"), "w") as g:
+        g.write(f.read())
+dom = find("trace", "domain_stats.csv")
+if dom:
+    with open(dom) as f, open(os.path.join(dst, "domain_stats.csv"), "w") as g:
+        g.write(f.read())
+print(json.dumps({k: res[k] for k in ("launches", "traffic_bytes_per_launch") if k in res}))
