@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--channels", type=int, default=15)
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("RIBCA_CHUNK_CELLS", "1024")))
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("RIBCA_STREAMS", "1")), help="classifiers run concurrently on this many HIP streams")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("RIBCA_STREAMS", "3")), help="each classifier's cells are split into this many segments enqueued on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -78,9 +78,8 @@ def main():
     tc = [-1.0] * 18
     vote_pair = ("immune_full", "struct") if "immune_full" in models and "struct" in models else (next(iter(models)), None)
 
-    side_streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else []
-
-    def one_pass():
+    def one_pass(streams=None):
+        streams = args.streams if streams is None else streams
         image = ops.normalize_image(raw, blur=0.3, amax=99.8)
         ids, tab = ops.label_table(mask)
         n = len(ids)
@@ -90,22 +89,8 @@ def main():
         bb_d = torch.from_numpy(tab[lo:hi, :4].astype(np.int32)).to(dev)
         patches, _ = ops.extract_patches(image, mask, cmin, ids_d, bb_d)
         probs = {}
-        if args.streams > 1:
-            # the five classifiers are independent: spreading them over a few streams lets one model's HBM-bound epilogues
-            # and partially filled last tile rounds overlap another model's MFMA phase
-            cur = torch.cuda.current_stream()
-            order = sorted(models, key=lambda k: -models[k].flops_per_cell)
-            for i, name in enumerate(order):
-                st = side_streams[i % args.streams]
-                st.wait_stream(cur)
-                with torch.cuda.stream(st):
-                    probs[name] = models[name].predict_proba(patches, srcs[name], chunk_cells=args.chunk, ws_slot=1 + i % args.streams)
-            for st in side_streams:
-                cur.wait_stream(st)
-            patches.record_stream(cur)
-        else:
-            for name, model in models.items():
-                probs[name] = model.predict_proba(patches, srcs[name], chunk_cells=args.chunk)
+        for name, model in models.items():
+            probs[name] = model.predict_proba(patches, srcs[name], chunk_cells=args.chunk, streams=streams)
         if world > 1:
             probs = {k: dist.all_gather_rows(v, n) for k, v in probs.items()}
         a, b = vote_pair
@@ -147,7 +132,7 @@ def main():
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"synthetic {args.channels}-ch {args.size}x{args.size} tile, {n_cells} cells, Full Panel, "
                                f"{len(models)} ViT classifiers per cell (normalise + label table + crop/soft-mask + ViT + vote)",
-                   "cells": n_cells, "models": list(models), "chunk_cells": args.chunk, "precision": "bf16x3 split MFMA, fp32 accumulate",
+                   "cells": n_cells, "models": list(models), "chunk_cells": args.chunk, "segment_streams": args.streams, "precision": "bf16x3 split MFMA, fp32 accumulate",
                    "parallelism": f"cells sharded over {world} rank(s), all-gather of per-cell probabilities" if world > 1 else "single GPU"},
         "vit_gflop_per_cell": round(flops_cell / 1e9, 4),
         "vit_mfma_util_vs_bf16_dense": round(value * flops_cell / (world * PEAK_BF16_DENSE_TFLOPS * 1e12), 5),
@@ -156,7 +141,7 @@ def main():
     # ---- roofline of the dominant kernel (the bf16x3 GEMM family), one extra profiled pass -----------------------------
     if not args.no_roofline and rank == 0:
         ops.prof_enable(True)
-        one_pass()
+        one_pass(streams=1)      # per-kernel durations: one stream, so a launch's events bracket that launch alone
         torch.cuda.synchronize()
         prof = ops.prof_read()
         ops.prof_enable(False)

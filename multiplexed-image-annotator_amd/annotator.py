@@ -107,6 +107,7 @@ class Annotator(object):
         self.probs: List[Dict[str, np.ndarray]] = []       # per image: model -> (n, K) fp32 host table
         self.label_ids: List[np.ndarray] = []
         self.chunk_cells = int(os.environ.get("RIBCA_CHUNK_CELLS", "1024"))
+        self.streams = int(os.environ.get("RIBCA_STREAMS", "3"))      # cell segments in flight per classifier (ops.VitModel.predict_proba)
 
     # ---- weights ---------------------------------------------------------------------------------------------------
     def set_weights(self, weights: Dict[str, Dict[str, torch.Tensor]]) -> None:
@@ -180,7 +181,7 @@ class Annotator(object):
             present = [i for i, c in enumerate(index) if c != -1]
             imputer.impute(panel, present, chunk_cells=self.chunk_cells)
             patches, src = panel, list(range(len(index)))
-        local = model.predict_proba(patches, src, chunk_cells=self.chunk_cells)
+        local = model.predict_proba(patches, src, chunk_cells=self.chunk_cells, streams=self.streams)
         full = dist.all_gather_rows(local, n) if self.world_size > 1 else local
         return full
 

@@ -290,9 +290,14 @@ class VitModel:
                 pass
             self._h = None
 
-    def predict_proba(self, patches: torch.Tensor, src_chan: Sequence[int], chunk_cells: int = 1024, ws_slot: int = 0) -> torch.Tensor:
+    def predict_proba(self, patches: torch.Tensor, src_chan: Sequence[int], chunk_cells: int = 1024, ws_slot: int = 0,
+                      streams: int = 1) -> torch.Tensor:
         """softmax(model(x), dim=1) for full-channel patches (n, C_img, 40, 40); ``src_chan[c]`` = image channel of model
-        channel c or -1 for a blank plane (reference preprocess.py:110-120, model.py:397-406)."""
+        channel c or -1 for a blank plane (reference preprocess.py:110-120, model.py:397-406).
+
+        ``streams`` > 1 splits the cells into that many contiguous segments and enqueues each on its own HIP stream (own
+        workspace slot): cells are independent, so one segment's launch gaps, tile tails and store bursts overlap another
+        segment's MFMA work.  The result is identical to the single-stream run (every cell sees the same arithmetic)."""
         assert patches.is_cuda and patches.dtype == torch.float32 and patches.dim() == 4 and patches.shape[2:] == (PATCH, PATCH)
         if len(src_chan) != self.C:
             raise ValueError(f"model expects {self.C} channels, got an index list of {len(src_chan)}")
@@ -305,12 +310,47 @@ class VitModel:
         chunk = max(1, min(int(chunk_cells), n))
         src = torch.tensor(list(src_chan), dtype=torch.int32, device=patches.device)
         nbytes = lib().ribca_vit_workspace_bytes(self._h, chunk)
-        ws = workspace(nbytes + 256, patches.device, ws_slot)
-        base = ws.data_ptr()
-        aligned = (base + 255) & ~255
-        check(lib().ribca_vit_forward(self._h, ptr(patches.contiguous()), c_img, ptr(src), n, ptr(probs), aligned, nbytes, chunk,
-                                      stream_ptr()), "ribca_vit_forward")
+        patches = patches.contiguous()
+        n_chunks = (n + chunk - 1) // chunk
+        nseg = max(1, min(int(streams), n_chunks))
+        if nseg == 1:
+            ws = workspace(nbytes + 256, patches.device, ws_slot)
+            aligned = (ws.data_ptr() + 255) & ~255
+            check(lib().ribca_vit_forward(self._h, ptr(patches), c_img, ptr(src), n, ptr(probs), aligned, nbytes, chunk, stream_ptr()),
+                  "ribca_vit_forward")
+            return probs
+        main = torch.cuda.current_stream(patches.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        side = _side_streams(patches.device, nseg)
+        for i, st in enumerate(side):
+            c0, c1 = n_chunks * i // nseg, n_chunks * (i + 1) // nseg
+            lo, hi = c0 * chunk, min(c1 * chunk, n)
+            if hi <= lo:
+                continue
+            ws = workspace(nbytes + 256, patches.device, (ws_slot + 1) * 64 + i)
+            aligned = (ws.data_ptr() + 255) & ~255
+            st.wait_event(ready)
+            with torch.cuda.stream(st):
+                check(lib().ribca_vit_forward(self._h, ptr(patches[lo:hi]), c_img, ptr(src), hi - lo, ptr(probs[lo:hi]), aligned, nbytes, chunk,
+                                              stream_ptr()), "ribca_vit_forward")
+            done = torch.cuda.Event()
+            done.record(st)
+            main.wait_event(done)
         return probs
+
+
+_SIDE: Dict[Tuple[int, int], "torch.cuda.Stream"] = {}
+
+
+def _side_streams(device, n: int):
+    out = []
+    for i in range(n):
+        key = (device.index or 0, i)
+        if key not in _SIDE:
+            _SIDE[key] = torch.cuda.Stream(device=device)
+        out.append(_SIDE[key])
+    return out
 
 
 def mae_blob_keys(enc_depth: int, dec_depth: int) -> List[str]:

@@ -382,3 +382,21 @@ def test_mae_vs_oracle(dev, panel, present):
     got = ops.MaeModel(sd, dev).impute(x.to(dev).contiguous(), present, chunk_cells=16).cpu()
     assert torch.equal(got[:, present], x[:, present])
     assert (got - ref).abs().max().item() < 5e-4
+
+
+@pytest.mark.gpu
+def test_vit_segment_streams_identical():
+    """Splitting the cells over several HIP streams (ops.VitModel.predict_proba(streams=...)) must not change a single bit."""
+    import torch
+    from multiplexed_image_annotator_amd import ops, synth
+    dev = torch.device("cuda:0")
+    sd = synth.make_vit_state_dict("immune_base", seed=5, depth=2)
+    model = ops.VitModel(sd, dev)
+    g = torch.Generator().manual_seed(3)
+    patches = (torch.rand((700, 9, 40, 40), generator=g) * 2 - 1).to(dev)
+    src = [0, 1, 2, -1, 4, 5, 8]
+    a = model.predict_proba(patches, src, chunk_cells=64, streams=1)
+    b = model.predict_proba(patches, src, chunk_cells=64, streams=3)
+    c = model.predict_proba(patches, src, chunk_cells=64, streams=16)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(a, c)
