@@ -74,7 +74,9 @@ def test_layernorm(dev, d):
 
 
 GEMM_SHAPES = [(1, 288, 288), (100, 864, 288), (128, 1152, 288), (300, 288, 1152), (257, 144, 144), (130, 432, 144),
-               (77, 576, 2304), (200, 1728, 576), (129, 384, 384), (64, 64, 64)]
+               (77, 576, 2304), (200, 1728, 576), (129, 384, 384), (64, 64, 64),
+               # >= 256 tiles of 256 x 96: the persistent streaming kernel (1 and 2 epilogue sub-tiles per K step), ragged last m-tile
+               (11100, 576, 576), (22100, 288, 288), (11011, 576, 2304), (16500, 384, 384), (40000, 576, 576), (70001, 288, 288)]
 
 
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
@@ -94,7 +96,7 @@ def test_gemm_residual(dev, m, n, k):
     assert err < 5e-5, err   # bf16x3: ~2^-16 per operand, fp32 accumulate; |terms| ~ 1
 
 
-@pytest.mark.parametrize("m,n,k", [(150, 1152, 288), (101, 576, 144), (260, 2304, 576)])
+@pytest.mark.parametrize("m,n,k", [(150, 1152, 288), (101, 576, 144), (260, 2304, 576), (7001, 1152, 288), (3000, 2304, 576), (20000, 1152, 288), (12000, 2304, 576)])
 def test_gemm_gelu(dev, m, n, k):
     from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
     kp = (k + 31) // 32 * 32
@@ -110,10 +112,10 @@ def test_gemm_gelu(dev, m, n, k):
     assert err < 1e-4, err
 
 
-@pytest.mark.parametrize("d", [144, 288, 384, 576])
-def test_qkv_attention(dev, d):
+@pytest.mark.parametrize("d,cells", [(144, 3), (288, 3), (384, 3), (576, 3), (288, 130), (384, 130), (576, 131), (288, 400)])
+def test_qkv_attention(dev, d, cells):
     from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
-    cells, heads, ntok = 3, 12, 101
+    heads, ntok = 12, 101
     hd = d // heads
     hdp, hdv = (hd + 31) // 32 * 32, (hd + 15) // 16 * 16
     m = cells * ntok
