@@ -15,6 +15,9 @@ from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
 
 cells = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 variants = [int(v) for v in sys.argv[2:]] or [1, 2]
+# RIBCA_BENCH_ROTATE=n: cycle through n copies of the activation / output buffers so that successive launches do not find
+# their operands in the 256 MB Infinity Cache (what a launch sees inside the real pipeline)
+ROT = int(os.environ.get("RIBCA_BENCH_ROTATE", "1"))
 dev = _lib.require_gpu()
 M = cells * 101
 shapes = []
@@ -25,21 +28,24 @@ g = torch.Generator(device="cpu").manual_seed(0)
 print(f"M = {M} rows ({cells} cells); times in ms, TF = algorithmic TFLOP/s (x3 MFMA passes issued)")
 for name, d, n, kp, kind in shapes:
     a = (torch.randn((M, 2 * kp), generator=g) * 0.1).to(torch.bfloat16).view(torch.int16).to(dev)
+    a_set = [a] + [a.clone() for _ in range(ROT - 1)]
     npad = lib().ribca_gemm_padded_n(n)
     w = (torch.randn((npad, 2 * kp), generator=g) * 0.1).to(torch.bfloat16).view(torch.int16).to(dev)
     bias = torch.zeros(n, device=dev)
     out = torch.zeros((M, n if kind == 0 else 2 * n), dtype=torch.float32 if kind == 0 else torch.int16, device=dev)
     ldo = n if kind == 0 else 2 * n
+    out_set = [out] + [out.clone() for _ in range(ROT - 1)]
     res = {}
     for rnd in range(3):
         for v in variants:
             lib().ribca_set_gemm_variant(v)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 5
+            reps = 5 if ROT == 1 else 2 * ROT
             check(lib().ribca_test_gemm(kind, ptr(a), 2 * kp, ptr(w), 2 * kp, M, n, kp, ptr(bias), ptr(out), ldo, stream_ptr()), "gemm")
             e0.record()
-            for _ in range(reps):
-                check(lib().ribca_test_gemm(kind, ptr(a), 2 * kp, ptr(w), 2 * kp, M, n, kp, ptr(bias), ptr(out), ldo, stream_ptr()), "gemm")
+            for r in range(reps):
+                check(lib().ribca_test_gemm(kind, ptr(a_set[r % ROT]), 2 * kp, ptr(w), 2 * kp, M, n, kp, ptr(bias), ptr(out_set[r % ROT]), ldo,
+                                            stream_ptr()), "gemm")
             e1.record()
             torch.cuda.synchronize()
             res.setdefault(v, []).append(e0.elapsed_time(e1) / reps)
