@@ -50,6 +50,17 @@ int ribca_extract_patches(const float* image, int32_t C, int32_t H, int32_t W, c
                           const int32_t* cell_id, const int32_t* bbox, const double* taps, int32_t n, float* patches, double* avg,
                           void* stream);
 
+/* Same for cell_size != 30 (preprocess.py:78,106): window patch_size = int(40 * cell_size / 30), then
+ * skimage.transform.resize(patch, (C, 40, 40), order=0, anti_aliasing=True, preserve_range=True): fp64 Gaussian pre-filter
+ * (aa_taps[0..aa_radius], weight at distance k, sigma = (patch_size/40 - 1)/2; aa_radius = 0 when patch_size <= 40) in
+ * 'mirror' mode, nearest-neighbour grid sampling at src_index[0..39] (host: floor(((o + 0.5) * patch_size/40 - 0.5) + 0.5) in
+ * fp64, as scipy.ndimage.zoom(order=0, grid_mode=True)), one rounding to fp32.  avg is taken over the patch_size window
+ * before the resize, as crop_cell does.  4 <= patch_size <= 90. */
+int ribca_extract_patches_scaled(const float* image, int32_t C, int32_t H, int32_t W, const int32_t* mask, const float* chan_min,
+                                 const int32_t* cell_id, const int32_t* bbox, const double* taps, int32_t n, int32_t patch_size,
+                                 const double* aa_taps, int32_t aa_radius, const int32_t* src_index, float* patches, double* avg,
+                                 void* stream);
+
 /* ---- whole-image normalisation primitives (ImageProcessor._normalize, preprocess.py:214-239) ---------------------
  * The host drives them per image (ops.normalize_image in the Python package shows the sequence): the percentile needs
  * a data-dependent host decision, everything touching pixels runs here.  Results are bit-identical to the reference. */

@@ -547,6 +547,21 @@ int ribca_extract_patches(const float* image, int32_t C, int32_t H, int32_t W, c
   return 0;
 }
 
+int ribca_extract_patches_scaled(const float* image, int32_t C, int32_t H, int32_t W, const int32_t* mask, const float* chan_min,
+                                 const int32_t* cell_id, const int32_t* bbox, const double* taps, int32_t n, int32_t patch_size,
+                                 const double* aa_taps, int32_t aa_radius, const int32_t* src_index, float* patches, double* avg,
+                                 void* stream) {
+  if (n == 0) return 0;
+  if (!image || !mask || !chan_min || !cell_id || !bbox || !taps || !patches || !src_index) return fail("ribca_extract_patches_scaled: NULL buffer");
+  if (aa_radius > 0 && !aa_taps) return fail("ribca_extract_patches_scaled: aa_taps is NULL");
+  if (C <= 0 || H <= 0 || W <= 0 || n < 0) return fail("ribca_extract_patches_scaled: bad sizes");
+  PatchArgs a{image, C, H, W, mask, chan_min, cell_id, bbox, taps, patches, avg, n};
+  if (launch_extract_patches_scaled(a, patch_size, aa_taps, aa_radius, src_index, (hipStream_t)stream) != 0)
+    return fail("ribca_extract_patches_scaled: patch_size must be in [4, 90] (cell_size up to 67) and aa_radius in [0, 15]");
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 int ribca_vote(const float* p_a, int32_t k_a, const int8_t* map_a, const float* p_b, int32_t k_b, const int8_t* map_b,
                const float* type_conf, float conf, int32_t n, int8_t* label, float* out_conf, void* stream) {
   if (n == 0) return 0;

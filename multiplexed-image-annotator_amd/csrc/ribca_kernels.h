@@ -79,6 +79,9 @@ struct PatchArgs {
   int n;
 };
 void launch_extract_patches(const PatchArgs& a, hipStream_t s);
+// cell_size != 30: window ps x ps, anti-alias taps (aa_radius + 1 doubles, 0 = no filter), 40 nearest-neighbour source indices.
+// Returns non-zero if ps is outside what one workgroup can hold (ps*ps <= 8192).
+int launch_extract_patches_scaled(const PatchArgs& a, int ps, const double* aa_taps, int aa_radius, const int32_t* src_index, hipStream_t s);
 
 // ----- whole-image normalisation (normalize.hip) ---------------------------------------------------------------
 void launch_u16_to_f32(const uint16_t* in, float* out, long long n, hipStream_t s);

@@ -114,9 +114,44 @@ def channel_min(image: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_RESIZE_PLANS: Dict[Tuple[int, int], Tuple[Optional[torch.Tensor], int, torch.Tensor]] = {}
+
+
+def resize_plan(patch_size: int) -> Tuple[Optional[np.ndarray], int, np.ndarray]:
+    """What ``skimage.transform.resize((C, ps, ps) -> (C, 40, 40), order=0, anti_aliasing=True)`` does per plane, as data:
+    Gaussian taps at distance 0..R (sigma = (ps/40 - 1)/2 > 0 only when down-sampling; scipy's truncate-4 radius), and the 40
+    nearest-neighbour source indices of ``scipy.ndimage.zoom(order=0, grid_mode=True)`` -- both computed with the same fp64
+    operations as the libraries (reference call site preprocess.py:106)."""
+    ps = int(patch_size)
+    factor = np.divide(ps, PATCH)                              # skimage: factors = input_shape / output_shape
+    sigma = max(0.0, float((factor - 1) / 2))
+    taps, radius = None, 0
+    if sigma > 0:
+        radius = int(4.0 * sigma + 0.5)
+        if radius > 0:
+            taps = _gauss_weights(sigma)
+    zoom = np.float64(ps) / np.float64(PATCH)                  # ndimage.zoom(grid_mode=True): input extent / output extent
+    o = np.arange(PATCH, dtype=np.float64)
+    cc = (o + 0.5) * zoom - 0.5                                # NI_ZoomShift: cc += 0.5; cc *= zoom; cc -= 0.5
+    idx = np.floor(cc + 0.5).astype(np.int64)                  # order 0: start = floor(cc + 0.5)
+    idx = np.clip(idx, 0, ps - 1)
+    return taps, radius, idx.astype(np.int32)
+
+
+def _resize_plan_dev(patch_size: int, device):
+    key = (int(patch_size), device.index or 0)
+    if key not in _RESIZE_PLANS:
+        taps, radius, idx = resize_plan(patch_size)
+        t = torch.from_numpy(np.ascontiguousarray(taps)).to(device) if taps is not None else None
+        _RESIZE_PLANS[key] = (t, radius, torch.from_numpy(idx).to(device))
+    return _RESIZE_PLANS[key]
+
+
 def extract_patches(image: torch.Tensor, mask: torch.Tensor, chan_min: torch.Tensor, ids: torch.Tensor, bbox: torch.Tensor,
-                    want_avg: bool = False, out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """Soft-masked fp32 patches (n, C, 40, 40) for the given cells (ids int32 [n], bbox int32 [n, 4])."""
+                    want_avg: bool = False, out: Optional[torch.Tensor] = None, patch_size: int = PATCH) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Soft-masked fp32 patches (n, C, 40, 40) for the given cells (ids int32 [n], bbox int32 [n, 4]).  ``patch_size`` =
+    ``int(40 * cell_size / 30)`` (reference preprocess.py:78): windows of another size are resized to 40 x 40 as the
+    reference does (preprocess.py:106)."""
     c, h, w = image.shape
     n = ids.numel()
     assert image.dtype == torch.float32 and mask.dtype == torch.int32 and ids.dtype == torch.int32 and bbox.dtype == torch.int32
@@ -124,9 +159,14 @@ def extract_patches(image: torch.Tensor, mask: torch.Tensor, chan_min: torch.Ten
     if out is None:
         out = torch.empty((n, c, PATCH, PATCH), dtype=torch.float32, device=image.device)
     avg = torch.empty((n, c), dtype=torch.float64, device=image.device) if want_avg else None
-    if n:
+    if n and int(patch_size) == PATCH:
         check(lib().ribca_extract_patches(ptr(image), c, h, w, ptr(mask), ptr(chan_min), ptr(ids), ptr(bbox), ptr(_taps(image.device)), n,
                                           ptr(out), ptr(avg), stream_ptr()), "ribca_extract_patches")
+    elif n:
+        taps, radius, idx = _resize_plan_dev(patch_size, image.device)
+        check(lib().ribca_extract_patches_scaled(ptr(image), c, h, w, ptr(mask), ptr(chan_min), ptr(ids), ptr(bbox), ptr(_taps(image.device)), n,
+                                                 int(patch_size), ptr(taps), radius, ptr(idx), ptr(out), ptr(avg), stream_ptr()),
+              "ribca_extract_patches_scaled")
     return out, avg
 
 

@@ -107,6 +107,9 @@ class ImageProcessor(object):
         self.masks: List[np.ndarray] = []
         self.device = device
         self.scale = cell_size / 30.0
+        self.patch_size = int(40 * self.scale)           # preprocess.py:78
+        if not 4 <= self.patch_size <= 90:
+            raise NotImplementedError("cell_size must give a crop window of 4..90 pixels (cell_size 3..67): one workgroup holds the window")
         self.n_jobs = n_jobs
         # device-resident state of the hot path
         self.images_dev: List[torch.Tensor] = []
@@ -142,14 +145,12 @@ class ImageProcessor(object):
         ids = torch.from_numpy(self.cell_ids[image_idx][lo:hi].astype(np.int32)).to(dev)
         bbox = torch.from_numpy(self.cell_tables[image_idx][lo:hi, :4].astype(np.int32)).to(dev)
         return ops.extract_patches(self.images_dev[image_idx], self.masks_dev[image_idx], self.chan_min[image_idx], ids, bbox,
-                                   want_avg=want_avg)
+                                   want_avg=want_avg, patch_size=self.patch_size)
 
     # ---- reference entry point -------------------------------------------------------------------------------------
     def transform(self, shard_fn=None, gather_fn=None, keep_patches: bool = True, chunk: int = 16384):
         """preprocess.py:241-290.  ``shard_fn(n) -> (lo, hi)`` picks this rank's cells (default: all);
         ``gather_fn(local (n_local, C) fp64 tensor, n) -> (n, C)`` reassembles per-cell rows across ranks."""
-        if self.scale != 1.0:
-            raise NotImplementedError("cell_size != 30 (patch resize, reference preprocess.py:78,106) is not on the GPU path yet")
         dev = _lib.require_gpu()
         for i, (image_path, mask_path) in enumerate(zip(self.image_paths, self.mask_paths)):
             image = read_image(image_path)

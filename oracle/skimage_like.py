@@ -59,4 +59,7 @@ def resize(image: np.ndarray, output_shape, order: int = 0, anti_aliasing: bool 
         if np.any(sig > 0):
             filtered = ndi.gaussian_filter(img, sig, cval=0, mode="mirror")
     zoom = [1.0 / f for f in factors]
-    return ndi.zoom(filtered, zoom, order=order, mode="mirror", cval=0, grid_mode=True)
+    out = ndi.zoom(filtered, zoom, order=order, mode="mirror", cval=0, grid_mode=True)
+    # resize(clip=True) default: _clip_warp_output clips to the range of the (unfiltered) input
+    np.clip(out, np.min(img), np.max(img), out=out)
+    return out

@@ -217,6 +217,32 @@ def golden_patches():
     print("patches.npz", {k: v.shape for k, v in out.items() if k.endswith("patches")})
 
 
+def golden_patches_scaled():
+    """cell_size != 30: the reference's own _img2patches with scale = cell_size / 30 (patch_size = int(40 * scale), crop_cell
+    on that window, resize back to 40 x 40).  skimage is absent, so `resize` is oracle/skimage_like.py: this pins the
+    reference's control flow around it (window size, what is resized, what the intensity is taken from), not skimage itself."""
+    pre = ref("preprocess")
+    dummy = object.__new__(pre.ImageProcessor)
+    out = {}
+    m = odd_mask()
+    raw = small_raw_tile(3, 90, 120, synth.SEED_BASE + 141)
+    dummy.scale = 1.0
+    img = pre.ImageProcessor._normalize(dummy, raw, blur=0.3, amax=99.8)
+    d = pre.ImageProcessor._cell_pos_dict(dummy, m, n_jobs=0)
+    tmp = tempfile.mkdtemp()
+    out["image"] = img
+    out["mask"] = m
+    for cell_size in (20, 34, 45, 60):
+        dummy.scale = cell_size / 30.0
+        inten = pre.ImageProcessor._img2patches(dummy, img, m, [2, 0, 1], d, None, id=f"g_s{cell_size}", save_path=tmp, save_tensor=True,
+                                                int_full=True)
+        out[f"s{cell_size}_patches"] = torch.load(os.path.join(tmp, f"g_s{cell_size}_batch_0.pt")).numpy()
+        out[f"s{cell_size}_intensity"] = inten
+    shutil.rmtree(tmp)
+    np.savez_compressed(os.path.join(HERE, "patches_scaled.npz"), **out)
+    print("patches_scaled.npz", {k: v.shape for k, v in out.items() if k.endswith("patches")})
+
+
 # ---------------------------------------------------------------------------------------------- G4
 PARSER_CASES = {
     "basic7": ['CD45', 'CD20', 'CD4', 'CD8', 'DAPI', 'CD11c', 'CD3'],
@@ -534,6 +560,6 @@ def golden_mae():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["normalize", "cellpos", "patches", "parser", "vote", "vit", "e2e", "mae"]
+    which = sys.argv[1:] or ["normalize", "cellpos", "patches", "patches_scaled", "parser", "vote", "vit", "e2e", "mae"]
     for w in which:
         globals()["golden_" + w]()

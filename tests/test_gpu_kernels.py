@@ -402,3 +402,40 @@ def test_vit_segment_streams_identical():
     c = model.predict_proba(patches, src, chunk_cells=64, streams=16)
     torch.cuda.synchronize()
     assert torch.equal(a, b) and torch.equal(a, c)
+
+
+@pytest.mark.parametrize("cell_size", [20, 34, 45, 60, 67])
+def test_patches_scaled_match_oracle(dev, cell_size):
+    """cell_size != 30 (reference preprocess.py:78,106): crop window int(40 * cell_size / 30), soft mask on that window,
+    anti-aliased nearest-neighbour resize to 40 x 40.  Bit-exact against the oracle restatement (scipy primitives)."""
+    from oracle import ref_preprocess as rp
+    ops = _ops()
+    mask_t, raw_t = synth.make_mask_and_image(200, 230, 60, 4, seed=77, device=torch.device("cpu"))
+    mask = mask_t.numpy().astype(np.int32)
+    image = rp.normalize_image(raw_t.numpy(), blur=0.3, amax=99.8)
+    ids, table = rp.cell_table(mask)
+    sel = np.arange(len(ids))[:40]
+    exp, exp_int = rp.patches_for_panel(image, mask, [0, 1, 2, 3], ids[sel], table[sel], scale=cell_size / 30.0)
+    img_d = torch.from_numpy(image).to(dev)
+    mask_d = torch.from_numpy(mask).to(dev)
+    got, avg = ops.extract_patches(img_d, mask_d, ops.channel_min(img_d), torch.from_numpy(ids[sel].astype(np.int32)).to(dev),
+                                   torch.from_numpy(table[sel, :4].astype(np.int32)).to(dev), want_avg=True,
+                                   patch_size=int(40 * (cell_size / 30.0)))
+    np.testing.assert_array_equal(got.cpu().numpy(), exp)
+    np.testing.assert_allclose((avg.cpu().numpy() + 1) / 2, exp_int, rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize("cell_size", [20, 34, 45, 60])
+def test_patches_scaled_golden(dev, golden_dir, cell_size):
+    """Same through the C ABI against vectors produced by the reference's own _img2patches (tests/golden/make_golden.py)."""
+    ops = _ops()
+    g = np.load(os.path.join(golden_dir, "patches_scaled.npz"))
+    img = torch.from_numpy(g["image"]).to(dev)
+    mask = torch.from_numpy(g["mask"]).to(dev)
+    ids, tab = ops.label_table(mask)
+    patches, avg = ops.extract_patches(img, mask, ops.channel_min(img), torch.from_numpy(ids.astype(np.int32)).to(dev),
+                                       torch.from_numpy(tab[:, :4].astype(np.int32)).to(dev), want_avg=True,
+                                       patch_size=int(40 * (cell_size / 30.0)))
+    np.testing.assert_array_equal(patches.cpu().numpy()[:, [2, 0, 1]], g[f"s{cell_size}_patches"])
+    # the intensity table is per IMAGE channel (crop_cell averages every channel), not per panel channel
+    np.testing.assert_allclose((avg.cpu().numpy() + 1) / 2, g[f"s{cell_size}_intensity"], rtol=1e-12, atol=1e-14)

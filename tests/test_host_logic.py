@@ -40,3 +40,25 @@ def test_gaussian_taps_match_scipy():
         resp = gaussian_filter1d(impulse, sigma, mode="nearest", truncate=4.0)
         np.testing.assert_array_equal(resp[3 * r:3 * r + r + 1], taps[off:off + r + 1])
         off += r + 1
+
+
+@pytest.mark.parametrize("ps", [20, 26, 39, 41, 45, 53, 60, 80, 90])
+def test_resize_plan_matches_scipy_zoom(ps):
+    """ops.resize_plan: the 40 nearest-neighbour source indices and the anti-alias taps are what scipy.ndimage.zoom(order=0,
+    grid_mode=True) / gaussian_filter use (the two library calls inside skimage.transform.resize, reference preprocess.py:106)."""
+    import numpy as np
+    from scipy import ndimage as ndi
+    from multiplexed_image_annotator_amd import ops
+    taps, radius, idx = ops.resize_plan(ps)
+    ramp = np.arange(ps * ps, dtype=np.float64).reshape(ps, ps)
+    z = ndi.zoom(ramp, [40 / ps * 1.0 if False else 1.0 / (ps / 40)] * 2, order=0, mode="mirror", grid_mode=True)
+    assert z.shape == (40, 40)
+    np.testing.assert_array_equal(z, ramp[np.ix_(idx, idx)])
+    sigma = max(0.0, (ps / 40 - 1) / 2)
+    if sigma > 0 and int(4 * sigma + 0.5) > 0:
+        imp = np.zeros(4 * radius + 1)
+        imp[2 * radius] = 1.0
+        ref = ndi.gaussian_filter(imp, sigma, mode="mirror")
+        np.testing.assert_array_equal(ref[2 * radius:3 * radius + 1], taps)
+    else:
+        assert taps is None and radius == 0

@@ -107,3 +107,13 @@ def test_window_bounds_edges():
     assert rp.window_bounds(0, 4, 0, 6, 90, 120) == (0, 40, 0, 40)
     assert rp.window_bounds(85, 89, 110, 119, 90, 120) == (67, 90, 94, 120)
     assert rp.window_bounds(30, 39, 40, 49, 90, 120) == (14, 54, 24, 64)
+
+
+@pytest.mark.parametrize("cell_size", [20, 34, 45, 60])
+def test_scaled_patches_match_reference(golden_dir, cell_size):
+    """cell_size != 30 through the reference's own _img2patches (preprocess.py:76-135): window int(40 * cell_size / 30), resize to 40."""
+    g = np.load(os.path.join(golden_dir, "patches_scaled.npz"))
+    ids, tab = rp.cell_table(g["mask"])
+    patches, inten = rp.patches_for_panel(g["image"], g["mask"], [2, 0, 1], ids, tab, scale=cell_size / 30.0)
+    np.testing.assert_array_equal(patches, g[f"s{cell_size}_patches"])
+    np.testing.assert_array_equal(inten, g[f"s{cell_size}_intensity"])
