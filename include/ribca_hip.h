@@ -130,6 +130,14 @@ int64_t ribca_mae_workspace_bytes(const ribca_mae_t* m, int32_t chunk_cells, int
 int ribca_mae_impute(const ribca_mae_t* m, float* patches, const int32_t* present_host, int32_t n_present, int32_t n_cells,
                      void* workspace, int64_t workspace_bytes, int32_t chunk_cells, void* stream);
 
+/* ---- label painting (Annotator.colorize, model.py:806-858, without tissue regions) ---------------------------------
+ * mask (n_pixels) int32; label_to_cell (L) int32: row of the label in the per-cell arrays or -1; per-cell colours
+ * cell_type_rgb / cell_conf_rgb (n_cells, 3) uint8 and cell_type_idx (n_cells) uint8 (= cell-type index + 1).
+ * Outputs: (n_pixels, 3), (n_pixels, 3), (n_pixels) uint8; background and unknown labels are 0. */
+int ribca_colorize(const int32_t* mask, int64_t n_pixels, const int32_t* label_to_cell, int32_t L, const uint8_t* cell_type_rgb,
+                   const uint8_t* cell_conf_rgb, const uint8_t* cell_type_idx, uint8_t* out_type_rgb, uint8_t* out_conf_rgb,
+                   uint8_t* out_type_idx, void* stream);
+
 /* ---- vote (Annotator.merge_by_voting, model.py:481-633) ------------------------------------------------------ */
 /* Global class ids: 0..16 = key order of utils.get_void_vote (utils.py:143-146), 17 = "Others".
  * p_a (n, k_a) and optional p_b (n, k_b) are softmax outputs; map_* (k) int8 give each class's global id;

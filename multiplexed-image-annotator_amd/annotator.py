@@ -12,7 +12,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from . import _lib, dist, ops
+from . import _lib, colors, dist, ops
 from .logger import Logger
 from .marker_parse import MarkerParser
 from .preprocess import ImageProcessor
@@ -246,7 +246,7 @@ class Annotator(object):
         self.cell_types = self._get_unique_cell_types()
         self.cell_types = np.delete(self.cell_types, np.where(self.cell_types == "Others"))
         self.cell_types = np.append(self.cell_types, "Others")
-        self.colors = _spread_colors(len(self.cell_types))
+        self.colors = colors.get_colors(len(self.cell_types))     # model.py:459 (the legend PNG of model.py:461-462 is not drawn)
         self._annotations_all = None
 
     def merge_by_voting(self):
@@ -311,14 +311,42 @@ class Annotator(object):
         os.rmdir(self.temp_dir)
         self.logger.log("Temporary files cleared")
 
+    # ---- label painting (model.py:806-858) -------------------------------------------------------------------------
+    def paint(self, image_idx: int):
+        """Device tensors (H, W, 3) uint8 cell-type colours, (H, W, 3) uint8 confidence colours (silver where thresholded),
+        (H, W) uint8 cell-type index + 1 -- what ``colorize`` writes as PNGs.  One gather kernel per image instead of the
+        reference's per-cell fancy indexing."""
+        pre = self.preprocessor
+        ids = pre.cell_ids[image_idx]
+        types = {str(t): k for k, t in enumerate(self.cell_types)}
+        gid_to_type = np.array([types.get(name, 0) for name in ops.GLOBAL_NAMES], dtype=np.int64)
+        tidx = gid_to_type[self.label_ids[image_idx]]
+        palette = np.array(self.colors, dtype=np.uint8)
+        conf = np.array([float(c) for c in self.confidence[image_idx]], dtype=np.float32)
+        return ops.colorize(pre.masks_dev[image_idx], ids, palette[tidx], colors.confidence_colors(conf), (tidx + 1).astype(np.uint8))
+
+    def colorize(self, from_script=False):
+        if len(self.preprocessor.masks) == 0:
+            raise ValueError("No masks to colorize")
+        if len(self.annotations) == 0:
+            raise ValueError("No annotations to colorize")
+        if self.n_regions > 0:
+            raise NotImplementedError("tissue-region maps need tissue_region_analysis, which is outside the accelerated path")
+        from PIL import Image
+        for i in range(len(self.preprocessor.masks)):
+            type_rgb, conf_rgb, type_idx = (t.cpu().numpy() for t in self.paint(i))
+            if self.rank != 0:
+                continue
+            Image.fromarray(type_rgb).save(os.path.join(self.result_dir, f"{self.batch_id}_colorized_annotation_{i}.png"))
+            if not from_script:            # napari working file of the reference GUI (model.py:845-847), only inside its source tree
+                gui_dir = "./src/multiplexed_image_annotator/cell_type_annotation/_working_dir_temp"
+                if os.path.isdir(gui_dir):
+                    Image.fromarray(type_idx).save(os.path.join(gui_dir, "output_img.png"))
+            Image.fromarray(conf_rgb).save(os.path.join(self.result_dir, f"{self.batch_id}_confidence_{i}.png"))
+
     # ---- outside the accelerated path ------------------------------------------------------------------------------
     def _out_of_scope(self, *_a, **_k):
-        raise NotImplementedError("post-analysis / plotting of the reference (heatmaps, UMAP, neighbourhood, tissue regions, colourised "
-                                  "masks) is CPU work downstream of the CSV and outside this accelerated hot path")
+        raise NotImplementedError("post-analysis / plotting of the reference (heatmaps, UMAP, neighbourhood, tissue regions) is CPU "
+                                  "work downstream of the CSV and outside this accelerated hot path")
 
-    generate_heatmap = umap_visualization = neighborhood_analysis = tissue_region_analysis = colorize = cell_type_composition = _out_of_scope
-
-
-def _spread_colors(n: int):
-    import colorsys
-    return [[int(255 * v) for v in colorsys.hsv_to_rgb(i / max(n, 1), 0.65, 0.95)] for i in range(n)]
+    generate_heatmap = umap_visualization = neighborhood_analysis = tissue_region_analysis = cell_type_composition = _out_of_scope

@@ -574,6 +574,19 @@ int ribca_vote(const float* p_a, int32_t k_a, const int8_t* map_a, const float* 
   return 0;
 }
 
+int ribca_colorize(const int32_t* mask, int64_t n_pixels, const int32_t* label_to_cell, int32_t L, const uint8_t* cell_type_rgb,
+                   const uint8_t* cell_conf_rgb, const uint8_t* cell_type_idx, uint8_t* out_type_rgb, uint8_t* out_conf_rgb,
+                   uint8_t* out_type_idx, void* stream) {
+  if (n_pixels == 0) return 0;
+  if (!mask || !label_to_cell || !cell_type_rgb || !cell_conf_rgb || !cell_type_idx || !out_type_rgb || !out_conf_rgb || !out_type_idx)
+    return fail("ribca_colorize: NULL buffer");
+  if (n_pixels < 0 || L <= 0) return fail("ribca_colorize: bad sizes");
+  launch_colorize(mask, n_pixels, label_to_cell, L, cell_type_rgb, cell_conf_rgb, cell_type_idx, out_type_rgb, out_conf_rgb, out_type_idx,
+                  (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------- normalisation primitives
 int ribca_u16_to_f32(const uint16_t* in, float* out, int64_t n, void* stream) {
   if (n > 0 && (!in || !out)) return fail("ribca_u16_to_f32: NULL buffer");

@@ -170,6 +170,30 @@ def extract_patches(image: torch.Tensor, mask: torch.Tensor, chan_min: torch.Ten
     return out, avg
 
 
+def colorize(mask: torch.Tensor, ids: np.ndarray, type_rgb: np.ndarray, conf_rgb: np.ndarray, type_idx: np.ndarray):
+    """Paint every labelled pixel with its cell's colours (reference Annotator.colorize, model.py:806-858): ``ids`` ascending cell
+    labels (n), per-cell ``type_rgb`` / ``conf_rgb`` (n, 3) uint8 and ``type_idx`` (n) uint8.  Returns device tensors (H, W, 3),
+    (H, W, 3), (H, W) uint8."""
+    assert mask.is_cuda and mask.dtype == torch.int32 and mask.dim() == 2
+    n = len(ids)
+    assert type_rgb.shape == (n, 3) and conf_rgb.shape == (n, 3) and type_idx.shape == (n,)
+    h, w = mask.shape
+    dev = mask.device
+    top = int(ids.max()) + 1 if n else 1
+    table = np.full(top, -1, dtype=np.int32)
+    table[np.asarray(ids, dtype=np.int64)] = np.arange(n, dtype=np.int32)
+    tab_d = torch.from_numpy(table).to(dev)
+    a = torch.from_numpy(np.ascontiguousarray(type_rgb, dtype=np.uint8)).to(dev) if n else torch.zeros((1, 3), dtype=torch.uint8, device=dev)
+    b = torch.from_numpy(np.ascontiguousarray(conf_rgb, dtype=np.uint8)).to(dev) if n else torch.zeros((1, 3), dtype=torch.uint8, device=dev)
+    c = torch.from_numpy(np.ascontiguousarray(type_idx, dtype=np.uint8)).to(dev) if n else torch.zeros((1,), dtype=torch.uint8, device=dev)
+    out_t = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
+    out_c = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
+    out_i = torch.empty((h, w), dtype=torch.uint8, device=dev)
+    check(lib().ribca_colorize(ptr(mask.contiguous()), h * w, ptr(tab_d), top, ptr(a), ptr(b), ptr(c), ptr(out_t), ptr(out_c), ptr(out_i),
+                               stream_ptr()), "ribca_colorize")
+    return out_t, out_c, out_i
+
+
 # ------------------------------------------------------------------------------------------- whole-image normalisation
 def _gauss_weights(sigma: float) -> np.ndarray:
     """Taps at distance 0..R of scipy.ndimage.gaussian_filter(sigma, truncate=4.0), computed as scipy computes them."""

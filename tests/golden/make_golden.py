@@ -518,6 +518,53 @@ def golden_e2e():
     print("e2e", {k: len(v["labels"]) for k, v in meta.items()})
 
 
+# ---------------------------------------------------------------------------------------------- colorize
+def golden_colorize():
+    """Annotator.colorize (model.py:806-858) and utils.get_colors / number_to_rgb, driven with the labels / confidences of the
+    e2e goldens (no ViT run needed): the three label paintings of each tile + the palette for several sizes."""
+    model = ref("model")
+    utils = ref("utils")
+    pre = ref("preprocess")
+    meta = json.load(open(os.path.join(HERE, "e2e.json")))
+    arrs = np.load(os.path.join(HERE, "e2e.npz"))
+    out = {}
+    cwd = os.getcwd()
+    for cname, m in meta.items():
+        tmp = tempfile.mkdtemp()
+        os.chdir(tmp)
+        os.makedirs("results")
+        os.makedirs("src/multiplexed_image_annotator/cell_type_annotation/_working_dir_temp")
+        mask, _ = synth.make_mask_and_image(m["h"], m["w"], m["cells"], len(m["markers"]), m["seed"], want_image=False)
+        mask = mask.numpy().astype(np.int32)
+        a = object.__new__(model.Annotator)
+        dummy = object.__new__(pre.ImageProcessor)
+        dummy.masks = [mask]
+        dummy.cell_pos_dict = [pre.ImageProcessor._cell_pos_dict(dummy, mask, n_jobs=0)]
+        a.preprocessor = dummy
+        a.annotations = [list(m["labels"])]
+        conf = arrs[cname + "__conf"]
+        a.confidence = [[-1 if c == -1 else np.float32(c) for c in conf]]
+        a.cell_types = np.array(m["cell_types"])
+        a.colors = utils.get_colors(len(a.cell_types))
+        a.n_regions = 0
+        a.result_dir = "results"
+        a.batch_id = "g"
+        a.colorize(from_script=False)
+        from PIL import Image
+        out[cname + "__type_rgb"] = np.array(Image.open("results/g_colorized_annotation_0.png"))
+        out[cname + "__conf_rgb"] = np.array(Image.open("results/g_confidence_0.png"))
+        out[cname + "__type_idx"] = np.array(Image.open("src/multiplexed_image_annotator/cell_type_annotation/_working_dir_temp/output_img.png"))
+        os.chdir(cwd)
+        shutil.rmtree(tmp)
+    for n in (1, 2, 6, 17, 18, 19, 30):
+        out[f"colors_{n}"] = np.array(utils.get_colors(n), np.int64)
+    vals = np.concatenate([np.linspace(0, 1, 257), np.float32([0.25, 0.3, 0.5360000133514404, 0.999999])]).astype(np.float32)
+    out["viridis_in"] = vals
+    out["viridis_rgb"] = np.array([utils.number_to_rgb(v) for v in vals], np.int64)
+    np.savez_compressed(os.path.join(HERE, "colorize.npz"), **out)
+    print("colorize.npz", {k: v.shape for k, v in out.items()})
+
+
 # ---------------------------------------------------------------------------------------------- G6
 def mae_inputs(panel, n, seed):
     L = synth.MAE_PANELS[panel]
@@ -560,6 +607,6 @@ def golden_mae():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["normalize", "cellpos", "patches", "patches_scaled", "parser", "vote", "vit", "e2e", "mae"]
+    which = sys.argv[1:] or ["normalize", "cellpos", "patches", "patches_scaled", "parser", "vote", "vit", "e2e", "mae", "colorize"]
     for w in which:
         globals()["golden_" + w]()

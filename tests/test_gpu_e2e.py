@@ -58,6 +58,17 @@ def test_annotator_matches_reference_golden(golden_dir, tmp_path, name):
     assert np.abs(conf - arrs[f"{name}__conf"]).max() < 1e-3
     assert [isinstance(c, int) for c in a.confidence[0]] == [c == -1 for c in arrs[f"{name}__conf"]]
     np.testing.assert_allclose(a.preprocessor.intensity_full[0], arrs[f"{name}__intensity"], rtol=1e-12, atol=1e-14)
+    # label painting (reference Annotator.colorize): type colours / indices identical; a confidence colour may move to the
+    # neighbouring viridis bucket where conf * 256 sits within the 1e-3 tolerance of an integer
+    gc = np.load(os.path.join(golden_dir, "colorize.npz"))
+    assert [tuple(c) for c in a.colors[:-1]] == [tuple(c) for c in gc["colors_30"][:len(a.cell_types) - 1].tolist()] and tuple(a.colors[-1]) == (192, 192, 192)
+    a.colorize(from_script=True)
+    from PIL import Image
+    np.testing.assert_array_equal(np.array(Image.open(tmp_path / "results" / "g_colorized_annotation_0.png")), gc[f"{name}__type_rgb"])
+    np.testing.assert_array_equal(a.paint(0)[2].cpu().numpy(), gc[f"{name}__type_idx"])
+    cpng = np.array(Image.open(tmp_path / "results" / "g_confidence_0.png")).astype(np.int64)
+    diff = np.abs(cpng - gc[f"{name}__conf_rgb"].astype(np.int64))
+    assert (diff.max(axis=2) > 0).mean() < 0.02 and diff.max() <= 6
     csv_equal_up_to_conf(open(tmp_path / "results" / "g_annotation_0.csv").read(), meta["csv"], 1.5e-3)
     # pixel lists of the lazy cell_pos_dict agree with the mask
     key = meta["cell_ids"][3]

@@ -439,3 +439,27 @@ def test_patches_scaled_golden(dev, golden_dir, cell_size):
     np.testing.assert_array_equal(patches.cpu().numpy()[:, [2, 0, 1]], g[f"s{cell_size}_patches"])
     # the intensity table is per IMAGE channel (crop_cell averages every channel), not per panel channel
     np.testing.assert_allclose((avg.cpu().numpy() + 1) / 2, g[f"s{cell_size}_intensity"], rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize("name", ["basic", "two_model"])
+def test_colorize_golden(dev, golden_dir, name):
+    """ribca_colorize against the three label paintings the reference's Annotator.colorize produced (model.py:806-858)."""
+    from multiplexed_image_annotator_amd import colors
+    ops = _ops()
+    meta = json.load(open(os.path.join(golden_dir, "e2e.json")))[name]
+    conf = np.load(os.path.join(golden_dir, "e2e.npz"))[f"{name}__conf"]
+    g = np.load(os.path.join(golden_dir, "colorize.npz"))
+    mask, _ = synth.make_mask_and_image(meta["h"], meta["w"], meta["cells"], len(meta["markers"]), meta["seed"], want_image=False)
+    mask_d = mask.to(torch.int32).to(dev)
+    ids, _ = ops.label_table(mask_d)
+    tidx = np.array([meta["cell_types"].index(l) for l in meta["labels"]], np.int64)
+    palette = np.array(colors.get_colors(len(meta["cell_types"])), np.uint8)
+    t, c, i = ops.colorize(mask_d, ids, palette[tidx], colors.confidence_colors(conf), (tidx + 1).astype(np.uint8))
+    np.testing.assert_array_equal(t.cpu().numpy(), g[f"{name}__type_rgb"])
+    np.testing.assert_array_equal(c.cpu().numpy(), g[f"{name}__conf_rgb"])
+    np.testing.assert_array_equal(i.cpu().numpy(), g[f"{name}__type_idx"])
+    # odd pixel count (tail path of the 4-pixel groups)
+    sub = mask_d[:7, :9].contiguous()
+    t2, c2, i2 = ops.colorize(sub, ids, palette[tidx], colors.confidence_colors(conf), (tidx + 1).astype(np.uint8))
+    np.testing.assert_array_equal(t2.cpu().numpy(), g[f"{name}__type_rgb"][:7, :9])
+    np.testing.assert_array_equal(i2.cpu().numpy(), g[f"{name}__type_idx"][:7, :9])

@@ -62,3 +62,18 @@ def test_resize_plan_matches_scipy_zoom(ps):
         np.testing.assert_array_equal(ref[2 * radius:3 * radius + 1], taps)
     else:
         assert taps is None and radius == 0
+
+
+def test_palette_and_confidence_colours_match_reference(golden_dir):
+    """colors.get_colors / confidence_colors (host tables of the label painting) vs the reference's utils.get_colors / number_to_rgb."""
+    import os
+    import numpy as np
+    from multiplexed_image_annotator_amd import colors
+    g = np.load(os.path.join(golden_dir, "colorize.npz"))
+    for n in (1, 2, 6, 17, 18, 19, 30):
+        assert np.array_equal(np.array(colors.get_colors(n)), g[f"colors_{n}"])
+    v = g["viridis_in"]
+    got = colors.confidence_colors(v)
+    exp = g["viridis_rgb"].copy()
+    exp[~(v > 0)] = (192, 192, 192)                     # colorize paints non-positive confidences silver (model.py:831)
+    assert np.array_equal(got.astype(np.int64), exp)

@@ -98,3 +98,22 @@ def test_vote_tie_break_order(vote_cases):
     assert meta["b2_full_struct__default"]["labels"][1] == "CD4 T cell"
     # row 0, two models: all struct classes tie at 1/6 > 1/12 -> first struct key in vote order
     assert meta["b2_full_struct__default"]["labels"][0] == "Stroma cell"
+
+
+def test_colorize_oracle_matches_reference(golden_dir):
+    """oracle.ref_colorize vs the reference's own Annotator.colorize / get_colors / number_to_rgb (tests/golden/colorize.npz)."""
+    import json
+    from oracle import ref_colorize, ref_preprocess
+    from multiplexed_image_annotator_amd import synth
+    g = np.load(os.path.join(golden_dir, "colorize.npz"))
+    for n in (1, 2, 6, 17, 18, 19, 30):
+        assert np.array_equal(np.array(ref_colorize.get_colors(n)), g[f"colors_{n}"])
+    assert np.array_equal(ref_colorize.viridis_rgb(g["viridis_in"]), g["viridis_rgb"])
+    meta = json.load(open(os.path.join(golden_dir, "e2e.json")))
+    arrs = np.load(os.path.join(golden_dir, "e2e.npz"))
+    for cname, m in meta.items():
+        mask, _ = synth.make_mask_and_image(m["h"], m["w"], m["cells"], len(m["markers"]), m["seed"], want_image=False)
+        mask = mask.numpy().astype(np.int32)
+        ids, _ = ref_preprocess.cell_table(mask)
+        t, c, i = ref_colorize.colorize(mask, ids.tolist(), m["labels"], arrs[cname + "__conf"].tolist(), m["cell_types"])
+        assert np.array_equal(t, g[cname + "__type_rgb"]) and np.array_equal(c, g[cname + "__conf_rgb"]) and np.array_equal(i, g[cname + "__type_idx"])
