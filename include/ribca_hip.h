@@ -138,6 +138,14 @@ int ribca_colorize(const int32_t* mask, int64_t n_pixels, const int32_t* label_t
                    const uint8_t* cell_conf_rgb, const uint8_t* cell_type_idx, uint8_t* out_type_rgb, uint8_t* out_conf_rgb,
                    uint8_t* out_type_idx, void* stream);
 
+/* ---- neighbourhood analysis (spatial_methods.neighborhood_analysis, spatial_methods.py:13-130) ------------------------
+ * x, y (n_cells) fp64 cell centroids (mean column, mean row), cell_type (n_cells) int32 in [0, n_types).  For every cell the
+ * n_neighbors nearest cells in fp64 (itself first; ties towards the lower index -- the reference's ball tree leaves ties
+ * unspecified) and matrix[type(cell)][type(neighbour)] += 1 for the other n_neighbors - 1.  matrix (n_types, n_types) uint64 is
+ * ACCUMULATED into (zero it first; call once per image for the integrated mode).  n_neighbors <= 32, n_types <= 32. */
+int ribca_knn_cooccurrence(const double* x, const double* y, const int32_t* cell_type, int32_t n_cells, int32_t n_neighbors, int32_t n_types,
+                           uint64_t* matrix, void* stream);
+
 /* ---- vote (Annotator.merge_by_voting, model.py:481-633) ------------------------------------------------------ */
 /* Global class ids: 0..16 = key order of utils.get_void_vote (utils.py:143-146), 17 = "Others".
  * p_a (n, k_a) and optional p_b (n, k_b) are softmax outputs; map_* (k) int8 give each class's global id;

@@ -344,9 +344,44 @@ class Annotator(object):
                     Image.fromarray(type_idx).save(os.path.join(gui_dir, "output_img.png"))
             Image.fromarray(conf_rgb).save(os.path.join(self.result_dir, f"{self.batch_id}_confidence_{i}.png"))
 
+    # ---- neighbourhood analysis (model.py:798-800 -> spatial_methods.py:13-130) -----------------------------------------
+    def _cell_type_ints(self, image_idx: int) -> np.ndarray:
+        types = {str(t): k for k, t in enumerate(self.cell_types)}
+        gid_to_type = np.array([types.get(name, 0) for name in ops.GLOBAL_NAMES], dtype=np.int64)
+        return gid_to_type[self.label_ids[image_idx]]
+
+    def neighborhood_matrix(self, image_indices, n_neighbors=25) -> np.ndarray:
+        """Counts of (cell type, neighbour cell type) over every cell's n_neighbors - 1 nearest other cells, summed over the images."""
+        t = len(self.cell_types)
+        acc = None
+        for i in image_indices:
+            tab = self.preprocessor.cell_tables[i]
+            x = tab[:, 5].astype(np.float64) / tab[:, 6].astype(np.float64)      # np.mean(Column), np.mean(Row) of the reference
+            y = tab[:, 4].astype(np.float64) / tab[:, 6].astype(np.float64)
+            acc = ops.knn_cooccurrence(x, y, self._cell_type_ints(i), t, n_neighbors, out=acc)
+        return acc.cpu().numpy().astype(np.float64)
+
+    def neighborhood_analysis(self, n_neighbors=25, integrate=True, normalize=True):
+        """Writes the same CSVs as the reference (``{batch_id}_integrated_neighborhood.csv`` or one ``{batch_id}_neighborhood_{i}.csv``
+        per image); the seaborn heat-map PNGs are not drawn."""
+        if len(self.annotations) == 0:
+            raise ValueError("No annotations")
+        groups = [list(range(self._n_images))] if integrate else [[i] for i in range(self._n_images)]
+        for g, idx in enumerate(groups):
+            m = self.neighborhood_matrix(idx, n_neighbors)
+            if normalize:
+                sums = m.sum(axis=1, keepdims=True)
+                m = np.divide(m, sums, out=m.copy(), where=sums > 0)
+            name = f"{self.batch_id}_integrated_neighborhood.csv" if integrate else f"{self.batch_id}_neighborhood_{g}.csv"
+            if self.rank == 0:
+                with open(os.path.join(self.result_dir, name), "w") as f:
+                    f.write("cell_type," + "".join(f"{c}," for c in self.cell_types) + "\n")
+                    for r, c in enumerate(self.cell_types):
+                        f.write(f"{c}," + "".join(f"{m[r][j]:.3f}," for j in range(len(self.cell_types))) + "\n")
+
     # ---- outside the accelerated path ------------------------------------------------------------------------------
     def _out_of_scope(self, *_a, **_k):
-        raise NotImplementedError("post-analysis / plotting of the reference (heatmaps, UMAP, neighbourhood, tissue regions) is CPU "
+        raise NotImplementedError("post-analysis / plotting of the reference (heatmaps, UMAP, tissue regions) is CPU "
                                   "work downstream of the CSV and outside this accelerated hot path")
 
-    generate_heatmap = umap_visualization = neighborhood_analysis = tissue_region_analysis = cell_type_composition = _out_of_scope
+    generate_heatmap = umap_visualization = tissue_region_analysis = cell_type_composition = _out_of_scope

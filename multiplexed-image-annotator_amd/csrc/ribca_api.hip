@@ -587,6 +587,17 @@ int ribca_colorize(const int32_t* mask, int64_t n_pixels, const int32_t* label_t
   return 0;
 }
 
+int ribca_knn_cooccurrence(const double* x, const double* y, const int32_t* cell_type, int32_t n_cells, int32_t n_neighbors, int32_t n_types,
+                           uint64_t* matrix, void* stream) {
+  if (!x || !y || !cell_type || !matrix) return fail("ribca_knn_cooccurrence: NULL buffer");
+  if (n_cells <= 0) return fail("ribca_knn_cooccurrence: no cells");
+  if (n_neighbors > n_cells) return fail("ribca_knn_cooccurrence: n_neighbors exceeds the number of cells");
+  if (launch_knn_cooccurrence(x, y, cell_type, n_cells, n_neighbors, n_types, reinterpret_cast<unsigned long long*>(matrix), (hipStream_t)stream))
+    return fail("ribca_knn_cooccurrence: n_neighbors must be in [1, 32] and n_types in [1, 32]");
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------- normalisation primitives
 int ribca_u16_to_f32(const uint16_t* in, float* out, int64_t n, void* stream) {
   if (n > 0 && (!in || !out)) return fail("ribca_u16_to_f32: NULL buffer");

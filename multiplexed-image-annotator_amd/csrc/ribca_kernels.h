@@ -87,6 +87,10 @@ int launch_extract_patches_scaled(const PatchArgs& a, int ps, const double* aa_t
 void launch_colorize(const int32_t* mask, long long npx, const int32_t* label_to_cell, int L, const uint8_t* type_rgb, const uint8_t* conf_rgb,
                      const uint8_t* type_idx, uint8_t* out_type, uint8_t* out_conf, uint8_t* out_idx, hipStream_t s);
 
+// ----- k nearest neighbours + cell-type co-occurrence (knn.hip); non-zero return = unsupported k / T
+int launch_knn_cooccurrence(const double* x, const double* y, const int32_t* type, int n, int k, int T, unsigned long long* matrix,
+                            hipStream_t s);
+
 // ----- whole-image normalisation (normalize.hip) ---------------------------------------------------------------
 void launch_u16_to_f32(const uint16_t* in, float* out, long long n, hipStream_t s);
 void launch_gauss1d(const float* in, float* out, int planes, int H, int W, int axis, const double* w, int R, int mode, hipStream_t s);

@@ -194,6 +194,24 @@ def colorize(mask: torch.Tensor, ids: np.ndarray, type_rgb: np.ndarray, conf_rgb
     return out_t, out_c, out_i
 
 
+def knn_cooccurrence(x: np.ndarray, y: np.ndarray, cell_type: np.ndarray, n_types: int, n_neighbors: int, out: Optional[torch.Tensor] = None,
+                     device=None) -> torch.Tensor:
+    """(n_types, n_types) int64 device tensor of (cell, neighbour) type pairs over each cell's n_neighbors - 1 nearest other cells
+    (reference spatial_methods.neighborhood_analysis); accumulates into ``out`` when given."""
+    dev = device or _lib.require_gpu()
+    n = len(x)
+    if n_neighbors > n:      # what scikit-learn's kneighbors raises inside the reference
+        raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {n_neighbors}, n_samples_fit = {n}")
+    xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(dev)
+    yd = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float64)).to(dev)
+    td = torch.from_numpy(np.ascontiguousarray(cell_type, dtype=np.int32)).to(dev)
+    if out is None:
+        out = torch.zeros((n_types, n_types), dtype=torch.int64, device=dev)
+    check(lib().ribca_knn_cooccurrence(ptr(xd), ptr(yd), ptr(td), n, int(n_neighbors), int(n_types), ptr(out), stream_ptr()),
+          "ribca_knn_cooccurrence")
+    return out
+
+
 # ------------------------------------------------------------------------------------------- whole-image normalisation
 def _gauss_weights(sigma: float) -> np.ndarray:
     """Taps at distance 0..R of scipy.ndimage.gaussian_filter(sigma, truncate=4.0), computed as scipy computes them."""

@@ -65,7 +65,7 @@ def install_shims():
     sk.filters = mod("skimage.filters", gaussian=skimage_like.gaussian)
     sk.transform = mod("skimage.transform", resize=skimage_like.resize)
     mod("tifffile", imwrite=lambda *a, **k: None)
-    mod("seaborn")
+    mod("seaborn", heatmap=lambda *a, **k: None)
     mod("umap")
     tm = mod("timm")
     tm.models = mod("timm.models")
@@ -565,6 +565,51 @@ def golden_colorize():
     print("colorize.npz", {k: v.shape for k, v in out.items()})
 
 
+# ---------------------------------------------------------------------------------------------- kNN neighbourhood
+def golden_neighborhood():
+    """spatial_methods.neighborhood_analysis (spatial_methods.py:13-130) on annotations_all rebuilt from the e2e goldens + one larger
+    synthetic tile with hashed cell types: the CSV text for per-image and integrated modes."""
+    sp = ref("spatial_methods")
+    pre = ref("preprocess")
+    meta = json.load(open(os.path.join(HERE, "e2e.json")))
+    dummy = object.__new__(pre.ImageProcessor)
+    ann_all, names = [], None
+    cases = {}
+    for cname in ("basic", "two_model"):
+        m = meta[cname]
+        mask, _ = synth.make_mask_and_image(m["h"], m["w"], m["cells"], len(m["markers"]), m["seed"], want_image=False)
+        d = pre.ImageProcessor._cell_pos_dict(dummy, mask.numpy().astype(np.int32), n_jobs=0)
+        cases[cname] = ([{"Cell ID": k, "Cell type": t, "Confidence": 0.5, "Row": d[k][0], "Column": d[k][1]} for k, t in zip(d.keys(), m["type_ints"])],
+                        m["cell_types"])
+    # a larger tile: 1500 cells, 6 types assigned by a hash of the label
+    mask, _ = synth.make_mask_and_image(640, 700, 1500, 1, synth.SEED_BASE + 151, want_image=False)
+    d = pre.ImageProcessor._cell_pos_dict(dummy, mask.numpy().astype(np.int32), n_jobs=0)
+    keys = list(d.keys())
+    types = (synth.hash_u24(synth.stream_key(synth.SEED_BASE + 151, "nbr"), torch.tensor(keys, dtype=torch.int64)) % 6).tolist()
+    cases["big"] = ([{"Cell ID": k, "Cell type": int(t), "Confidence": 0.5, "Row": d[k][0], "Column": d[k][1]} for k, t in zip(keys, types)],
+                    ["A", "B", "C", "D", "E", "Others"])
+    out = {"big_types": types, "big_ids": [int(k) for k in keys]}
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)
+    for cname, (ann, ctypes) in cases.items():
+        for nn in (10, 25):
+            sp.neighborhood_analysis([ann], n_neighbors=nn, cell_types=np.array(ctypes), integrate=False, normalize=True, batch_id=f"{cname}{nn}",
+                                     result_dir=".")
+            out[f"{cname}__k{nn}"] = open(f"{cname}{nn}_neighborhood_0.csv").read()
+    ann2 = [cases["big"][0], cases["big"][0][:700]]
+    sp.neighborhood_analysis(ann2, n_neighbors=25, cell_types=np.array(cases["big"][1]), integrate=True, normalize=True, batch_id="int", result_dir=".")
+    out["big_integrated_k25"] = open("int_integrated_neighborhood.csv").read()
+    sp.neighborhood_analysis([cases["big"][0]], n_neighbors=10, cell_types=np.array(cases["big"][1]), integrate=False, normalize=False, batch_id="raw",
+                             result_dir=".")
+    out["big_raw_k10"] = open("raw_neighborhood_0.csv").read()
+    os.chdir(cwd)
+    shutil.rmtree(tmp)
+    with open(os.path.join(HERE, "neighborhood.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("neighborhood.json", {k: len(v) for k, v in out.items()})
+
+
 # ---------------------------------------------------------------------------------------------- G6
 def mae_inputs(panel, n, seed):
     L = synth.MAE_PANELS[panel]
@@ -607,6 +652,6 @@ def golden_mae():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["normalize", "cellpos", "patches", "patches_scaled", "parser", "vote", "vit", "e2e", "mae", "colorize"]
+    which = sys.argv[1:] or ["normalize", "cellpos", "patches", "patches_scaled", "parser", "vote", "vit", "e2e", "mae", "colorize", "neighborhood"]
     for w in which:
         globals()["golden_" + w]()

@@ -69,6 +69,12 @@ def test_annotator_matches_reference_golden(golden_dir, tmp_path, name):
     cpng = np.array(Image.open(tmp_path / "results" / "g_confidence_0.png")).astype(np.int64)
     diff = np.abs(cpng - gc[f"{name}__conf_rgb"].astype(np.int64))
     assert (diff.max(axis=2) > 0).mean() < 0.02 and diff.max() <= 6
+    # neighbourhood analysis (reference spatial_methods.neighborhood_analysis through Annotator.neighborhood_analysis)
+    gn = json.load(open(os.path.join(golden_dir, "neighborhood.json")))
+    a.neighborhood_analysis(n_neighbors=10, integrate=False, normalize=True)
+    assert open(tmp_path / "results" / "g_neighborhood_0.csv").read() == gn[f"{name}__k10"]
+    a.neighborhood_analysis(n_neighbors=25, integrate=True, normalize=True)
+    assert open(tmp_path / "results" / "g_integrated_neighborhood.csv").read() == gn[f"{name}__k25"]
     csv_equal_up_to_conf(open(tmp_path / "results" / "g_annotation_0.csv").read(), meta["csv"], 1.5e-3)
     # pixel lists of the lazy cell_pos_dict agree with the mask
     key = meta["cell_ids"][3]

@@ -463,3 +463,24 @@ def test_colorize_golden(dev, golden_dir, name):
     t2, c2, i2 = ops.colorize(sub, ids, palette[tidx], colors.confidence_colors(conf), (tidx + 1).astype(np.uint8))
     np.testing.assert_array_equal(t2.cpu().numpy(), g[f"{name}__type_rgb"][:7, :9])
     np.testing.assert_array_equal(i2.cpu().numpy(), g[f"{name}__type_idx"][:7, :9])
+
+
+@pytest.mark.parametrize("cname", ["basic", "two_model", "big"])
+def test_knn_cooccurrence_golden(dev, golden_dir, cname):
+    """ribca_knn_cooccurrence vs the CSVs the reference's neighborhood_analysis wrote (scikit-learn ball tree, spatial_methods.py:13-130)."""
+    from oracle import ref_spatial
+    from test_oracle_host_logic import _neighborhood_inputs
+    ops = _ops()
+    g, x, y, types, names = _neighborhood_inputs(golden_dir, cname)
+    for k in (10, 25):
+        m = ops.knn_cooccurrence(x, y, types, len(names), k).cpu().numpy().astype(np.float64)
+        assert ref_spatial.csv_text(ref_spatial.normalize_rows(m), names) == g[f"{cname}__k{k}"]
+        assert m.sum() == len(x) * (k - 1)
+    if cname == "big":
+        raw = ops.knn_cooccurrence(x, y, types, len(names), 10).cpu().numpy().astype(np.float64)
+        assert ref_spatial.csv_text(raw, names) == g["big_raw_k10"]
+        acc = ops.knn_cooccurrence(x, y, types, len(names), 25)
+        acc = ops.knn_cooccurrence(x[:700], y[:700], types[:700], len(names), 25, out=acc)
+        assert ref_spatial.csv_text(ref_spatial.normalize_rows(acc.cpu().numpy().astype(np.float64)), names) == g["big_integrated_k25"]
+        with pytest.raises(ValueError):
+            ops.knn_cooccurrence(x[:5], y[:5], types[:5], len(names), 10)

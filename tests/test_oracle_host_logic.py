@@ -117,3 +117,34 @@ def test_colorize_oracle_matches_reference(golden_dir):
         ids, _ = ref_preprocess.cell_table(mask)
         t, c, i = ref_colorize.colorize(mask, ids.tolist(), m["labels"], arrs[cname + "__conf"].tolist(), m["cell_types"])
         assert np.array_equal(t, g[cname + "__type_rgb"]) and np.array_equal(c, g[cname + "__conf_rgb"]) and np.array_equal(i, g[cname + "__type_idx"])
+
+
+def _neighborhood_inputs(golden_dir, cname):
+    from oracle import ref_preprocess, ref_spatial
+    from multiplexed_image_annotator_amd import synth
+    g = json.load(open(os.path.join(golden_dir, "neighborhood.json")))
+    if cname == "big":
+        mask, _ = synth.make_mask_and_image(640, 700, 1500, 1, synth.SEED_BASE + 151, want_image=False)
+        types, names = np.array(g["big_types"]), ["A", "B", "C", "D", "E", "Others"]
+    else:
+        m = json.load(open(os.path.join(golden_dir, "e2e.json")))[cname]
+        mask, _ = synth.make_mask_and_image(m["h"], m["w"], m["cells"], len(m["markers"]), m["seed"], want_image=False)
+        types, names = np.array(m["type_ints"]), m["cell_types"]
+    ids, table = ref_preprocess.cell_table(mask.numpy().astype(np.int32))
+    x, y = ref_spatial.centroids(table)
+    return g, x, y, types, names
+
+
+@pytest.mark.parametrize("cname", ["basic", "two_model", "big"])
+def test_neighborhood_oracle_matches_reference(golden_dir, cname):
+    """oracle.ref_spatial vs the CSVs written by the reference's neighborhood_analysis (scikit-learn ball tree)."""
+    from oracle import ref_spatial
+    g, x, y, types, names = _neighborhood_inputs(golden_dir, cname)
+    for k in (10, 25):
+        m = ref_spatial.normalize_rows(ref_spatial.cooccurrence(x, y, types, len(names), k))
+        assert ref_spatial.csv_text(m, names) == g[f"{cname}__k{k}"]
+    if cname == "big":
+        raw = ref_spatial.cooccurrence(x, y, types, len(names), 10)
+        assert ref_spatial.csv_text(raw, names) == g["big_raw_k10"]
+        both = ref_spatial.cooccurrence(x, y, types, len(names), 25) + ref_spatial.cooccurrence(x[:700], y[:700], types[:700], len(names), 25)
+        assert ref_spatial.csv_text(ref_spatial.normalize_rows(both), names) == g["big_integrated_k25"]
