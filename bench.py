@@ -43,10 +43,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("RIBCA_DIST_BACKEND", "nccl")     # "gloo" + RIBCA_SHARE_GPU=1: rehearsal of the N > 1 path on a 1-GPU box
     if world > 1:
         import torch.distributed as tdist
+        if os.environ.get("RIBCA_SHARE_GPU") == "1":
+            local_rank %= max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        tdist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            tdist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            tdist.init_process_group(backend)
     import __graft_entry__
     if rank == 0:
         __graft_entry__.build()
@@ -99,6 +105,7 @@ def main():
         return n, lab.cpu(), conf.cpu()
 
     def sync_all():
+        torch.cuda.synchronize()
         if world > 1:
             tdist.barrier()
         torch.cuda.synchronize()
@@ -120,7 +127,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3

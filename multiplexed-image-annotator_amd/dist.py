@@ -33,6 +33,8 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tens
     if ws == 1:
         assert local.shape[0] == n_total
         return local
+    if local.is_cuda and dist.get_backend(group) == "gloo":     # rehearsal / CPU-collective runs: stage through host memory
+        return all_gather_rows(local.cpu(), n_total, group).to(local.device)
     k = local.shape[1:]
     cap = max(shard_bounds(n_total, r, ws)[1] - shard_bounds(n_total, r, ws)[0] for r in range(ws))
     send = torch.zeros((cap,) + tuple(k), dtype=local.dtype, device=local.device)
