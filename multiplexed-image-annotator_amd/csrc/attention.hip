@@ -3,8 +3,10 @@
 //
 // One wave owns one (cell, head).  There is no LDS and no barrier: every MFMA operand is loaded straight from HBM/L2
 // into the lane that needs it, because the producer (the qkv GEMM epilogue) already wrote Q, K and V^T in fragment order:
-//   Q, K : [cell][head][112 tokens][2*hdp] packed-split rows  -> a 16-token tile is one contiguous 16*4*hdp-byte block and
-//          lane (r = lane&15, g = lane>>4) reads 32 contiguous bytes (hi|lo of k-group g) of row r: fully coalesced.
+//   Q, K : [cell][head][112 tokens][2*hdq] packed-split rows, hdq = round8(hd) (no padding to the MFMA K of 32: a 16-token
+//          tile is one contiguous 16*4*hdq-byte block; lane (r = lane&15, g = lane>>4) reads the 32 contiguous bytes (hi|lo)
+//          of k-group 4*ks+g of row r, or uses zeros when that group is beyond hdq -- hd = 24 moves 96 instead of 128 bytes
+//          per row, hd = 48 192 instead of 256, hd = 12 64 instead of 128).
 //   V^T  : [cell][head][hdv][2*128 keys], keys permuted so that the 8 keys lane-group g holds after K*Q^T are contiguous.
 //
 // Per 16-query tile:  S^T = K * Q^T (keys on MFMA rows, queries on lanes) -> each lane holds, for ITS query, keys
@@ -18,10 +20,14 @@
 
 namespace ribca {
 
-template <int KS /* hdp/32 */, int DT /* hdv/16 */, int NT /* 16-token tiles: 7 for the 101-token classifiers, 1 for the imputer */>
+template <int HD /* head dim */, int NT /* 16-token tiles: 7 for the 101-token classifiers, 1 for the imputer */>
 __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K,
                                                         const uint16_t* __restrict__ Vt, uint16_t* __restrict__ out, int ldo,
-                                                        int n_pairs, int hd, int H, int T, int q_tiles) {
+                                                        int n_pairs, int H, int T, int q_tiles) {
+  constexpr int KS = (HD + 31) / 32;        // MFMA K steps of the Q K^T product
+  constexpr int DT = (HD + 15) / 16;        // 16-row tiles of V^T
+  constexpr int hd = HD;
+  constexpr int hdq = (HD + 7) / 8 * 8;
   const int lane = threadIdx.x & 63;
   const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);  // (cell, head) index, wave-uniform
   if (pair >= n_pairs) return;
@@ -29,7 +35,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
   const int r16 = lane & 15, g = lane >> 4;
   constexpr int KST = (NT + 1) / 2;         // 32-key steps of the P*V product
   constexpr int TP = 16 * NT;
-  constexpr int ROW = 2 * KS * 32;          // bf16 per Q/K row
+  constexpr int ROW = 2 * hdq;              // bf16 per Q/K row
+  constexpr int ngrp = hdq >> 3;            // stored k-groups per row
   constexpr int VROW = 2 * 32 * KST;        // bf16 per V^T row
   const uint16_t* qb = Q + (size_t)pair * TP * ROW;
   const uint16_t* kb = K + (size_t)pair * TP * ROW;
@@ -41,18 +48,26 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
   for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const uint4* p = reinterpret_cast<const uint4*>(kb + (size_t)(kt * 16 + r16) * ROW + ks * 64 + g * 16);
-      khi[kt][ks] = __builtin_bit_cast(bf16x8, p[0]);
-      klo[kt][ks] = __builtin_bit_cast(bf16x8, p[1]);
+      uint4 h4 = {0u, 0u, 0u, 0u}, l4 = {0u, 0u, 0u, 0u};
+      if (ks * 4 + 3 < ngrp || ks * 4 + g < ngrp) {
+        const uint4* p = reinterpret_cast<const uint4*>(kb + (size_t)(kt * 16 + r16) * ROW + (ks * 4 + g) * 16);
+        h4 = p[0]; l4 = p[1];
+      }
+      khi[kt][ks] = __builtin_bit_cast(bf16x8, h4);
+      klo[kt][ks] = __builtin_bit_cast(bf16x8, l4);
     }
 
   for (int qt = 0; qt < q_tiles; ++qt) {
     bf16x8 qhi[KS], qlo[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const uint4* p = reinterpret_cast<const uint4*>(qb + (size_t)(qt * 16 + r16) * ROW + ks * 64 + g * 16);
-      qhi[ks] = __builtin_bit_cast(bf16x8, p[0]);
-      qlo[ks] = __builtin_bit_cast(bf16x8, p[1]);
+      uint4 h4 = {0u, 0u, 0u, 0u}, l4 = {0u, 0u, 0u, 0u};
+      if (ks * 4 + 3 < ngrp || ks * 4 + g < ngrp) {
+        const uint4* p = reinterpret_cast<const uint4*>(qb + (size_t)(qt * 16 + r16) * ROW + (ks * 4 + g) * 16);
+        h4 = p[0]; l4 = p[1];
+      }
+      qhi[ks] = __builtin_bit_cast(bf16x8, h4);
+      qlo[ks] = __builtin_bit_cast(bf16x8, l4);
     }
     f32x4 s[2 * KST];
 #pragma unroll
@@ -109,9 +124,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
       f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int t = 0; t < KST; ++t) {
-        const uint4* p = reinterpret_cast<const uint4*>(vb + (size_t)(dt * 16 + r16) * VROW + (4 * t + g) * 16);
-        const bf16x8 vhi = __builtin_bit_cast(bf16x8, p[0]);
-        const bf16x8 vlo = __builtin_bit_cast(bf16x8, p[1]);
+        uint4 h4 = {0u, 0u, 0u, 0u}, l4 = {0u, 0u, 0u, 0u};
+        if (dt * 16 + 15 < hd || dt * 16 + r16 < hd) {   // V^T rows beyond the head dim are padding: never read
+          const uint4* p = reinterpret_cast<const uint4*>(vb + (size_t)(dt * 16 + r16) * VROW + (4 * t + g) * 16);
+          h4 = p[0]; l4 = p[1];
+        }
+        const bf16x8 vhi = __builtin_bit_cast(bf16x8, h4);
+        const bf16x8 vlo = __builtin_bit_cast(bf16x8, l4);
         o = mfma_bf16(vlo, phi[t], o);
         o = mfma_bf16(vhi, plo[t], o);
         o = mfma_bf16(vhi, phi[t], o);
@@ -129,6 +148,7 @@ AttnGeom make_attn_geom(int D, int H, int T) {
   AttnGeom a;
   a.D = D; a.H = H; a.hd = D / H; a.T = T;
   a.hdp = (a.hd + 31) / 32 * 32;
+  a.hdq = (a.hd + 7) / 8 * 8;
   a.hdv = (a.hd + 15) / 16 * 16;
   a.NT = (T + 15) / 16;
   a.TP = 16 * a.NT;
@@ -142,21 +162,19 @@ void launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, 
   const int pairs = cells * a.H;
   if (pairs <= 0) return;
   const dim3 grid((pairs + 3) / 4), block(256);
-  const int ks = a.hdp / 32, dt = a.hdv / 16;
-#define RIBCA_ATT(KS_, DT_, NT_) \
-  hipLaunchKernelGGL((attention_kernel<KS_, DT_, NT_>), grid, block, 0, s, q, k, vt, out, ldo, pairs, a.hd, a.H, a.T, q_tiles)
-  if (a.NT == 7 && ks == 1 && dt == 1) RIBCA_ATT(1, 1, 7);
-  else if (a.NT == 7 && ks == 1 && dt == 2) RIBCA_ATT(1, 2, 7);
-  else if (a.NT == 7 && ks == 2 && dt == 3) RIBCA_ATT(2, 3, 7);
-  else if (a.NT == 1 && ks == 2 && dt == 4) RIBCA_ATT(2, 4, 1);
-  else if (a.NT == 1 && ks == 1 && dt == 2) RIBCA_ATT(1, 2, 1);
+#define RIBCA_ATT(HD_, NT_) \
+  hipLaunchKernelGGL((attention_kernel<HD_, NT_>), grid, block, 0, s, q, k, vt, out, ldo, pairs, a.H, a.T, q_tiles)
+  if (a.NT == 7 && a.hd == 12) RIBCA_ATT(12, 7);
+  else if (a.NT == 7 && a.hd == 24) RIBCA_ATT(24, 7);
+  else if (a.NT == 7 && a.hd == 32) RIBCA_ATT(32, 7);
+  else if (a.NT == 7 && a.hd == 48) RIBCA_ATT(48, 7);
+  else if (a.NT == 1 && a.hd == 64) RIBCA_ATT(64, 1);
   else abort();   // geometry is validated by the C ABI before any launch
 #undef RIBCA_ATT
 }
 
 bool attention_supported(const AttnGeom& a) {
-  const int ks = a.hdp / 32, dt = a.hdv / 16;
-  return (a.NT == 7 && ((ks == 1 && (dt == 1 || dt == 2)) || (ks == 2 && dt == 3))) || (a.NT == 1 && ((ks == 2 && dt == 4) || (ks == 1 && dt == 2)));
+  return (a.NT == 7 && (a.hd == 12 || a.hd == 24 || a.hd == 32 || a.hd == 48)) || (a.NT == 1 && a.hd == 64);
 }
 
 }  // namespace ribca

@@ -104,7 +104,7 @@ struct EpiEmbed {
 };
 
 struct EpiQKV {
-  uint16_t* q; uint16_t* k; uint16_t* vt; const float* bias; int D, hd, hdp, hdv; float scale; int M, N;
+  uint16_t* q; uint16_t* k; uint16_t* vt; const float* bias; int D, hd, hdp /* stored dims per Q/K row = AttnGeom::hdq */, hdv; float scale; int M, N;
   int T, TP, H, KP;   // tokens per cell, padded token rows of Q/K, heads, padded keys per V^T row
   struct Ctx {};
   // row / column decompositions are computed once per accumulator row (4) and column group (TN), not once per tile
@@ -577,7 +577,7 @@ void launch_gemm_embed(const GemmArgs& g, float* z, int ldz, const float* pos, i
   launch_any(g, EpiEmbed{z, ldz, g.bias, pos, D, g.M, g.N}, s);
 }
 void launch_gemm_qkv(const GemmArgs& g, uint16_t* q, uint16_t* k, uint16_t* vt, const AttnGeom& a, float scale, hipStream_t s) {
-  launch_any(g, EpiQKV{q, k, vt, g.bias, a.D, a.hd, a.hdp, a.hdv, scale, g.M, g.N, a.T, a.TP, a.H, a.KP}, s);
+  launch_any(g, EpiQKV{q, k, vt, g.bias, a.D, a.hd, a.hdq /* Q/K row pitch: compact */, a.hdv, scale, g.M, g.N, a.T, a.TP, a.H, a.KP}, s);
 }
 void launch_gemm_rowmap(const GemmArgs& g, float* out, int ldo, const float* add, int ldadd, const int* slot, const int* addrow, int R,
                         int dst_per_cell, hipStream_t s) {

@@ -195,7 +195,7 @@ BlockWs carve_blocks(Carver& c, int cells, const AttnGeom& a) {
   w.z = c.take<float>(Mc * a.D);
   w.xa_bytes = Mc * 2 * Dp * sizeof(uint16_t);
   w.xa = c.take<uint16_t>(Mc * 2 * Dp);
-  const size_t qk = (size_t)cells * a.H * a.TP * 2 * a.hdp;
+  const size_t qk = (size_t)cells * a.H * a.TP * 2 * a.hdq;
   w.qk_bytes = qk * sizeof(uint16_t);
   w.q = c.take<uint16_t>(qk);
   w.k = c.take<uint16_t>(qk);

@@ -24,10 +24,11 @@ void launch_gemm_resid(const GemmArgs& g, float* z, int ldz, hipStream_t s);
 void launch_gemm_gelu(const GemmArgs& g, uint16_t* out, int ldo, hipStream_t s);
 // patch-embed: row m = cell*100 + t  ->  z[cell*101 + 1 + t][n] = acc + bias + pos[1+t][n]
 void launch_gemm_embed(const GemmArgs& g, float* z, int ldz, const float* pos, int D, hipStream_t s);
-// geometry of one attention problem: D = H*hd features, T tokens per cell; Q/K rows padded to TP = 16*NT tokens and hdp dims,
-// V^T rows = hdv head dims x KP keys (KP = 32*ceil(NT/2))
+// geometry of one attention problem: D = H*hd features, T tokens per cell; Q/K rows padded to TP = 16*NT tokens and STORED with
+// hdq = round8(hd) dims (compact: whole PS groups only); the MFMA K dimension is hdp = round32(hd), the groups beyond hdq are
+// zero registers, never memory.  V^T rows = hdv head dims x KP keys (KP = 32*ceil(NT/2)); rows >= hd are never read.
 struct AttnGeom {
-  int D, H, hd, hdp, hdv, T, NT, TP, KP;
+  int D, H, hd, hdp, hdv, T, NT, TP, KP, hdq;
 };
 AttnGeom make_attn_geom(int D, int H, int T);
 bool attention_supported(const AttnGeom& a);

@@ -117,7 +117,7 @@ def test_qkv_attention(dev, d, cells):
     from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
     heads, ntok = 12, 101
     hd = d // heads
-    hdp, hdv = (hd + 31) // 32 * 32, (hd + 15) // 16 * 16
+    hdp, hdv = (hd + 7) // 8 * 8, (hd + 15) // 16 * 16       # Q/K rows are stored compactly: whole PS groups of 8 dims only
     m = cells * ntok
     dp = (d + 31) // 32 * 32
     y = rnd((m, d), 12, dev)
