@@ -83,26 +83,6 @@ struct EpiGelu {
   }
 };
 
-struct EpiEmbed {
-  float* z; int ldz; const float* bias; const float* pos; int D; int M, N;
-  struct Ctx { float4 pe; };
-  __device__ __forceinline__ float4 fetch_bias(int n) const {
-    return n < N ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
-  }
-  __device__ __forceinline__ void fetch(int m, int n, Ctx& c) const {
-    const int cell = m / 100, t = m - cell * 100;
-    c.pe = (m < M && n < N) ? *reinterpret_cast<const float4*>(pos + (size_t)(1 + t) * D + n) : float4{0.f, 0.f, 0.f, 0.f};
-  }
-  template <int PX = 16>
-  __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx& c) const {
-    if (m >= M || n >= N) return;
-    const int cell = m / 100, t = m - cell * 100;
-    float4 o;
-    o.x = v[0] + b.x + c.pe.x; o.y = v[1] + b.y + c.pe.y; o.z = v[2] + b.z + c.pe.z; o.w = v[3] + b.w + c.pe.w;
-    *reinterpret_cast<float4*>(z + ((size_t)cell * kTokens + 1 + t) * ldz + n) = o;
-  }
-};
-
 struct EpiQKV {
   uint16_t* q; uint16_t* k; uint16_t* vt; const float* bias; int D, hd, hdp /* stored dims per Q/K row = AttnGeom::hdq */, hdv; float scale; int M, N;
   int T, TP, H, KP;   // tokens per cell, padded token rows of Q/K, heads, padded keys per V^T row
@@ -572,9 +552,6 @@ void launch_gemm_resid(const GemmArgs& g, float* z, int ldz, hipStream_t s) {
 }
 void launch_gemm_gelu(const GemmArgs& g, uint16_t* out, int ldo, hipStream_t s) {
   launch_any(g, EpiGelu{out, ldo, g.bias, g.M, g.N}, s);
-}
-void launch_gemm_embed(const GemmArgs& g, float* z, int ldz, const float* pos, int D, hipStream_t s) {
-  launch_any(g, EpiEmbed{z, ldz, g.bias, pos, D, g.M, g.N}, s);
 }
 void launch_gemm_qkv(const GemmArgs& g, uint16_t* q, uint16_t* k, uint16_t* vt, const AttnGeom& a, float scale, hipStream_t s) {
   launch_any(g, EpiQKV{q, k, vt, g.bias, a.D, a.hd, a.hdq /* Q/K row pitch: compact */, a.hdv, scale, g.M, g.N, a.T, a.TP, a.H, a.KP}, s);

@@ -22,8 +22,6 @@ struct GemmArgs {
 void launch_gemm_resid(const GemmArgs& g, float* z, int ldz, hipStream_t s);
 // out_ps[m][n] = gelu(acc + bias), packed-split          (mlp.fc1)
 void launch_gemm_gelu(const GemmArgs& g, uint16_t* out, int ldo, hipStream_t s);
-// patch-embed: row m = cell*100 + t  ->  z[cell*101 + 1 + t][n] = acc + bias + pos[1+t][n]
-void launch_gemm_embed(const GemmArgs& g, float* z, int ldz, const float* pos, int D, hipStream_t s);
 // geometry of one attention problem: D = H*hd features, T tokens per cell; Q/K rows padded to TP = 16*NT tokens and STORED with
 // hdq = round8(hd) dims (compact: whole PS groups only); the MFMA K dimension is hdp = round32(hd), the groups beyond hdq are
 // zero registers, never memory.  V^T rows = hdv head dims x KP keys (KP = 32*ceil(NT/2)); rows >= hd are never read.
@@ -47,8 +45,6 @@ void launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, 
 // ----- small ViT kernels (vit_misc.hip) ----------------------------------------------------------------------
 void launch_layernorm_ps(const float* z, int ldz, const float* gamma, const float* beta, uint16_t* out, int ldo, int M, int D,
                          hipStream_t s);
-void launch_im2col_ps(const float* patches, int c_img, const int* src_chan, int C, uint16_t* out, int ldo, int Kp, int cells,
-                      hipStream_t s);
 void launch_embed_f32(const float* patches, int c_img, const int* src_chan, int C, const float* w, const float* bias, const float* pos,
                       float* z, int ldz, int D, int cells, hipStream_t s);
 void launch_cls_rows(float* z, int ldz, const float* cls, const float* pos, int D, int cells, int tokens_per_cell, hipStream_t s);

@@ -1,4 +1,4 @@
-// Small HBM-bound kernels of the ViT forward: LayerNorm -> packed-split, im2col of the 4x4/4 patch-embed conv,
+// Small kernels of the ViT forward: LayerNorm -> packed-split, the fp32 patch-embed conv (im2col on the fly),
 // CLS rows, final LayerNorm + head + softmax, and the one-off weight packer.
 // Reference semantics: timm Block.norm1/norm2 and VisionTransformer.norm are nn.LayerNorm(eps=1e-6) (model.py:66-88);
 // patch embedding is Conv2d(C, D, 4, 4) with K order (c, ky, kx) and token order py*10+px; head + softmax at model.py:402-404.
@@ -55,41 +55,6 @@ void launch_layernorm_ps(const float* z, int ldz, const float* gamma, const floa
                          hipStream_t s) {
   if (M <= 0) return;
   hipLaunchKernelGGL(layernorm_ps_kernel, dim3((M + 3) / 4), dim3(256), 0, s, z, ldz, gamma, beta, out, ldo, M, D);
-}
-
-// im2col for Conv2d(C, D, k=4, s=4) on (cells, c_img, 40, 40) fp32 patches -> rows (cell*100 + py*10 + px) of Kp columns,
-// column k = c*16 + ky*4 + kx.  src_chan[c] = image channel feeding model channel c, or -1 for a blank (-1.0) plane
-// (reference preprocess.py:110-120).  Columns >= 16*C are zero.  One thread per 4 consecutive kx.
-__global__ __launch_bounds__(256) void im2col_ps_kernel(const float* __restrict__ patches, int c_img, const int* __restrict__ src_chan,
-                                                        int C, uint16_t* __restrict__ out, int ldo, int Kp, long long total) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int kq = Kp >> 2;
-  const long long rowi = idx / kq;
-  const int q = (int)(idx - rowi * kq);  // column group: k = 4q = c*16 + ky*4
-  const int c = q >> 2, ky = q & 3;
-  const long long cell = rowi / 100;
-  const int t = (int)(rowi - cell * 100);
-  const int py = t / 10, px = t - py * 10;
-  float v[4] = {0.f, 0.f, 0.f, 0.f};
-  if (c < C) {
-    const int sc = src_chan[c];
-    if (sc < 0) {
-      v[0] = v[1] = v[2] = v[3] = -1.0f;
-    } else {
-      const float4 p = *reinterpret_cast<const float4*>(patches + (((size_t)cell * c_img + sc) * 40 + (4 * py + ky)) * 40 + 4 * px);
-      v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w;
-    }
-  }
-  ps_store4(out + (size_t)rowi * ldo, 4 * q, v);
-}
-
-void launch_im2col_ps(const float* patches, int c_img, const int* src_chan, int C, uint16_t* out, int ldo, int Kp, int cells,
-                      hipStream_t s) {
-  const long long total = (long long)cells * 100 * (Kp >> 2);
-  if (total <= 0) return;
-  hipLaunchKernelGGL(im2col_ps_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, patches, c_img, src_chan, C, out, ldo, Kp,
-                     total);
 }
 
 // Patch embedding in plain fp32 (timm PatchEmbed: Conv2d(C, D, k=4, s=4), model.py:47):
