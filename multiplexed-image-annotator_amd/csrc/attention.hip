@@ -15,6 +15,8 @@
 // (k index = key, column = query) -- no cross-lane movement, no LDS round trip.  O^T tiles put 4 consecutive head
 // dims of one query in a lane: one 8-byte hi + one 8-byte lo store into the packed-split attention output.
 // All three products use the bf16x3 split (ribca_common.h).  Q is pre-scaled by hd^-0.5 by the producer.
+#include <cstdlib>
+
 #include "ribca_common.h"
 #include "ribca_kernels.h"
 
@@ -144,6 +146,162 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------- LDS-staged form (classifiers)
+// The kernel above is bound by its dependent chain (Q load -> MFMA -> softmax -> V^T loads from L2 -> MFMA -> store) at 1-3
+// waves/SIMD: K fragments of all 112 keys live in registers (114-296 VGPRs).  Here K and V^T of one (cell, head) are copied
+// ONCE into LDS (direct-to-LDS loads, 13-45 KB), WPP waves share them and split the query tiles (tile qt belongs to wave
+// qt % WPP), every fragment read is an LDS read of ~100 cycles, and the next query tile's Q fragments are prefetched while
+// the current tile is processed.  Same arithmetic, same operation order per query row as above -> identical results.
+template <int HD, int NT, int WPP>
+__global__ __launch_bounds__(64 * WPP) void attention_lds_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K,
+                                                                 const uint16_t* __restrict__ Vt, uint16_t* __restrict__ out, int ldo,
+                                                                 int H, int T, int q_tiles) {
+  constexpr int KS = (HD + 31) / 32;
+  constexpr int DT = (HD + 15) / 16;
+  constexpr int hd = HD;
+  constexpr int hdq = (HD + 7) / 8 * 8;
+  constexpr int KST = (NT + 1) / 2;
+  constexpr int TP = 16 * NT;
+  constexpr int ROW = 2 * hdq;                       // bf16 per Q/K row
+  constexpr int ngrp = hdq >> 3;
+  constexpr int VROW = 2 * 32 * KST;                 // bf16 per V^T row
+  constexpr int K_BYTES = TP * ROW * 2;
+  constexpr int V_BYTES = hd * VROW * 2;             // only the hd real rows
+  constexpr int K_LDS = (K_BYTES + 1023) / 1024 * 1024;
+  constexpr int V_LDS = (V_BYTES + 1023) / 1024 * 1024;
+  __shared__ __attribute__((aligned(16))) char lds[K_LDS + V_LDS];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.x;
+  const int cell = pair / H, head = pair - cell * H;
+  const int r16 = lane & 15, g = lane >> 4;
+  const uint16_t* qb = Q + (size_t)pair * TP * ROW;
+  const char* kb = reinterpret_cast<const char*>(K + (size_t)pair * TP * ROW);
+  const char* vb = reinterpret_cast<const char*>(Vt + (size_t)pair * (DT * 16) * VROW);
+
+  // ---- stage K and V^T: 1 KB per wave instruction, linear
+  for (int i = wave; i < K_LDS / 1024; i += WPP) {
+    int off = i * 1024 + lane * 16;
+    off = off < K_BYTES ? off : K_BYTES - 16;        // the tail instruction re-reads the last chunk into LDS padding
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + off),
+                                     (__attribute__((address_space(3))) void*)(lds + i * 1024), 16, 0, 0);
+  }
+  // V^T rows are 512 bytes = a whole number of bank rows: the 16 rows of a fragment read would all hit the same banks.  The
+  // copy is linear in LDS, so the XOR swizzle (32-byte hi|lo pair p of row r lives at pair p ^ (r & 15)) is applied to the
+  // global source address of each lane.
+  static_assert(VROW * 2 == 512, "V^T row pitch");
+  for (int i = wave; i < V_LDS / 1024; i += WPP) {
+    const int o = i * 1024 + lane * 16;
+    const int row = o >> 9, c = (o & 511) >> 4;
+    int off = row * 512 + ((((c >> 1) ^ (row & 15)) << 1) | (c & 1)) * 16;
+    off = o < V_BYTES ? off : V_BYTES - 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb + off),
+                                     (__attribute__((address_space(3))) void*)(lds + K_LDS + i * 1024), 16, 0, 0);
+  }
+  // first Q tile of this wave while the copies fly
+  auto load_q = [&](int qt, bf16x8 (&qh)[KS], bf16x8 (&ql)[KS]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      uint4 h4 = {0u, 0u, 0u, 0u}, l4 = {0u, 0u, 0u, 0u};
+      if (ks * 4 + 3 < ngrp || ks * 4 + g < ngrp) {
+        const uint4* p = reinterpret_cast<const uint4*>(qb + (size_t)(qt * 16 + r16) * ROW + (ks * 4 + g) * 16);
+        h4 = p[0]; l4 = p[1];
+      }
+      qh[ks] = __builtin_bit_cast(bf16x8, h4);
+      ql[ks] = __builtin_bit_cast(bf16x8, l4);
+    }
+  };
+  bf16x8 qhi[KS], qlo[KS], qhi_n[KS], qlo_n[KS];
+  if (wave < q_tiles) load_q(wave, qhi, qlo);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int qt = wave; qt < q_tiles; qt += WPP) {
+    if (qt + WPP < q_tiles) load_q(qt + WPP, qhi_n, qlo_n);
+    int opaque = 0;
+    asm volatile("" : "+v"(opaque));           // K / V^T fragments are re-read from LDS every tile, not hoisted into registers
+    const char* kl = lds + opaque;
+    const char* vl = lds + K_LDS + opaque;
+    f32x4 s[2 * KST];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        uint4 h4 = {0u, 0u, 0u, 0u}, l4 = {0u, 0u, 0u, 0u};
+        if (ks * 4 + 3 < ngrp || ks * 4 + g < ngrp) {
+          const uint4* p = reinterpret_cast<const uint4*>(kl + ((kt * 16 + r16) * ROW + (ks * 4 + g) * 16) * 2);
+          h4 = p[0]; l4 = p[1];
+        }
+        const bf16x8 kh = __builtin_bit_cast(bf16x8, h4), klo_ = __builtin_bit_cast(bf16x8, l4);
+        s[kt] = mfma_bf16(klo_, qhi[ks], s[kt]);
+        s[kt] = mfma_bf16(kh, qlo[ks], s[kt]);
+        s[kt] = mfma_bf16(kh, qhi[ks], s[kt]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (16 * (NT - 1) + 4 * g + r >= T) s[NT - 1][r] = -INFINITY;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(s[kt][r] - mx);
+        s[kt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (NT & 1) s[NT] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 phi[KST], plo[KST];
+#pragma unroll
+    for (int t = 0; t < KST; ++t) {
+      float pa[4], pb[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pa[r] = s[2 * t][r] * inv; pb[r] = s[2 * t + 1][r] * inv; }
+      uint2 ha, la, hb, lb;
+      split4(pa, ha, la);
+      split4(pb, hb, lb);
+      phi[t] = __builtin_bit_cast(bf16x8, uint4{ha.x, ha.y, hb.x, hb.y});
+      plo[t] = __builtin_bit_cast(bf16x8, uint4{la.x, la.y, lb.x, lb.y});
+    }
+    const int qtok = qt * 16 + r16;
+    uint16_t* orow = out + ((size_t)cell * T + qtok) * ldo;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < KST; ++t) {
+        uint4 h4 = {0u, 0u, 0u, 0u}, l4 = {0u, 0u, 0u, 0u};
+        if (dt * 16 + 15 < hd || dt * 16 + r16 < hd) {
+          const uint4* p = reinterpret_cast<const uint4*>(vl + (dt * 16 + r16) * (VROW * 2) + (((4 * t + g) ^ r16) << 5));   // row & 15 == r16
+          h4 = p[0]; l4 = p[1];
+        }
+        const bf16x8 vhi = __builtin_bit_cast(bf16x8, h4), vlo = __builtin_bit_cast(bf16x8, l4);
+        o = mfma_bf16(vlo, phi[t], o);
+        o = mfma_bf16(vhi, plo[t], o);
+        o = mfma_bf16(vhi, phi[t], o);
+      }
+      const int d = dt * 16 + 4 * g;
+      if (qtok < T && d < hd) {
+        float v[4] = {o[0], o[1], o[2], o[3]};
+        ps_store4(orow, head * hd + d, v);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { qhi[ks] = qhi_n[ks]; qlo[ks] = qlo_n[ks]; }
+  }
+}
+
 AttnGeom make_attn_geom(int D, int H, int T) {
   AttnGeom a;
   a.D = D; a.H = H; a.hd = D / H; a.T = T;
@@ -161,6 +319,17 @@ void launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, 
   if (q_tiles <= 0 || q_tiles > a.NT) q_tiles = a.NT;
   const int pairs = cells * a.H;
   if (pairs <= 0) return;
+  static const int lds_form = getenv("RIBCA_ATTN_REGS") ? 0 : 1;     // A/B switch: the register-resident form above
+  if (lds_form && a.NT == 7) {
+#define RIBCA_ATT_LDS(HD_, WPP_) \
+  hipLaunchKernelGGL((attention_lds_kernel<HD_, 7, WPP_>), dim3(pairs), dim3(64 * WPP_), 0, s, q, k, vt, out, ldo, a.H, a.T, q_tiles)
+    // 4 waves per (cell, head) measured 2 % faster than 2 (871.6 vs 887.6 ms per pass over the five classifiers)
+    if (a.hd == 12) { RIBCA_ATT_LDS(12, 4); return; }
+    if (a.hd == 24) { RIBCA_ATT_LDS(24, 4); return; }
+    if (a.hd == 32) { RIBCA_ATT_LDS(32, 4); return; }
+    if (a.hd == 48) { RIBCA_ATT_LDS(48, 4); return; }
+#undef RIBCA_ATT_LDS
+  }
   const dim3 grid((pairs + 3) / 4), block(256);
 #define RIBCA_ATT(HD_, NT_) \
   hipLaunchKernelGGL((attention_kernel<HD_, NT_>), grid, block, 0, s, q, k, vt, out, ldo, pairs, a.H, a.T, q_tiles)
