@@ -278,3 +278,53 @@ def test_two_images_one_run(tmp_path):
         total += ref_spatial.cooccurrence(x, y, both._cell_type_ints(k), len(both.cell_types), 10)
     got = open(tmp_path / "both" / "results" / "b_integrated_neighborhood.csv").read()
     assert got == ref_spatial.csv_text(total, [str(c) for c in both.cell_types])
+
+
+def _rank_worker(rank, world, port, root, seed):
+    """One rank of the sharded Annotator (both ranks share cuda:0 here; gloo carries the all-gather)."""
+    import torch.distributed as tdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    from multiplexed_image_annotator_amd.annotator import Annotator
+    sd = {m: synth.make_vit_state_dict(m, seed, depth=2) for m in ("immune_base", "struct")}
+    a = Annotator(os.path.join(root, "markers.txt"), os.path.join(root, "images.csv"), "cuda", os.path.join(root, "sharded"), "r", False, False, -1,
+                  True, 0.3, 99.8, 0.3, 30, None)
+    a.set_weights(sd)
+    a.preprocess()
+    a.predict(16)
+    a.export_annotations()
+    lo, hi = a.preprocessor.shards[0]
+    n = len(a.preprocessor.cell_ids[0])
+    assert (hi - lo) in (n // world, n // world + 1) and a.preprocessor.panel_patches(0).shape[0] == hi - lo   # only this rank's cells were cropped
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_two_ranks_match_single_rank(tmp_path):
+    """BASELINE config 4 in small: cells sharded over 2 ranks (one process each, both on this GPU; gloo instead of RCCL), all-gather
+    of the probability rows, rank 0 writes the CSV -- byte-identical to the single-rank run."""
+    import socket
+    import torch.multiprocessing as mp
+    from multiplexed_image_annotator_amd.annotator import Annotator
+    from multiplexed_image_annotator_amd.marker_parse import PANELS
+    seed = synth.SEED_BASE + 71
+    markers = ['CD45', 'CD20', 'CD4', 'CD8', 'DAPI', 'CD11c', 'CD3', 'aSMA', 'CD31', 'PanCK', 'Vimentin', 'Ki67']
+    mask, img = synth.make_mask_and_image(208, 240, 91, len(markers), seed)
+    write_case(tmp_path, img.numpy().astype(np.uint16), mask.numpy().astype(np.int32), markers)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.get_context("spawn")
+    mp.spawn(_rank_worker, args=(2, port, str(tmp_path), seed), nprocs=2, join=True)
+    sd = {m: synth.make_vit_state_dict(m, seed, depth=2) for m in ("immune_base", "struct")}
+    one = Annotator(str(tmp_path / "markers.txt"), str(tmp_path / "images.csv"), "cuda", str(tmp_path / "single"), "r", False, False, -1, True, 0.3, 99.8,
+                    0.3, 30, None)
+    one.set_weights(sd)
+    one.preprocess()
+    one.predict(16)
+    one.export_annotations()
+    a = open(tmp_path / "sharded" / "results" / "r_annotation_0.csv").read()
+    b = open(tmp_path / "single" / "results" / "r_annotation_0.csv").read()
+    assert a == b and len(a.splitlines()) == len(one.annotations[0]) + 1
