@@ -146,6 +146,13 @@ int ribca_colorize(const int32_t* mask, int64_t n_pixels, const int32_t* label_t
 int ribca_knn_cooccurrence(const double* x, const double* y, const int32_t* cell_type, int32_t n_cells, int32_t n_neighbors, int32_t n_types,
                            uint64_t* matrix, void* stream);
 
+/* Neighbourhood compositions of spatial_methods.tissue_region_partition (spatial_methods.py:133-180): sizes (DEVICE array, n_sizes <= 8,
+ * strictly increasing, max <= 255; the reference uses 10,20,30,50,75,100,150,200) -> counts (n_cells, n_sizes, n_types) uint16 =
+ * number of cells of each type among the nearest sizes[l] OTHER cells (fp64 distances, ties towards the lower index).  The
+ * reference divides each row by its sum and feeds PCA + KMeans on the host.  Synchronises the stream once (reads sizes). */
+int ribca_knn_compositions(const double* x, const double* y, const int32_t* cell_type, int32_t n_cells, int32_t n_types, const int32_t* sizes,
+                           int32_t n_sizes, uint16_t* counts, void* stream);
+
 /* ---- vote (Annotator.merge_by_voting, model.py:481-633) ------------------------------------------------------ */
 /* Global class ids: 0..16 = key order of utils.get_void_vote (utils.py:143-146), 17 = "Others".
  * p_a (n, k_a) and optional p_b (n, k_b) are softmax outputs; map_* (k) int8 give each class's global id;

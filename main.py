@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """CLI with the reference's argument surface (reference main.py:56-112) on the MI355X hot path.
 
-Runs marker parsing -> preprocess -> predict -> export_annotations -> neighborhood_analysis -> colorize, in the reference's
-order (main.py:19-28); its plotting / clustering steps (heat-maps, tissue regions, pie charts, legends) are CPU work
-downstream of the CSV and are not part of this accelerated path.  Multi-GPU: launch under ``python -m torch.distributed.run --nproc-per-node N main.py ...``.
+Runs marker parsing -> preprocess -> predict -> export_annotations -> tissue_region_analysis -> neighborhood_analysis ->
+colorize, as the reference does (main.py:19-28); its plotting steps (heat-maps, pie charts, legends) are CPU work downstream
+of the CSV and are not part of this accelerated path.  Multi-GPU: launch under ``python -m torch.distributed.run --nproc-per-node N main.py ...``.
 """
 import argparse
 import os
@@ -70,6 +70,9 @@ def run(args):
     a.predict(args.bs)
     a.export_annotations()
     n_cells = min((len(ids) for ids in a.preprocessor.cell_ids), default=0)
+    if args.n_regions > 0 and n_cells >= 201:      # the reference's 201-neighbour query raises on smaller images
+        a.tissue_region_analysis(args.n_regions)
+        a.export_annotations()                      # reference order is regions -> export; the CSV gains its Tissue Region column
     if n_cells >= 25:                              # the reference's kNN (25 neighbours) raises on smaller images
         a.neighborhood_analysis(integrate=True, normalize=True)
     a.colorize(from_script=True)

@@ -27,6 +27,7 @@ SIGNATURES = {
                                                c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ribca_colorize": (c_int32, [c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ribca_knn_cooccurrence": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "ribca_knn_compositions": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
     "ribca_u16_to_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "ribca_gauss1d": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
     "ribca_bg_subtract": (c_int32, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),

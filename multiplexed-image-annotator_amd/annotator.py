@@ -330,8 +330,6 @@ class Annotator(object):
             raise ValueError("No masks to colorize")
         if len(self.annotations) == 0:
             raise ValueError("No annotations to colorize")
-        if self.n_regions > 0:
-            raise NotImplementedError("tissue-region maps need tissue_region_analysis, which is outside the accelerated path")
         from PIL import Image
         for i in range(len(self.preprocessor.masks)):
             type_rgb, conf_rgb, type_idx = (t.cpu().numpy() for t in self.paint(i))
@@ -343,6 +341,15 @@ class Annotator(object):
                 if os.path.isdir(gui_dir):
                     Image.fromarray(type_idx).save(os.path.join(gui_dir, "output_img.png"))
             Image.fromarray(conf_rgb).save(os.path.join(self.result_dir, f"{self.batch_id}_confidence_{i}.png"))
+            if self.n_regions > 0:             # model.py:823-855: region colours from the same palette, silver last
+                pre = self.preprocessor
+                ids = pre.cell_ids[i]
+                region = np.array([self.tissue_regions[i][int(k)] for k in ids.tolist()], dtype=np.int64)
+                palette = np.array(colors.get_colors(self.n_regions + 1), dtype=np.uint8)
+                t_rgb, _, t_idx = ops.colorize(pre.masks_dev[i], ids, palette[region], palette[region], (region + 1).astype(np.uint8))
+                Image.fromarray(t_rgb.cpu().numpy()).save(os.path.join(self.result_dir, f"{self.batch_id}_tissue_region_{i}.png"))
+                if not from_script and os.path.isdir("./src/multiplexed_image_annotator/cell_type_annotation/_working_dir_temp"):
+                    Image.fromarray(t_idx.cpu().numpy()).save("./src/multiplexed_image_annotator/cell_type_annotation/_working_dir_temp/output_img_2.png")
 
     # ---- neighbourhood analysis (model.py:798-800 -> spatial_methods.py:13-130) -----------------------------------------
     def _cell_type_ints(self, image_idx: int) -> np.ndarray:
@@ -379,9 +386,36 @@ class Annotator(object):
                     for r, c in enumerate(self.cell_types):
                         f.write(f"{c}," + "".join(f"{m[r][j]:.3f}," for j in range(len(self.cell_types))) + "\n")
 
+    # ---- tissue regions (model.py:802-804 -> spatial_methods.py:133-198) -------------------------------------------------
+    def tissue_region_analysis(self, n, method="kmeans"):
+        """Per-cell region labels from the cell-type make-up of each cell's 10 ... 200 nearest neighbours.  The 201-NN search and
+        the counting run on the GPU (ops.knn_compositions); PCA(0.99) and the clustering are the same scikit-learn calls as in
+        the reference (their random start is not seeded there either, so labels are reproducible only up to that)."""
+        from sklearn.cluster import HDBSCAN, KMeans, SpectralClustering
+        from sklearn.decomposition import PCA
+        self.n_regions = n
+        self.tissue_regions = []
+        for i in range(self._n_images):
+            tab = self.preprocessor.cell_tables[i]
+            x = tab[:, 5].astype(np.float64) / tab[:, 6].astype(np.float64)
+            y = tab[:, 4].astype(np.float64) / tab[:, 6].astype(np.float64)
+            types = self._cell_type_ints(i)
+            comp = ops.knn_compositions(x, y, types, int(types.max()) + 1)
+            comp = PCA(n_components=0.99).fit_transform(comp)
+            if method == "kmeans":
+                clusterer = KMeans(n_clusters=n)
+            elif method == "hdbscan":
+                clusterer = HDBSCAN(n_clusters=n)        # as written in the reference (raises there too: HDBSCAN has no n_clusters)
+            elif method == "spectral":
+                clusterer = SpectralClustering(n_clusters=n, n_jobs=self.n_jobs if self.n_jobs and self.n_jobs > 0 else None)
+            else:
+                raise UnboundLocalError("local variable 'clusterer' referenced before assignment")
+            labels = clusterer.fit_predict(comp)
+            self.tissue_regions.append({int(k): labels[j] for j, k in enumerate(self.preprocessor.cell_ids[i].tolist())})
+
     # ---- outside the accelerated path ------------------------------------------------------------------------------
     def _out_of_scope(self, *_a, **_k):
-        raise NotImplementedError("post-analysis / plotting of the reference (heatmaps, UMAP, tissue regions) is CPU "
+        raise NotImplementedError("plotting of the reference (heatmaps, UMAP, pie charts) is CPU "
                                   "work downstream of the CSV and outside this accelerated hot path")
 
-    generate_heatmap = umap_visualization = tissue_region_analysis = cell_type_composition = _out_of_scope
+    generate_heatmap = umap_visualization = cell_type_composition = _out_of_scope

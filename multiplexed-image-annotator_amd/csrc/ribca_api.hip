@@ -598,6 +598,24 @@ int ribca_knn_cooccurrence(const double* x, const double* y, const int32_t* cell
   return 0;
 }
 
+int ribca_knn_compositions(const double* x, const double* y, const int32_t* cell_type, int32_t n_cells, int32_t n_types, const int32_t* sizes,
+                           int32_t n_sizes, uint16_t* counts, void* stream) {
+  if (!x || !y || !cell_type || !sizes || !counts) return fail("ribca_knn_compositions: NULL buffer");
+  if (n_cells <= 0 || n_sizes <= 0) return fail("ribca_knn_compositions: bad sizes");
+  int32_t host[8];
+  if (n_sizes > 8) return fail("ribca_knn_compositions: at most 8 neighbourhood sizes");
+  HIP_TRY(hipMemcpyAsync(host, sizes, sizeof(int32_t) * n_sizes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  for (int i = 0; i < n_sizes; ++i)
+    if (host[i] < 1 || (i > 0 && host[i] <= host[i - 1])) return fail("ribca_knn_compositions: sizes must be positive and strictly increasing");
+  const int k = host[n_sizes - 1] + 1;
+  if (k > n_cells) return fail("ribca_knn_compositions: more neighbours requested than cells");
+  if (launch_knn_compositions(x, y, cell_type, n_cells, k, n_types, n_sizes, sizes, counts, (hipStream_t)stream))
+    return fail("ribca_knn_compositions: needs max(sizes) <= 255 and n_types <= 32");
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------- normalisation primitives
 int ribca_u16_to_f32(const uint16_t* in, float* out, int64_t n, void* stream) {
   if (n > 0 && (!in || !out)) return fail("ribca_u16_to_f32: NULL buffer");

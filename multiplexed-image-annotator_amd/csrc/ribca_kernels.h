@@ -88,6 +88,10 @@ void launch_colorize(const int32_t* mask, long long npx, const int32_t* label_to
 int launch_knn_cooccurrence(const double* x, const double* y, const int32_t* type, int n, int k, int T, unsigned long long* matrix,
                             hipStream_t s);
 
+// per cell: counts of each type among its nearest list[l] other cells (k = list[last] + 1 <= 256 neighbours incl. itself)
+int launch_knn_compositions(const double* x, const double* y, const int32_t* type, int n, int k, int T, int n_lists, const int* list_dev,
+                            uint16_t* counts, hipStream_t s);
+
 // ----- whole-image normalisation (normalize.hip) ---------------------------------------------------------------
 void launch_u16_to_f32(const uint16_t* in, float* out, long long n, hipStream_t s);
 void launch_gauss1d(const float* in, float* out, int planes, int H, int W, int axis, const double* w, int R, int mode, hipStream_t s);

@@ -212,6 +212,30 @@ def knn_cooccurrence(x: np.ndarray, y: np.ndarray, cell_type: np.ndarray, n_type
     return out
 
 
+TISSUE_NEIGHBOURHOODS = (10, 20, 30, 50, 75, 100, 150, 200)       # spatial_methods.py:155
+
+
+def knn_compositions(x: np.ndarray, y: np.ndarray, cell_type: np.ndarray, n_types: int, sizes: Sequence[int] = TISSUE_NEIGHBOURHOODS,
+                     device=None) -> np.ndarray:
+    """(n, len(sizes) * n_types) float64: for every cell and every neighbourhood size the fraction of each cell type among its
+    nearest other cells -- the ``compositions`` matrix of the reference's tissue_region_partition (spatial_methods.py:158-176).
+    The k-NN search and the counting run on the GPU; the division count / size is done here in fp64 as numpy does it there."""
+    dev = device or _lib.require_gpu()
+    n = len(x)
+    if max(sizes) + 1 > n:
+        raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {max(sizes) + 1}, n_samples_fit = {n}")
+    xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(dev)
+    yd = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float64)).to(dev)
+    td = torch.from_numpy(np.ascontiguousarray(cell_type, dtype=np.int32)).to(dev)
+    sd = torch.tensor(list(sizes), dtype=torch.int32, device=dev)
+    counts = torch.empty((n, len(sizes), n_types), dtype=torch.int16, device=dev)
+    check(lib().ribca_knn_compositions(ptr(xd), ptr(yd), ptr(td), n, int(n_types), ptr(sd), len(sizes), ptr(counts), stream_ptr()),
+          "ribca_knn_compositions")
+    c = counts.cpu().numpy().astype(np.float64)
+    c /= c.sum(axis=2, keepdims=True)
+    return c.reshape(n, len(sizes) * n_types)
+
+
 # ------------------------------------------------------------------------------------------- whole-image normalisation
 def _gauss_weights(sigma: float) -> np.ndarray:
     """Taps at distance 0..R of scipy.ndimage.gaussian_filter(sigma, truncate=4.0), computed as scipy computes them."""

@@ -44,3 +44,28 @@ def csv_text(m: np.ndarray, cell_types: Sequence[str]) -> str:
     for i, c in enumerate(cell_types):
         lines.append(f"{c}," + "".join(f"{m[i][j]:.3f}," for j in range(len(cell_types))) + "\n")
     return "".join(lines)
+
+
+TISSUE_NEIGHBOURHOODS = (10, 20, 30, 50, 75, 100, 150, 200)       # spatial_methods.py:155
+
+
+def compositions(x: np.ndarray, y: np.ndarray, types: np.ndarray, sizes: Sequence[int] = TISSUE_NEIGHBOURHOODS) -> np.ndarray:
+    """spatial_methods.py:157-176: per cell, for each neighbourhood size, the fraction of every cell type (0 .. max type) among
+    its nearest other cells (201-NN query, the cell itself dropped), concatenated size-major.  Brute force, ties by lower index."""
+    n = len(x)
+    k = max(sizes) + 1
+    if k > n:
+        raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {k}, n_samples_fit = {n}")
+    n_types = int(np.max(types)) + 1
+    out = np.zeros((n, len(sizes) * n_types), np.float64)
+    for j in range(n):
+        dx, dy = x - x[j], y - y[j]
+        d = dx * dx + dy * dy
+        order = np.lexsort((np.arange(n), d))[1:k]
+        row = []
+        for s in sizes:
+            temp = np.bincount(types[order[:s]], minlength=n_types).astype(np.float64)
+            temp /= np.sum(temp)
+            row.extend(temp)
+        out[j] = row
+    return out

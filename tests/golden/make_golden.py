@@ -610,6 +610,39 @@ def golden_neighborhood():
     print("neighborhood.json", {k: len(v) for k, v in out.items()})
 
 
+def golden_tissue():
+    """spatial_methods.tissue_region_partition (spatial_methods.py:133-198): the `compositions` matrix the reference builds from its
+    201-nearest-neighbour query (captured at the PCA call; PCA / KMeans themselves are scikit-learn with a random start and are not
+    pinned), on the 1484-cell tile of the neighbourhood goldens."""
+    sp = ref("spatial_methods")
+    pre = ref("preprocess")
+    dummy = object.__new__(pre.ImageProcessor)
+    mask, _ = synth.make_mask_and_image(640, 700, 1500, 1, synth.SEED_BASE + 151, want_image=False)
+    d = pre.ImageProcessor._cell_pos_dict(dummy, mask.numpy().astype(np.int32), n_jobs=0)
+    keys = list(d.keys())
+    types = (synth.hash_u24(synth.stream_key(synth.SEED_BASE + 151, "nbr"), torch.tensor(keys, dtype=torch.int64)) % 6).tolist()
+    ann = [{"Cell ID": k, "Cell type": int(t), "Confidence": 0.5, "Row": d[k][0], "Column": d[k][1]} for k, t in zip(keys, types)]
+    captured = {}
+
+    class CapturePCA:
+        def __init__(self, n_components=None):
+            pass
+
+        def fit_transform(self, x):
+            captured["x"] = np.array(x, copy=True)
+            return x[:, :4]
+
+    real = sp.PCA
+    sp.PCA = CapturePCA
+    try:
+        labels = sp.tissue_region_partition([ann], n_clusters=3, n_jobs=0, method="kmeans")
+    finally:
+        sp.PCA = real
+    assert len(labels[0]) == len(keys)
+    np.savez_compressed(os.path.join(HERE, "tissue.npz"), compositions=captured["x"].astype(np.float64), types=np.array(types, np.int64))
+    print("tissue.npz", captured["x"].shape)
+
+
 # ---------------------------------------------------------------------------------------------- G6
 def mae_inputs(panel, n, seed):
     L = synth.MAE_PANELS[panel]
@@ -652,6 +685,6 @@ def golden_mae():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["normalize", "cellpos", "patches", "patches_scaled", "parser", "vote", "vit", "e2e", "mae", "colorize", "neighborhood"]
+    which = sys.argv[1:] or ["normalize", "cellpos", "patches", "patches_scaled", "parser", "vote", "vit", "e2e", "mae", "colorize", "neighborhood", "tissue"]
     for w in which:
         globals()["golden_" + w]()

@@ -484,3 +484,30 @@ def test_knn_cooccurrence_golden(dev, golden_dir, cname):
         assert ref_spatial.csv_text(ref_spatial.normalize_rows(acc.cpu().numpy().astype(np.float64)), names) == g["big_integrated_k25"]
         with pytest.raises(ValueError):
             ops.knn_cooccurrence(x[:5], y[:5], types[:5], len(names), 10)
+
+
+def test_tissue_compositions_golden(dev, golden_dir):
+    """ribca_knn_compositions (k = 201 via an LDS candidate buffer) vs the compositions matrix of the reference's tissue_region_partition."""
+    from test_oracle_host_logic import _neighborhood_inputs
+    ops = _ops()
+    g = np.load(os.path.join(golden_dir, "tissue.npz"))
+    _, x, y, types, _ = _neighborhood_inputs(golden_dir, "big")
+    got = ops.knn_compositions(x, y, types, int(types.max()) + 1)
+    np.testing.assert_array_equal(got, g["compositions"])
+    # small neighbourhoods agree with the register-list kernel
+    c10 = ops.knn_compositions(x, y, types, 6, sizes=(9,))
+    m = np.zeros((6, 6))
+    np.add.at(m, (np.repeat(types, 6), np.tile(np.arange(6), len(types))), (c10 * 9).reshape(-1))
+    np.testing.assert_allclose(m, ops.knn_cooccurrence(x, y, types, 6, 10).cpu().numpy(), atol=1e-6)
+    with pytest.raises(ValueError):
+        ops.knn_compositions(x[:100], y[:100], types[:100], 6)
+    # many rounds of the candidate buffer without a re-sort in between (the path a small tile never takes)
+    rng = np.random.default_rng(5)
+    n = 9000
+    px, py, pt = rng.random(n) * 1000, rng.random(n) * 800, rng.integers(0, 7, n)
+    big = ops.knn_compositions(px, py, pt, 7)
+    for j in rng.integers(0, n, 150):
+        d = (px - px[j]) ** 2 + (py - py[j]) ** 2
+        order = np.lexsort((np.arange(n), d))[1:201]
+        row = np.concatenate([np.bincount(pt[order[:s]], minlength=7) / float(s) for s in ops.TISSUE_NEIGHBOURHOODS])
+        np.testing.assert_array_equal(big[j], row)

@@ -148,3 +148,12 @@ def test_neighborhood_oracle_matches_reference(golden_dir, cname):
         assert ref_spatial.csv_text(raw, names) == g["big_raw_k10"]
         both = ref_spatial.cooccurrence(x, y, types, len(names), 25) + ref_spatial.cooccurrence(x[:700], y[:700], types[:700], len(names), 25)
         assert ref_spatial.csv_text(ref_spatial.normalize_rows(both), names) == g["big_integrated_k25"]
+
+
+def test_tissue_compositions_oracle_matches_reference(golden_dir):
+    """oracle.ref_spatial.compositions vs the matrix captured inside the reference's tissue_region_partition (201-NN ball tree)."""
+    from oracle import ref_spatial
+    g = np.load(os.path.join(golden_dir, "tissue.npz"))
+    _, x, y, types, _ = _neighborhood_inputs(golden_dir, "big")
+    assert np.array_equal(types, g["types"])
+    np.testing.assert_array_equal(ref_spatial.compositions(x, y, types), g["compositions"])

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Times the two post-predict consumers on the GPU at the BASELINE config-3 size (4096 x 4096 mask, ~100 k cells): label painting
+"""Times the post-predict consumers on the GPU at the BASELINE config-3 size (4096 x 4096 mask, ~100 k cells): label painting
 (ribca_colorize) and the 25-nearest-neighbour co-occurrence (ribca_knn_cooccurrence)."""
 import os
 import sys
@@ -24,7 +24,8 @@ pal = np.array(colors.get_colors(12), np.uint8)
 x = tab[:, 5] / tab[:, 6]
 y = tab[:, 4] / tab[:, 6]
 for name, fn in (("colorize", lambda: ops.colorize(mask, ids, pal[tidx], colors.confidence_colors(conf), (tidx + 1).astype(np.uint8))),
-                 ("knn25", lambda: ops.knn_cooccurrence(x, y, tidx, 12, 25))):
+                 ("knn25", lambda: ops.knn_cooccurrence(x, y, tidx, 12, 25)),
+                 ("compositions (201-NN, 8 sizes)", lambda: ops.knn_compositions(x, y, tidx, 12))):
     fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
