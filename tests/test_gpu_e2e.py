@@ -357,3 +357,35 @@ def test_two_ranks_match_single_rank(tmp_path):
     a = open(tmp_path / "sharded" / "results" / "r_annotation_0.csv").read()
     b = open(tmp_path / "single" / "results" / "r_annotation_0.csv").read()
     assert a == b and len(a.splitlines()) == len(one.annotations[0]) + 1
+
+
+@pytest.mark.parametrize("case", ["empty", "single", "sparse_odd", "sparse_cs20", "float32", "uint8"])
+def test_edge_inputs_run_end_to_end(tmp_path, case):
+    """Empty mask, one cell, non-contiguous labels on an odd-sized tile (borders on all sides), other pixel dtypes, a small cell_size:
+    preprocess -> predict -> export -> colorize (-> neighbourhood) must run and write one CSV row per cell."""
+    from multiplexed_image_annotator_amd.annotator import Annotator
+    rng = np.random.default_rng(0)
+    raw = rng.integers(0, 4000, (7, 101, 99)).astype(np.uint16)
+    mask = np.zeros((101, 99), np.int32)
+    if case == "single":
+        mask[50:56, 40:47] = 5
+    elif case != "empty":
+        for k, (r, c) in enumerate([(3, 3), (3, 95), (97, 2), (96, 96), (50, 50), (20, 70), (70, 20), (40, 10), (10, 40), (60, 80), (80, 60), (30, 30)]):
+            mask[max(r - 3, 0):r + 4, max(c - 3, 0):c + 4] = 1000 + 37 * k
+    if case == "float32":
+        raw = raw.astype(np.float32)
+    if case == "uint8":
+        raw = (raw // 16).astype(np.uint8)
+    mf, csv = write_case(tmp_path, raw, mask, synth.BASIC_PANEL_MARKERS)
+    a = Annotator(mf, csv, "cuda", str(tmp_path), "e", True, False, -1, True, 0.3, 99.8, 0.3, 20 if case == "sparse_cs20" else 30, None)
+    a.set_weights({"immune_base": synth.make_vit_state_dict("immune_base", 7, depth=2)})
+    a.preprocess()
+    a.predict(8)
+    a.export_annotations()
+    a.colorize(from_script=True)
+    n = len(np.unique(mask)) - 1
+    assert len(a.annotations[0]) == n
+    assert len(open(tmp_path / "results" / "e_annotation_0.csv").read().splitlines()) == n + 1
+    if n >= 10:
+        a.neighborhood_analysis(n_neighbors=10)
+        assert os.path.exists(tmp_path / "results" / "e_integrated_neighborhood.csv")
