@@ -1,5 +1,5 @@
-// bf16x3 MFMA GEMM for the ViT linears (timm Attention.qkv / Attention.proj / Mlp.fc1 / Mlp.fc2 / PatchEmbed.proj,
-// reached from reference cell_type_annotation/model.py:402 ``model(x)``).
+// bf16x3 MFMA GEMM for the ViT linears (timm Attention.qkv / Attention.proj / Mlp.fc1 / Mlp.fc2; the imputer's embeddings and
+// prediction head too), reached from reference cell_type_annotation/model.py:402 ``model(x)``).
 //
 //   C[m][n] = sum_k A[m][k] * W[n][k]        A: activations  [M ][2*Kp] packed-split bf16 (ribca_common.h)
 //                                            W: nn.Linear wt [Np][2*Kp] packed-split bf16, Np = N padded to the tile
@@ -26,8 +26,10 @@
 //   each lane's GLOBAL source address.
 // * block id -> tile map is XCD-aware (blocks b, b+8, ... share an L2): every XCD walks whole rows of n-tiles of one
 //   m-tile, so an A tile is fetched into one L2 once and reused by all its n-tiles.
-// * Epilogues run in two sweeps (all loads, then compute + stores); they are NOT yet overlapped with the next tile's K loop
-//   and cost 25-45 % of the short-K launches (tools/bench_gemm.py variant 9) -- see DESIGN.md section 9.
+// * Epilogue through LDS: the finished tile is parked in the (dead) ring and all 12 waves write it out in row-major 16-byte
+//   chunks -- whole 256-512 byte row segments per instruction (what a CU can drain depends on the address shape of a store,
+//   tools/store_bench.hip).  It is not overlapped with the next tile's K loop; DESIGN.md section 6 lists the persistent /
+//   streaming / relay forms that were built for that and why they did not pay (output traffic, not the latency chain).
 #include <cstdlib>
 #include <type_traits>
 
