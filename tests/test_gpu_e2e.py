@@ -389,3 +389,41 @@ def test_edge_inputs_run_end_to_end(tmp_path, case):
     if n >= 10:
         a.neighborhood_analysis(n_neighbors=10)
         assert os.path.exists(tmp_path / "results" / "e_integrated_neighborhood.csv")
+
+
+def test_config3_full_size_properties():
+    """BASELINE config 3 at its real size (15-ch 4096 x 4096, ~100 k cells, five classifiers, the bench's own inputs): properties that do
+    not need the CPU oracle -- every labelled pixel counted once, patches of a shard == rows of the full run, probability rows sum to
+    one, a shard's probabilities == the same rows of the full run bit for bit (any chunking, any number of streams), and the oracle
+    agrees on a 24-cell sample of the biggest model."""
+    from multiplexed_image_annotator_amd import _lib, ops
+    from oracle import ref_vit
+    dev = _lib.require_gpu()
+    seed = synth.SEED_BASE + 3
+    mask, img = synth.make_mask_and_image(4096, 4096, 100000, 15, seed, device=dev)
+    mask = mask.to(torch.int32)
+    image = ops.normalize_image(img.to(torch.int16), blur=0.3, amax=99.8)
+    del img
+    ids, tab = ops.label_table(mask)
+    n = len(ids)
+    assert n > 99000 and int(tab[:, 6].sum()) == int((mask > 0).sum())
+    cmin = ops.channel_min(image)
+    ids_d = torch.from_numpy(ids.astype(np.int32)).to(dev)
+    bb_d = torch.from_numpy(tab[:, :4].astype(np.int32)).to(dev)
+    patches, _ = ops.extract_patches(image, mask, cmin, ids_d, bb_d)
+    lo, hi = 61234, 61234 + 1500
+    part, _ = ops.extract_patches(image, mask, cmin, ids_d[lo:hi].contiguous(), bb_d[lo:hi].contiguous())
+    assert torch.equal(part, patches[lo:hi])
+    for name, (d, c, k) in synth.VIT_CONFIGS.items():
+        sd = synth.make_vit_state_dict(name, seed)
+        model = ops.VitModel(sd, dev)
+        src = list(range(c))
+        p_full = model.predict_proba(patches, src, chunk_cells=1024, streams=3)
+        assert torch.isfinite(p_full).all() and (p_full.sum(1) - 1).abs().max().item() < 1e-5
+        p_part = model.predict_proba(part, src, chunk_cells=300, streams=1)
+        assert torch.equal(p_part, p_full[lo:hi])
+        if name == "immune_full":
+            x = part[:24, :c].cpu()
+            ref = ref_vit.predict_proba(sd, x, 8)
+            assert (p_part[:24].cpu() - ref).abs().max().item() < 1e-3 and torch.equal(p_part[:24].cpu().argmax(1), ref.argmax(1))
+        del model, p_full
