@@ -6,7 +6,13 @@ ranks with one RCCL all-gather of the per-cell probabilities = configs[3]).
 One step = one pass of the hot path over the tile, inputs (uint16 image, int32 mask, packed weights) resident in HBM:
 normalise -> label table -> per-cell crop / soft mask -> 5 x (patch-embed, 12 blocks, head, softmax) -> vote -> labels
 on the host.  Prints ONE JSON line (rank 0).  ``roofline`` is measured live with HIP events around every GEMM launch of
-one extra (untimed) profiled pass; ``cpu_baseline`` times the CPU oracle on a bounded sample of the same workload.
+one extra (untimed) profiled pass; ``cpu_baseline`` times the CPU oracle on a bounded sample of the same workload;
+``dropin`` times the boundary itself (``Annotator.preprocess -> predict -> export_annotations`` from host ``.npy`` files,
+H2D copies and the CSV included) on the same tile.
+
+``--gpus N`` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (``torch.distributed.run`` as a child
+process, before this process touches a GPU); under the driver's own ``torch.distributed.run`` launch it is just a rank.
+``--impute`` switches the workload to BASELINE config 5 (one full-panel marker missing -> MAE imputer + the five ViTs).
 """
 import argparse
 import json
@@ -35,15 +41,66 @@ def parse():
     ap.add_argument("--streams", type=int, default=int(os.environ.get("RIBCA_STREAMS", "3")), help="each classifier's cells are split into this many segments enqueued on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the Annotator (boundary path) timing")
+    ap.add_argument("--impute", action="store_true", help="BASELINE config 5: last full-panel marker missing, imputed by the MAE (infer=True)")
+    ap.add_argument("--cpu-sample", type=int, default=512, help="cells of the CPU-oracle sample")
+    ap.add_argument("--launch-check", action="store_true", help="rendezvous + one all-gather only (no GPU work): CPU test of the N-rank launch path")
     return ap.parse_args()
+
+
+def launch_ranks(args) -> int:
+    """Start ``args.gpus`` ranks of this script under torch.distributed.run as a CHILD process.  Nothing in this (parent) process
+    has touched a GPU: counting devices does not initialise HIP, and the library is only compiled here, not loaded."""
+    import socket
+    import subprocess
+    share = os.environ.get("RIBCA_SHARE_GPU") == "1" or args.launch_check
+    have = torch.cuda.device_count()
+    if have < args.gpus and not share:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    if not args.launch_check:
+        from multiplexed_image_annotator_amd import build as _build
+        _build.build(verbose=False)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
+def launch_check(args, world, rank, backend):
+    """The N-rank plumbing without a GPU: process group, barrier, the padded all-gather of dist.all_gather_rows, JSON on rank 0."""
+    import torch.distributed as tdist
+    from multiplexed_image_annotator_amd import dist
+    if world > 1:
+        tdist.init_process_group("gloo" if backend != "nccl" or not torch.cuda.is_available() else backend)
+    n = 1001
+    lo, hi = dist.shard_bounds(n, rank, world)
+    local = torch.arange(lo, hi, dtype=torch.float32).reshape(-1, 1).repeat(1, 33)
+    full = dist.all_gather_rows(local, n)
+    ok = bool(torch.equal(full[:, 0], torch.arange(n, dtype=torch.float32)))
+    if world > 1:
+        tdist.barrier()
+        tdist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "launch check (no measurement)", "value": None, "n_gpus": world, "gather_ok": ok}))
+    return 0 if ok else 1
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("RIBCA_DIST_BACKEND", "nccl")     # "gloo" + RIBCA_SHARE_GPU=1: rehearsal of the N > 1 path on a 1-GPU box
+    if args.launch_check:
+        sys.exit(launch_check(args, world, rank, backend))
     if world > 1:
         import torch.distributed as tdist
         if os.environ.get("RIBCA_SHARE_GPU") == "1":
@@ -86,7 +143,7 @@ def main():
 
     def one_pass(streams=None):
         streams = args.streams if streams is None else streams
-        image = ops.normalize_image(raw, blur=0.3, amax=99.8)
+        image = ops.normalize_image(raw, blur=0.3, amax=99.8, u16_bits=True)
         ids, tab = ops.label_table(mask)
         n = len(ids)
         lo, hi = dist.shard_bounds(n, rank, world)
@@ -97,8 +154,11 @@ def main():
         probs = {}
         for name, model in models.items():
             probs[name] = model.predict_proba(patches, srcs[name], chunk_cells=args.chunk, streams=streams)
-        if world > 1:
-            probs = {k: dist.all_gather_rows(v, n) for k, v in probs.items()}
+        if world > 1:       # ONE all-gather per tile: the five models' probability columns side by side (33 floats per cell)
+            names = list(probs)
+            widths = [probs[k].shape[1] for k in names]
+            full = dist.all_gather_rows(torch.cat([probs[k] for k in names], dim=1), n)
+            probs = {k: t.contiguous() for k, t in zip(names, torch.split(full, widths, dim=1))}
         a, b = vote_pair
         lab, conf = ops.vote(probs[a], [gid[c] for c in CLASS_NAMES[a]], probs[b] if b else None,
                              [gid[c] for c in CLASS_NAMES[b]] if b else None, tc, 0.3)

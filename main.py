@@ -42,43 +42,84 @@ def parse_args(argv=None):
     return args
 
 
-def run(args):
+def _setup():
     import __graft_entry__
     __graft_entry__.build()
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
-    from multiplexed_image_annotator_amd.annotator import Annotator
-    csv_path = args.batch_csv
-    if args.image_path:
-        csv_path = os.path.join(args.main_dir, "images.csv")
-        if int(os.environ.get("RANK", "0")) == 0:
-            os.makedirs(args.main_dir, exist_ok=True)
-            with open(csv_path, "w") as f:
-                f.write("image_path,mask_path\n%s,%s\n" % (args.image_path, args.mask_path))
-        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-            import torch.distributed as dist
-            dist.barrier()
-    a = Annotator(args.marker_list_path, csv_path, args.device, args.main_dir, args.batch_id, args.strict, args.infer, args.min_cells,
-                  args.normalize, args.blur, args.amax, args.confidence, args.cell_size, args.cell_type_confidence, n_jobs=args.n_jobs)
-    p = a.channel_parser
-    if not (p.immune_base or p.immune_extended or p.immune_full or p.struct or p.nerve):
+        if not dist.is_initialized():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            dist.init_process_group(os.environ.get("RIBCA_DIST_BACKEND", "nccl"))
+
+
+def _pipeline(annotator, bs, n_regions):
+    """The call sequence of reference main.py:19-28 / 43-52, verbatim.  Its plotting calls (generate_heatmap,
+    cell_type_composition) are outside the accelerated path: this Annotator logs and skips them."""
+    p = annotator.channel_parser
+    if not p.immune_base and not p.immune_extended and not p.immune_full and not p.struct and not p.nerve:
         raise ValueError("No panels are applied. Please check the marker list.")
-    a.preprocess()
-    a.predict(args.bs)
-    a.export_annotations()
-    n_cells = min((len(ids) for ids in a.preprocessor.cell_ids), default=0)
-    if args.n_regions > 0 and n_cells >= 201:      # the reference's 201-neighbour query raises on smaller images
-        a.tissue_region_analysis(args.n_regions)
-        a.export_annotations()                      # reference order is regions -> export; the CSV gains its Tissue Region column
-    if n_cells >= 25:                              # the reference's kNN (25 neighbours) raises on smaller images
-        a.neighborhood_analysis(integrate=True, normalize=True)
-    a.colorize(from_script=True)
-    a.clear_tmp()
-    return a
+    annotator.preprocess()
+    annotator.predict(bs)
+    annotator.generate_heatmap(integrate=True)
+    annotator.export_annotations()
+    n_cells = min((len(ids) for ids in annotator.preprocessor.cell_ids), default=0)
+    if n_regions > 0 and n_cells >= 201:           # the reference's 201-neighbour query raises on smaller images
+        annotator.tissue_region_analysis(n_regions)
+        annotator.export_annotations()              # so that the CSV carries the Tissue Region column the analysis just produced
+    if n_cells >= 25:                               # the reference's kNN (25 neighbours) raises on smaller images
+        annotator.neighborhood_analysis(integrate=True, normalize=True)
+    annotator.colorize(from_script=True)
+    annotator.cell_type_composition()
+    annotator.clear_tmp()
+
+
+def run(marker_list_path, image_path, mask_path, device, main_dir, batch_id, bs, strict, infer, min_cells, n_regions, normalize, blur, amax,
+        confidence, cell_size, cell_type_confidence, n_jobs):
+    """reference main.py:9-36: one image + mask -> images.csv -> annotate; returns (intensity_dict, names) as the reference does."""
+    import numpy as np
+    _setup()
+    from multiplexed_image_annotator_amd.annotator import Annotator
+    path_ = os.path.join(main_dir, "images.csv")
+    if int(os.environ.get("RANK", "0")) == 0:
+        os.makedirs(main_dir, exist_ok=True)
+        with open(path_, "w") as f:
+            f.write("image_path,mask_path\n%s,%s\n" % (image_path, mask_path))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    annotator = Annotator(marker_list_path, path_, device, main_dir, batch_id, strict, infer, min_cells, normalize, blur, amax, confidence,
+                          cell_size, cell_type_confidence, n_jobs=n_jobs)
+    _pipeline(annotator, bs, n_regions)
+    intensity_dict = {}
+    full = annotator.preprocessor.intensity_full[0]
+    for i in range(len(full)):
+        intensity_dict[i + 1] = full[i]
+    intensity_dict[0] = np.zeros_like(full[0])
+    names = annotator.get_cell_type_names()
+    return intensity_dict, names
+
+
+def batch_run(marker_list_path, image_path, device, main_dir, batch_id, bs, strict, infer, min_cells, n_regions, normalize, blur, amax,
+              confidence, cell_size, cell_type_confidence, n_jobs=0):
+    """reference main.py:39-52: ``image_path`` is a CSV with columns image_path,mask_path."""
+    _setup()
+    from multiplexed_image_annotator_amd.annotator import Annotator
+    annotator = Annotator(marker_list_path, image_path, device, main_dir, batch_id, strict, infer, min_cells, normalize, blur, amax,
+                          confidence, cell_size, cell_type_confidence, n_jobs=n_jobs)
+    _pipeline(annotator, bs, n_regions)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    common = dict(marker_list_path=args.marker_list_path, device=args.device, main_dir=args.main_dir, batch_id=args.batch_id, bs=args.bs,
+                  strict=args.strict, infer=args.infer, min_cells=args.min_cells, n_regions=args.n_regions, normalize=args.normalize,
+                  blur=args.blur, amax=args.amax, confidence=args.confidence, cell_size=args.cell_size,
+                  cell_type_confidence=args.cell_type_confidence, n_jobs=args.n_jobs)
+    if args.batch_csv:
+        return batch_run(image_path=args.batch_csv, **common)
+    return run(image_path=args.image_path, mask_path=args.mask_path, **common)
 
 
 if __name__ == "__main__":
-    run(parse_args())
+    main()

@@ -1,8 +1,9 @@
 """``Annotator``: drop-in for the reference orchestrator on its hot path (cell_type_annotation/model.py:90-919):
 same constructor, ``preprocess()``, ``predict(batch_size)``, ``export_annotations()``, ``clear_tmp()``,
 ``get_cell_type_names()`` and the attributes downstream code reads (``annotations``, ``confidence``, ``annotations_all``,
-``cell_types``, ``channel_parser``, ``preprocessor``, ``*_pred``).  Compute runs in the HIP library; post-analysis / plotting
-methods of the reference are outside the accelerated path and raise NotImplementedError.
+``cell_types``, ``channel_parser``, ``preprocessor``, ``*_pred``).  Compute runs in the HIP library; the plotting methods of
+the reference (heat-maps, pie charts, UMAP) are outside the accelerated path: they log and return, so the
+reference's own call sequence (main.py:19-28) completes against this class.
 """
 from __future__ import annotations
 
@@ -141,13 +142,36 @@ class Annotator(object):
             if sd is None:
                 raise ValueError("Panel not found")
             self.imputers[panel] = ops.MaeModel(sd, _lib.require_gpu())
-            missing = [self.channel_parser.panels[panel][i] for i, c in enumerate(self.channel_parser.indices[panel]) if c == -1]
-            self.logger.log("Imputer for {} is created. Marker(s) {} are imputed.".format(panel, " ".join(missing)))
+            index = self.channel_parser.indices[panel]
+            n_present = sum(1 for c in index if c != -1)
+            # preprocess.py:272-279, including its loop bound (only the first len(present) entries are inspected)
+            msg = "Imputer for {} is created. Marker(s) ".format(panel)
+            for ii in range(n_present):
+                if index[ii] == -1:
+                    msg += "{} ".format(self.channel_parser.panels[panel][ii])
+            msg += "are imputed."
+            print("Imputer for {} is created".format(panel))
+            self.logger.log(msg)
         return self.imputers[panel]
+
+    def _panels_to_impute(self) -> List[str]:
+        """preprocess.py:268: panels whose index list holds a -1, unless infer is off (never 'structure'; the reference's
+        "nerve" test never matches the real panel name 'nerve_cell', whose panel tolerates no missing marker anyway)."""
+        out = []
+        for panel in self.channel_parser.panels:
+            index = self.channel_parser.indices.get(panel)
+            if index is not None and self.infer and -1 in index and panel not in ("structure", "nerve"):
+                out.append(panel)
+        return out
 
     # ---- pipeline --------------------------------------------------------------------------------------------------
     def preprocess(self):
         rank, ws = self.rank, self.world_size
+        # The reference builds each MarkerImputer inside transform() (preprocess.py:272): a missing ``<panel>_impute.pth`` raises
+        # ValueError("Panel not found") there, not in predict().  Here they are built up front, so that every rank fails before
+        # any collective is entered (a rank raising later would leave the others waiting in the all-gather).
+        for panel in self._panels_to_impute():
+            self._imputer(panel)
         self.preprocessor.transform(shard_fn=(lambda n: dist.shard_bounds(n, rank, ws)) if ws > 1 else None,
                                     gather_fn=(lambda t, n: dist.all_gather_rows(t, n)) if ws > 1 else None)
         self._n_images = self.preprocessor._n_images
@@ -163,8 +187,8 @@ class Annotator(object):
         immune = "immune_full" if p.immune_full else ("immune_extended" if p.immune_extended else ("immune_base" if p.immune_base else None))
         return {"immune": immune, "struct": "struct" if p.struct else None, "nerve": "nerve" if p.nerve else None}
 
-    def _predict_cell_types(self, image_idx, model_name, batch_size=None) -> np.ndarray:
-        """softmax(model(x), dim=1) for this rank's cells of one image, all-gathered to the full (n, K) table."""
+    def _predict_cell_types(self, image_idx, model_name, batch_size=None) -> torch.Tensor:
+        """softmax(model(x), dim=1) for THIS RANK's cells of one image: (n_local, K) device table (predict() gathers)."""
         pre = self.preprocessor
         model = self.models[model_name]
         index = self.channel_parser.indices[MODEL_PANEL[model_name]]
@@ -181,9 +205,7 @@ class Annotator(object):
             present = [i for i, c in enumerate(index) if c != -1]
             imputer.impute(panel, present, chunk_cells=self.chunk_cells)
             patches, src = panel, list(range(len(index)))
-        local = model.predict_proba(patches, src, chunk_cells=self.chunk_cells, streams=self.streams)
-        full = dist.all_gather_rows(local, n) if self.world_size > 1 else local
-        return full
+        return model.predict_proba(patches, src, chunk_cells=self.chunk_cells, streams=self.streams)
 
     def predict(self, batch_size=32):
         self.logger.log("\nStart predicting cell types and tissue structures.")
@@ -208,6 +230,12 @@ class Annotator(object):
                 tables[name] = self._predict_cell_types(image_idx, name, batch_size)
             if not tables:
                 raise ValueError("No predictions to merge")
+            if self.world_size > 1:
+                # ONE all-gather per image: the models' probability columns side by side (<= 33 floats per cell), SURVEY 8(e)
+                names = list(tables)
+                widths = [tables[k].shape[1] for k in names]
+                full = dist.all_gather_rows(torch.cat([tables[k] for k in names], dim=1), len(self.preprocessor.cell_ids[image_idx]))
+                tables = {k: t.contiguous() for k, t in zip(names, torch.split(full, widths, dim=1))}
             imm, st, nv = active["immune"], active["struct"], active["nerve"]
             if imm == "immune_full" and st and nv:
                 raise KeyError("Others")       # reference branch 1 (model.py:483-510) fails exactly like this
@@ -250,7 +278,10 @@ class Annotator(object):
         self._annotations_all = None
 
     def merge_by_voting(self):
-        raise NotImplementedError("voting is fused into predict() (HIP vote kernel); call predict()")
+        """model.py:481-640.  predict() has already voted (HIP vote kernel over the probability tables); calling this afterwards,
+        as external code following the reference might, leaves the result as is.  Before predict() it fails as the reference does."""
+        if len(self.annotations) == 0:
+            raise ValueError("No predictions to merge")
 
     @property
     def annotations_all(self):
@@ -414,8 +445,18 @@ class Annotator(object):
             self.tissue_regions.append({int(k): labels[j] for j, k in enumerate(self.preprocessor.cell_ids[i].tolist())})
 
     # ---- outside the accelerated path ------------------------------------------------------------------------------
-    def _out_of_scope(self, *_a, **_k):
-        raise NotImplementedError("plotting of the reference (heatmaps, UMAP, pie charts) is CPU "
-                                  "work downstream of the CSV and outside this accelerated hot path")
+    def _skip(self, what: str):
+        msg = f"{what}: skipped (plotting downstream of the CSV, outside the accelerated hot path)"
+        self.logger.log(msg)
+        return None
 
-    generate_heatmap = umap_visualization = cell_type_composition = _out_of_scope
+    def generate_heatmap(self, integrate=False):
+        """model.py:697-766 (seaborn heat-maps of the intensity table): not drawn; ``preprocessor.intensity_full`` holds the data."""
+        return self._skip("generate_heatmap")
+
+    def cell_type_composition(self, reduction=True):
+        """model.py:860-913 (pie charts): not drawn; the CSVs hold the labels."""
+        return self._skip("cell_type_composition")
+
+    def umap_visualization(self, *_a, **_k):
+        return self._skip("umap_visualization")

@@ -290,7 +290,12 @@ __device__ __forceinline__ void lds_drain(const Epi& epi, const char* smem, int 
 // barrier (every wave at once, both SIMD partners) left the matrix pipe idle for a third of each K step; on dedicated waves
 // that cost overlaps the consumers' MFMAs (3 waves per SIMD: 2 consumers + 1 loader).  Consumers never touch vmcnt in the
 // loop, so their epilogue loads/stores cannot drain the ring.
-template <int BN, class Epi, int ABL = 0 /* timing ablations: 1 = no loads, 2 = no MFMA/LDS reads, 3 = no epilogue, 4 = stamps */,
+// timing ablations (measurement builds only; results are wrong on purpose): 1 = no loads, 2 = no MFMA/LDS reads, 3 = no epilogue,
+// 4 = stamps, 5 = no loads and no epilogue, 6 / 7 = two / one MFMA per operand pair, 8 / 9 = the same without the epilogue
+constexpr bool abl_no_loads(int a) { return a == 1 || a == 5; }
+constexpr bool abl_no_epi(int a) { return a == 3 || a == 5 || a == 8 || a == 9; }
+constexpr int abl_passes(int a) { return (a == 6 || a == 8) ? 2 : (a == 7 || a == 9) ? 1 : 3; }
+template <int BN, class Epi, int ABL = 0,
           bool STAG = false, bool LEPI = false /* epilogue through LDS: row-contiguous stores by all 12 waves */>
 __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw,
                                                             int M, int Kp, int mtiles, int ntiles, Epi epi, int deph) {
@@ -353,7 +358,7 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + ko),
                                          (__attribute__((address_space(3))) void*)(st + dst[i]), 16, 0, 0);
     };
-    if (ABL != 1) {
+    if (!abl_no_loads(ABL)) {
       issue(0, 0);
       if (nk > 1) issue(1, 1);
     }
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (ABL != 1 && kk + 2 < nk) {
+      if (!abl_no_loads(ABL) && kk + 2 < nk) {
         int nxt = cur + 2;
         nxt = nxt >= NST ? nxt - NST : nxt;
         issue(kk + 2, nxt);
@@ -372,7 +377,7 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
       cur = cur + 1 == NST ? 0 : cur + 1;
     }
     if (STAG) __builtin_amdgcn_s_barrier();     // phase 2nk
-    if constexpr (LEPI && STAG && ABL != 3) {
+    if constexpr (LEPI && STAG && !abl_no_epi(ABL)) {
       if (!lepi_tile_uses_registers(epi, n0, BN)) {
         __syncthreads();                          // consumers have parked the tile
         lds_drain<BN>(epi, smem, m0, n0, tid);
@@ -411,14 +416,18 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
     }
   };
   auto mfmas = [&]() {
+    if constexpr (abl_passes(ABL) >= 3) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(wlo[j], ahi[i], acc[i][j]);
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(wlo[j], ahi[i], acc[i][j]);
+    }
+    if constexpr (abl_passes(ABL) >= 2) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(whi[j], alo[i], acc[i][j]);
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(whi[j], alo[i], acc[i][j]);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -459,7 +468,7 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
     if (!late) __builtin_amdgcn_s_barrier();         // phase 2nk: partners finish their last MFMAs
   }
   if (ABL == 4) t2 = stamp_now();
-  if (ABL == 3) {   // timing ablation: no epilogue (accumulators kept alive so the MFMAs are not dead code)
+  if (abl_no_epi(ABL)) {   // timing ablation: no epilogue (accumulators kept alive so the MFMAs are not dead code)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -533,6 +542,11 @@ static void launch_bn(const GemmArgs& g, const Epi& epi, hipStream_t s) {
     case 5: launch_split<BN, Epi, 2, false>(g, epi, s); break;   // ablation: loads only
     case 7: launch_split<BN, Epi, 1, true>(g, epi, s); break;    // ablation: no loads, staggered
     case 9: launch_split<BN, Epi, 3, true>(g, epi, s); break;    // ablation: no epilogue
+    case 20: launch_split<BN, Epi, 5, true>(g, epi, s); break;   // ablation: no loads, no epilogue (the K-loop structure alone)
+    case 21: launch_split<BN, Epi, 6, true, true>(g, epi, s); break;   // ablation: 2 MFMAs per operand pair
+    case 22: launch_split<BN, Epi, 7, true, true>(g, epi, s); break;   // ablation: 1 MFMA per operand pair
+    case 23: launch_split<BN, Epi, 8, true>(g, epi, s); break;   // ablation: 2 MFMAs, no epilogue
+    case 24: launch_split<BN, Epi, 9, true>(g, epi, s); break;   // ablation: 1 MFMA, no epilogue
     case 12: launch_split<BN, Epi, 4, true, true>(g, epi, s); break;   // production kernel + diagnostic time stamps
     case 14: launch_split<BN, Epi, 0, true>(g, epi, s); break;   // A/B: epilogue straight from the accumulator registers
     default: launch_split<BN, Epi, 0, true, true>(g, epi, s); break;   // production: loader waves + half-step stagger + LDS epilogue

@@ -158,6 +158,7 @@ def extract_patches(image: torch.Tensor, mask: torch.Tensor, chan_min: torch.Ten
     assert mask.shape == (h, w) and bbox.shape == (n, 4)
     if out is None:
         out = torch.empty((n, c, PATCH, PATCH), dtype=torch.float32, device=image.device)
+    assert out.shape == (n, c, PATCH, PATCH) and out.dtype == torch.float32 and out.is_contiguous()
     avg = torch.empty((n, c), dtype=torch.float64, device=image.device) if want_avg else None
     if n and int(patch_size) == PATCH:
         check(lib().ribca_extract_patches(ptr(image), c, h, w, ptr(mask), ptr(chan_min), ptr(ids), ptr(bbox), ptr(_taps(image.device)), n,
@@ -189,7 +190,8 @@ def colorize(mask: torch.Tensor, ids: np.ndarray, type_rgb: np.ndarray, conf_rgb
     out_t = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
     out_c = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
     out_i = torch.empty((h, w), dtype=torch.uint8, device=dev)
-    check(lib().ribca_colorize(ptr(mask.contiguous()), h * w, ptr(tab_d), top, ptr(a), ptr(b), ptr(c), ptr(out_t), ptr(out_c), ptr(out_i),
+    mask_c = mask.contiguous()
+    check(lib().ribca_colorize(ptr(mask_c), h * w, ptr(tab_d), top, ptr(a), ptr(b), ptr(c), ptr(out_t), ptr(out_c), ptr(out_i),
                                stream_ptr()), "ribca_colorize")
     return out_t, out_c, out_i
 
@@ -285,11 +287,24 @@ def _order_statistics(x: torch.Tensor, ranks: np.ndarray) -> np.ndarray:
     return prefix.view(np.float32).copy()
 
 
+def _numpy_quantile_impl():
+    """numpy's own linear-quantile helpers (index, gamma, lerp): the percentile threshold of ``_normalize`` must round exactly
+    as ``np.percentile`` does.  They live in a private module that exists since NumPy 2.0 (the version this package is
+    validated against); anything else fails loudly instead of silently diverging from the reference."""
+    try:
+        from numpy.lib import _function_base_impl as fb
+        for name in ("_QuantileMethods", "_get_indexes", "_get_gamma", "_lerp"):
+            getattr(fb, name)
+    except (ImportError, AttributeError) as e:
+        raise _lib.RibcaError(f"normalize_image needs NumPy >= 2.0 quantile internals (found numpy {np.__version__}): {e}") from e
+    return fb
+
+
 def _percentile_plan(n: int, amax):
     """The two sorted-array indexes np.percentile(x, amax) (method 'linear', fp32 data of n values) interpolates between,
     and its fp32 interpolation weight -- obtained by running numpy's own index/gamma helpers, so dtypes and rounding are
     numpy's whatever its version.  Returns (prev, next, gamma) with prev == next and gamma None when no interpolation."""
-    from numpy.lib import _function_base_impl as fb
+    fb = _numpy_quantile_impl()
     q = np.asanyarray(np.true_divide(amax, np.float32(100)))     # np.percentile divides by a.dtype.type(100) for float data
     virtual = np.asanyarray(fb._QuantileMethods["linear"]["get_virtual_index"](n, q))
     if np.issubdtype(virtual.dtype, np.integer):
@@ -301,16 +316,18 @@ def _percentile_plan(n: int, amax):
 
 def _percentile_like_numpy(n: int, amax, lo_hi_getter):
     """np.percentile of one fp32 plane given a callable returning its exact order statistics (prev, next)."""
-    from numpy.lib import _function_base_impl as fb
+    fb = _numpy_quantile_impl()
     prev, nxt, gamma = _percentile_plan(n, amax)
     a, b = lo_hi_getter(np.array([prev]), np.array([nxt]))
     return np.float32(a) if gamma is None else fb._lerp(np.float32(a), np.float32(b), gamma)
 
 
-def normalize_image(raw, blur=0, amax=100) -> torch.Tensor:
+def normalize_image(raw, blur=0, amax=100, u16_bits: bool = False) -> torch.Tensor:
     """ImageProcessor._normalize (reference preprocess.py:214-239) on the GPU, bit-identical to the CPU path.
-    ``raw``: (C, H, W) numpy array or torch tensor of any real dtype; returns a fp32 CUDA tensor in [-1, 1]."""
-    from numpy.lib import _function_base_impl as fb
+    ``raw``: (C, H, W) numpy array or torch tensor of any real dtype; returns a fp32 CUDA tensor in [-1, 1].
+    ``u16_bits``: a torch.int16 tensor holds uint16 pixel BITS (how a device-resident uint16 image is carried, torch having no
+    uint16 arithmetic); without the flag int16 data is signed and converted by value like every other dtype."""
+    fb = _numpy_quantile_impl()
     dev = _lib.require_gpu()
     if isinstance(raw, np.ndarray):
         if raw.dtype == np.uint16:
@@ -319,8 +336,10 @@ def normalize_image(raw, blur=0, amax=100) -> torch.Tensor:
             check(lib().ribca_u16_to_f32(ptr(src), ptr(img), src.numel(), stream_ptr()), "ribca_u16_to_f32")
         else:
             img = torch.from_numpy(raw.astype(np.float32)).to(dev)
-    elif raw.dtype in (torch.int16, torch.uint16):       # uint16 pixels already resident on the device (int16 = same bits)
+    elif raw.dtype == torch.uint16 or (raw.dtype == torch.int16 and u16_bits):     # uint16 pixels already resident on the device
         src = raw.to(dev).contiguous()
+        if src.dtype == torch.uint16:
+            src = src.view(torch.int16)
         img = torch.empty(tuple(raw.shape), dtype=torch.float32, device=dev)
         check(lib().ribca_u16_to_f32(ptr(src), ptr(img), src.numel(), stream_ptr()), "ribca_u16_to_f32")
     else:
@@ -353,8 +372,12 @@ def normalize_image(raw, blur=0, amax=100) -> torch.Tensor:
                 m = min(m, np.float32(t))
             mode[p] = 1
             denom[p] = max(25, m)                 # preprocess.py:238
-    check(lib().ribca_norm_finalize(ptr(img), c, hw, ptr(torch.from_numpy(mode).to(dev)), ptr(torch.from_numpy(clip).to(dev)),
-                                    ptr(torch.from_numpy(denom).to(dev)), stream_ptr()), "ribca_norm_finalize")
+    # one named tensor per argument: a temporary would be returned to the caching allocator (and its block handed to the next
+    # .to(dev)) before the kernel that reads it is enqueued
+    mode_d = torch.from_numpy(mode).to(dev)
+    clip_d = torch.from_numpy(clip).to(dev)
+    denom_d = torch.from_numpy(denom).to(dev)
+    check(lib().ribca_norm_finalize(ptr(img), c, hw, ptr(mode_d), ptr(clip_d), ptr(denom_d), stream_ptr()), "ribca_norm_finalize")
     return img
 
 
@@ -550,8 +573,10 @@ def vote(p_a: torch.Tensor, map_a: Sequence[int], p_b: Optional[torch.Tensor], m
     ma = torch.tensor(list(map_a), dtype=torch.int8, device=dev)
     mb = torch.tensor(list(map_b), dtype=torch.int8, device=dev) if p_b is not None else None
     tc = torch.tensor([float(np.float32(v)) for v in type_conf], dtype=torch.float32, device=dev)
-    check(lib().ribca_vote(ptr(p_a.contiguous()), p_a.shape[1], ptr(ma), ptr(p_b.contiguous()) if p_b is not None else None,
-                           p_b.shape[1] if p_b is not None else 0, ptr(mb), ptr(tc), float(np.float32(conf)), n, ptr(label),
+    pa_c = p_a.contiguous()                                   # named: only tensors that outlive the call cross the ABI
+    pb_c = p_b.contiguous() if p_b is not None else None
+    check(lib().ribca_vote(ptr(pa_c), pa_c.shape[1], ptr(ma), ptr(pb_c) if pb_c is not None else None,
+                           pb_c.shape[1] if pb_c is not None else 0, ptr(mb), ptr(tc), float(np.float32(conf)), n, ptr(label),
                            ptr(out_conf), stream_ptr()), "ribca_vote")
     return label, out_conf
 

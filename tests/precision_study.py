@@ -1,0 +1,230 @@
+"""Precision study for the matrix-core operand formats of the ViT forward (test infrastructure; not collected by pytest).
+
+Emulates, on the CPU oracle ViT (``oracle.ref_vit``), what each candidate operand format of the HIP GEMM / attention
+kernels does to the per-cell softmax confidences, against the plain fp32 forward (the reference's CPU path,
+``cell_type_annotation/model.py:397-406``).  Every matrix product  C = A . B^T  of the block (qkv, Q.K^T, P.V, proj, fc1,
+fc2) is replaced by the scheme's sum of reduced-precision products, accumulated in fp32; the residual stream, LayerNorm,
+softmax and GELU stay fp32, as in the kernels.
+
+    python tests/precision_study.py --cells 256 --models immune_base immune_full --schemes bf16x3 f16_bf8t ...
+
+Schemes (x = h + l:  h = round16(x), l = x - h;  h' = low-precision copy of h used only against the other side's l):
+    bf16        h.h                      h = bf16                       1 MFMA pass
+    f16         h.h                      h = fp16                       1 pass
+    bf16x3      h.h + l.h + h.l          h, l = bf16                    3 passes   (round-1 production path)
+    f16x3       h.h + l.h + h.l          h, l = fp16                    3 passes
+    f16_bf8t    h.h + l8.h' + h'.l8      h = fp16, h' = high byte of h (e5m2, truncated), l8 = e5m2(2^12 l)    1 + 2 x 1/2
+    f16_bf8r    same, h' rounded to nearest e5m2
+    f16_fp8     same, h' = e4m3(h) l8 = e4m3(2^12 l)
+    f16_fp6     same, h' and l as MX e2m3 with one power-of-two scale per 32 k                                 1 + 2 x 1/4
+    f16_fp6t    fp6 l, h' = high byte (e5m2 truncation)  -- mixed fp8 x fp6 MFMA (fp8 rate)
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multiplexed_image_annotator_amd import synth  # noqa: E402
+from oracle import ref_vit  # noqa: E402
+
+LO_SCALE = 4096.0  # 2^12: l of an fp16-rounded value is below 2^-11 |x|
+
+
+def r_bf16(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def r_f16(x):
+    return x.to(torch.float16).to(torch.float32)
+
+
+def r_e5m2(x):
+    return x.clamp(-57344.0, 57344.0).to(torch.float8_e5m2).to(torch.float32)
+
+
+def r_e4m3(x):
+    return x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+
+
+def t_e5m2_of_f16(h):
+    """high byte of the fp16 encoding = the value truncated (toward zero) to e5m2"""
+    bits = h.to(torch.float16).view(torch.int16)
+    return (bits & -256).view(torch.float16).to(torch.float32)
+
+
+def mx_e2m3(x, block=32):
+    """OCP MX fp6 (e2m3): per ``block`` consecutive k one power-of-two scale 2^(floor(log2 max) - 2); elements rounded to
+    nearest on the e2m3 grid (subnormal step 1/8, max 7.5, saturating)."""
+    k = x.shape[-1]
+    pad = (-k) % block
+    xp = F.pad(x, (0, pad)) if pad else x
+    xb = xp.reshape(*xp.shape[:-1], -1, block)
+    amax = xb.abs().amax(dim=-1, keepdim=True)
+    e = torch.floor(torch.log2(torch.where(amax > 0, amax, torch.ones_like(amax)))) - 2.0
+    scale = torch.exp2(e)
+    y = (xb / scale).clamp(-7.5, 7.5)
+    ay = y.abs()
+    ex = torch.floor(torch.log2(torch.where(ay >= 1.0, ay, torch.ones_like(ay))))      # 0, 1, 2 for normals; subnormals use 0
+    step = torch.exp2(ex - 3.0)
+    q = torch.round(ay / step) * step        # round half to even on the grid
+    q = torch.sign(y) * q.clamp(max=7.5)
+    out = (q * scale).reshape(*xp.shape)
+    return out[..., :k] if pad else out
+
+
+def split(x, scheme):
+    """-> (h, hp, l): main operand, its low-precision copy, low-precision remainder (all fp32 values)."""
+    if scheme == "bf16":
+        return r_bf16(x), None, None
+    if scheme == "f16":
+        return r_f16(x), None, None
+    if scheme == "bf16x3":
+        h = r_bf16(x)
+        return h, h, r_bf16(x - h)
+    if scheme == "f16x3":
+        h = r_f16(x)
+        return h, h, r_f16(x - h)
+    h = r_f16(x)
+    l = x - h
+    if scheme == "f16_bf8t":
+        return h, t_e5m2_of_f16(h), r_e5m2(l * LO_SCALE) / LO_SCALE
+    if scheme == "f16_bf8r":
+        return h, r_e5m2(h), r_e5m2(l * LO_SCALE) / LO_SCALE
+    if scheme == "f16_fp8":
+        return h, r_e4m3(h), r_e4m3(l * LO_SCALE) / LO_SCALE
+    if scheme == "f16_bf8t_fp8":        # h' = truncated high byte, l = e4m3
+        return h, t_e5m2_of_f16(h), r_e4m3(l * LO_SCALE) / LO_SCALE
+    if scheme == "f16_fp6":
+        return h, mx_e2m3(h), mx_e2m3(l)
+    if scheme == "f16_fp6t":
+        return h, t_e5m2_of_f16(h), mx_e2m3(l)
+    raise ValueError(scheme)
+
+
+# Per-tensor allocation study: scheme "alloc:<spec>" with <spec> = comma list of tensor=format, tensors x1 wqkv q k v p o wproj x2 w1
+# hh w2 (default format "full"), formats:  full = f16 h + e5m2 l (3 bytes), used against the other side's exact h;
+# h = f16 only (2 bytes);  full4 = f16 h + e4m3 l;  full16 = f16 h + f16 l.
+ALLOC = {}
+
+
+def split_alloc(x, fmt):
+    h = r_f16(x)
+    if fmt == "h":
+        return h, None
+    l = x - h
+    if fmt == "full":
+        return h, r_e5m2(l * LO_SCALE) / LO_SCALE
+    if fmt == "full4":
+        return h, r_e4m3(l * LO_SCALE) / LO_SCALE
+    if fmt == "full16":
+        return h, r_f16(l)
+    raise ValueError(fmt)
+
+
+def mm_alloc(a, b, ta, tb):
+    ah, al = split_alloc(a, ALLOC.get(ta, "full"))
+    bh, bl = split_alloc(b, ALLOC.get(tb, "full"))
+    aa, bb = [ah], [bh]
+    if al is not None:
+        aa.append(al)
+        bb.append(bh)
+    if bl is not None:
+        aa.append(ah)
+        bb.append(bl)
+    return torch.cat(aa, dim=-1) @ torch.cat(bb, dim=-1).transpose(-2, -1)
+
+
+def mm(a, b, scheme, ta=None, tb=None):
+    """a (.., m, k) . b (.., n, k)^T under ``scheme``."""
+    if scheme.startswith("alloc"):
+        return mm_alloc(a, b, ta, tb)
+    if scheme == "fp32":
+        return a @ b.transpose(-2, -1)
+    ah, ahp, al = split(a, scheme)
+    bh, bhp, bl = split(b, scheme)
+    if al is None:
+        return ah @ bh.transpose(-2, -1)
+    aa = torch.cat((ah, ahp, al), dim=-1)
+    bb = torch.cat((bh, bl, bhp), dim=-1)
+    return aa @ bb.transpose(-2, -1)
+
+
+@torch.no_grad()
+def logits_scheme(sd, x, scheme, attn_scheme=None):
+    """oracle.ref_vit.logits with every block product under ``scheme`` (patch embedding and head stay fp32 as in the kernels:
+    embed_f32_kernel / head_softmax_kernel)."""
+    attn_scheme = attn_scheme or scheme
+    heads = ref_vit.HEADS
+    b = x.shape[0]
+    d = sd["cls_token"].shape[-1]
+    hd = d // heads
+    t = ref_vit.patch_embed(sd, x)
+    z = torch.cat((sd["cls_token"].expand(b, -1, -1), t), dim=1) + sd["pos_embed"]
+    n = z.shape[1]
+    for i in range(ref_vit.depth_of(sd)):
+        p = f"blocks.{i}."
+        y = F.layer_norm(z, (d,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], ref_vit.LN_EPS)
+        qkv = mm(y, sd[p + "attn.qkv.weight"], scheme, "x1", "wqkv") + sd[p + "attn.qkv.bias"]
+        qkv = qkv.reshape(b, n, 3, heads, hd).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0] * hd ** -0.5, qkv[1], qkv[2]
+        att = mm(q, k, attn_scheme, "q", "k").softmax(dim=-1)
+        y = mm(att, v.transpose(-2, -1), attn_scheme, "p", "v").transpose(1, 2).reshape(b, n, d)
+        z = z + mm(y, sd[p + "attn.proj.weight"], scheme, "o", "wproj") + sd[p + "attn.proj.bias"]
+        y = F.layer_norm(z, (d,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], ref_vit.LN_EPS)
+        y = F.gelu(mm(y, sd[p + "mlp.fc1.weight"], scheme, "x2", "w1") + sd[p + "mlp.fc1.bias"])
+        z = z + mm(y, sd[p + "mlp.fc2.weight"], scheme, "hh", "w2") + sd[p + "mlp.fc2.bias"]
+    z = F.layer_norm(z, (d,), sd["norm.weight"], sd["norm.bias"], ref_vit.LN_EPS)
+    return z[:, 0] @ sd["head.weight"].t() + sd["head.bias"]
+
+
+def patch_like_inputs(name, n, seed):
+    """same generator as tests/test_oracle_vit.py: background -1, sparse positive signal"""
+    d, c, k = synth.VIT_CONFIGS[name]
+    u = synth.uniform(synth.stream_key(seed, "vitx/" + name), n * c * 1600).reshape(n, c, 40, 40).to(torch.float32)
+    x = u * 2 - 1
+    return torch.where(x > 0.1, x, torch.full_like(x, -1.0))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cells", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--models", nargs="+", default=["immune_base", "immune_full"])
+    ap.add_argument("--schemes", nargs="+", default=["bf16x3", "f16", "f16_bf8t", "f16_bf8r", "f16_fp8", "f16_fp6"])
+    ap.add_argument("--seed", type=int, default=synth.SEED_BASE + 7)
+    args = ap.parse_args()
+    torch.set_num_threads(os.cpu_count() or 1)
+    for name in args.models:
+        sd = synth.make_vit_state_dict(name, args.seed)
+        x = patch_like_inputs(name, args.cells, args.seed + 1)
+        t0 = time.time()
+        ref = torch.cat([F.softmax(ref_vit.logits(sd, x[i:i + args.batch]), dim=1) for i in range(0, args.cells, args.batch)])
+        srt = ref.sort(dim=1, descending=True).values
+        margin = (srt[:, 0] - srt[:, 1])
+        print(f"{name}: {args.cells} cells, fp32 reference {time.time() - t0:.1f} s; top-2 margin min {margin.min():.2e} "
+              f"median {margin.median():.3f}", flush=True)
+        for scheme in args.schemes:
+            t0 = time.time()
+            if scheme.startswith("alloc"):
+                ALLOC.clear()
+                spec = scheme.split(":", 1)[1] if ":" in scheme else ""
+                for item in filter(None, spec.split(",")):
+                    k_, v_ = item.split("=")
+                    for name_ in k_.split("+"):
+                        ALLOC[name_] = v_
+            got = torch.cat([F.softmax(logits_scheme(sd, x[i:i + args.batch], scheme), dim=1)
+                             for i in range(0, args.cells, args.batch)])
+            dp = (got - ref).abs()
+            flips = int((got.argmax(1) != ref.argmax(1)).sum())
+            print(f"  {scheme:14s} max|dp| {dp.max():.2e}  mean|dp| {dp.mean():.2e}  p99.9 {dp.flatten().quantile(0.999):.2e}  "
+                  f"label flips {flips}   ({time.time() - t0:.0f} s)", flush=True)
+
+
+if __name__ == "__main__":
+    main()

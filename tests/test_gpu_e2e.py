@@ -176,12 +176,14 @@ def test_cli_single_image(tmp_path, golden_dir):
         mdir = "src/multiplexed_image_annotator/cell_type_annotation/models"      # CWD-relative, as in the reference
         os.makedirs(mdir)
         torch.save({"model": sd}, os.path.join(mdir, "immune_base.pth"))
-        args = cli.parse_args(["--marker-list-path", mf, "--image-path", str(tmp_path / "img.npy"), "--mask-path", str(tmp_path / "mask.npy"),
-                               "--batch-id", "g", "--main-dir", str(tmp_path / "out"), "--strict", "--no-infer", "--bs", "8"])
-        cli.run(args)
+        intensity, names = cli.main(["--marker-list-path", mf, "--image-path", str(tmp_path / "img.npy"), "--mask-path", str(tmp_path / "mask.npy"),
+                                     "--batch-id", "g", "--main-dir", str(tmp_path / "out"), "--strict", "--no-infer", "--bs", "8"])
     finally:
         os.chdir(cwd)
     csv_equal_up_to_conf(open(tmp_path / "out" / "results" / "g_annotation_0.csv").read(), meta["csv"], 1.5e-3)
+    # reference main.run returns (intensity_dict, names): key 0 = zeros, key i + 1 = intensity row of the i-th cell
+    assert sorted(intensity) == list(range(meta["cells"] + 1)) and not intensity[0].any() and intensity[1].shape == (len(meta["markers"]),)
+    assert names.startswith("1: ")
 
 
 def test_annotator_with_imputation_matches_oracle(tmp_path):
@@ -402,7 +404,7 @@ def test_config3_full_size_properties():
     seed = synth.SEED_BASE + 3
     mask, img = synth.make_mask_and_image(4096, 4096, 100000, 15, seed, device=dev)
     mask = mask.to(torch.int32)
-    image = ops.normalize_image(img.to(torch.int16), blur=0.3, amax=99.8)
+    image = ops.normalize_image(img.to(torch.int16), blur=0.3, amax=99.8, u16_bits=True)
     del img
     ids, tab = ops.label_table(mask)
     n = len(ids)

@@ -32,7 +32,7 @@ def timed(fn, reps=3):
     return best, out
 
 
-t_norm, image = timed(lambda: ops.normalize_image(raw, blur=0.3, amax=99.8))
+t_norm, image = timed(lambda: ops.normalize_image(raw, blur=0.3, amax=99.8, u16_bits=True))
 t_lab, (ids, tab) = timed(lambda: ops.label_table(mask))
 n = len(ids)
 t_min, cmin = timed(lambda: ops.channel_min(image))
