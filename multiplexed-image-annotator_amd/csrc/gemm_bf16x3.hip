@@ -53,7 +53,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 // that loads, waits and stores per tile costs one L2/HBM round trip per tile (16 dependent round trips ~ 11 us per
 // 256 x 128 tile, as much as 14 K-steps of MFMAs).
 struct EpiResid {
-  float* z; int ldz; const float* bias; int M, N;
+  float* z; int ldz; const float* bias; int M, N; int nt = 0;
   struct Ctx { float4 zv; };
   __device__ __forceinline__ float4 fetch_bias(int n) const {
     return n < N ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
@@ -64,14 +64,16 @@ struct EpiResid {
   template <int PX = 16>
   __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx& c) const {
     if (m >= M || n >= N) return;
-    float4 o;
-    o.x = c.zv.x + (v[0] + b.x); o.y = c.zv.y + (v[1] + b.y); o.z = c.zv.z + (v[2] + b.z); o.w = c.zv.w + (v[3] + b.w);
-    *reinterpret_cast<float4*>(z + (size_t)m * ldz + n) = o;
+    f32x4 o;
+    o[0] = c.zv.x + (v[0] + b.x); o[1] = c.zv.y + (v[1] + b.y); o[2] = c.zv.z + (v[2] + b.z); o[3] = c.zv.w + (v[3] + b.w);
+    f32x4* dst = reinterpret_cast<f32x4*>(z + (size_t)m * ldz + n);
+    if (nt) __builtin_nontemporal_store(o, dst);
+    else *dst = o;
   }
 };
 
 struct EpiGelu {
-  uint16_t* out; int ldo; const float* bias; int M, N;
+  uint16_t* out; int ldo; const float* bias; int M, N; int nt = 0;
   struct Ctx {};
   __device__ __forceinline__ float4 fetch_bias(int n) const {
     return n < N ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
@@ -81,13 +83,14 @@ struct EpiGelu {
   __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx&) const {
     if (m >= M || n >= N) return;
     float t[4] = {gelu_erf(v[0] + b.x), gelu_erf(v[1] + b.y), gelu_erf(v[2] + b.z), gelu_erf(v[3] + b.w)};
-    ps_store4_pair<PX>(out + (size_t)m * ldo, n, t);      // N % 8 == 0: the partner lane (n ^ 4, same m) passed the same guard
+    ps_store4_pair<PX>(out + (size_t)m * ldo, n, t, nt != 0);      // N % 8 == 0: the partner lane (n ^ 4, same m) passed the same guard
   }
 };
 
 struct EpiQKV {
   uint16_t* q; uint16_t* k; uint16_t* vt; const float* bias; int D, hd, hdp /* stored dims per Q/K row = AttnGeom::hdq */, hdv; float scale; int M, N;
   int T, TP, H, KP;   // tokens per cell, padded token rows of Q/K, heads, padded keys per V^T row
+  int nt = 0;
   struct Ctx {};
   // row / column decompositions are computed once per accumulator row (4) and column group (TN), not once per tile
   struct Row { int cell, t, vpos; };
@@ -124,7 +127,7 @@ struct EpiQKV {
         for (int i = 0; i < 4; ++i) x[i] *= scale;
       }
       uint16_t* rowp = (c.which == 0 ? q : k) + (ch * TP + r.t) * (size_t)(2 * hdp);
-      if ((hd & 7) == 0) ps_store4_pair<PX>(rowp, c.d, x);   // the partner lane's 4 columns are in the same head
+      if ((hd & 7) == 0) ps_store4_pair<PX>(rowp, c.d, x, nt != 0);   // the partner lane's 4 columns are in the same head
       else ps_store4(rowp, c.d, x);
     } else {
       uint2 hi, lo;
@@ -563,14 +566,19 @@ static void launch_any(const GemmArgs& g, const Epi& epi, hipStream_t s) {
   }
 }
 
+// RIBCA_NT bit 0: fc1 (GELU) output, bit 1: Q / K rows, bit 2: residual z  -- non-temporal epilogue stores (A/B switch)
+static int nt_mask() {
+  static const int m = getenv("RIBCA_NT") ? atoi(getenv("RIBCA_NT")) : 0;
+  return m;
+}
 void launch_gemm_resid(const GemmArgs& g, float* z, int ldz, hipStream_t s) {
-  launch_any(g, EpiResid{z, ldz, g.bias, g.M, g.N}, s);
+  launch_any(g, EpiResid{z, ldz, g.bias, g.M, g.N, (nt_mask() >> 2) & 1}, s);
 }
 void launch_gemm_gelu(const GemmArgs& g, uint16_t* out, int ldo, hipStream_t s) {
-  launch_any(g, EpiGelu{out, ldo, g.bias, g.M, g.N}, s);
+  launch_any(g, EpiGelu{out, ldo, g.bias, g.M, g.N, nt_mask() & 1}, s);
 }
 void launch_gemm_qkv(const GemmArgs& g, uint16_t* q, uint16_t* k, uint16_t* vt, const AttnGeom& a, float scale, hipStream_t s) {
-  launch_any(g, EpiQKV{q, k, vt, g.bias, a.D, a.hd, a.hdq /* Q/K row pitch: compact */, a.hdv, scale, g.M, g.N, a.T, a.TP, a.H, a.KP}, s);
+  launch_any(g, EpiQKV{q, k, vt, g.bias, a.D, a.hd, a.hdq /* Q/K row pitch: compact */, a.hdv, scale, g.M, g.N, a.T, a.TP, a.H, a.KP, (nt_mask() >> 1) & 1}, s);
 }
 void launch_gemm_rowmap(const GemmArgs& g, float* out, int ldo, const float* add, int ldadd, const int* slot, const int* addrow, int R,
                         int dst_per_cell, hipStream_t s) {

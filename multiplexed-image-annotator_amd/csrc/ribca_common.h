@@ -66,8 +66,9 @@ __device__ __forceinline__ void ps_store4(uint16_t* row, int k, const float v[4]
 // same, for a lane pair (lane, lane ^ PX) that together owns the 8 columns of one PS group (k % 4 == 0; the even lane holds
 // k % 8 == 0): the pair swaps halves so that each lane writes ONE 16-byte vector (all 8 hi, or all 8 lo) instead of two
 // 8-byte pieces -- half the store instructions and 64 contiguous bytes per row and instruction.  Both lanes must be active.
+typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t u32x4;
 template <int PX>
-__device__ __forceinline__ void ps_store4_pair(uint16_t* row, int k, const float v[4]) {
+__device__ __forceinline__ void ps_store4_pair(uint16_t* row, int k, const float v[4], bool nt = false) {
   uint2 hi, lo;
   split4(v, hi, lo);
   const bool odd = (k & 4) != 0;
@@ -75,8 +76,10 @@ __device__ __forceinline__ void ps_store4_pair(uint16_t* row, int k, const float
   uint2 recv;
   recv.x = __shfl_xor(send.x, PX, 64);
   recv.y = __shfl_xor(send.y, PX, 64);
-  const uint4 o = odd ? uint4{recv.x, recv.y, lo.x, lo.y} : uint4{hi.x, hi.y, recv.x, recv.y};
-  *reinterpret_cast<uint4*>(row + ps_off(k & ~7) + (odd ? 8 : 0)) = o;
+  const u32x4 o = odd ? u32x4{recv.x, recv.y, lo.x, lo.y} : u32x4{hi.x, hi.y, recv.x, recv.y};
+  u32x4* dst = reinterpret_cast<u32x4*>(row + ps_off(k & ~7) + (odd ? 8 : 0));
+  if (nt) __builtin_nontemporal_store(o, dst);      // streamed once, read by a later launch: keep it out of this XCD's L2
+  else *dst = o;
 }
 
 __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {

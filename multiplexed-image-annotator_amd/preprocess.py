@@ -25,10 +25,21 @@ from . import _lib, ops
 
 
 def read_image(path: str) -> np.ndarray:
-    """Image / mask reader (the reference uses skimage.io.imread, preprocess.py:244-246): .npy, multi-page TIFF, PNG."""
+    """Image / mask reader standing in for ``skimage.io.imread`` (reference preprocess.py:244-246), which hands ``.tif`` files to
+    tifffile: a multi-page TIFF comes back as (pages, H, W) in page order, a PNG as (H, W) or (H, W, samples).  ``tifffile`` is used
+    when it is installed (it also reads the planar / OME / BigTIFF layouts PIL cannot); otherwise PIL page by page.  ``.npy`` is an
+    extension of this package (device-ready arrays)."""
     p = str(path)
-    if p.endswith(".npy"):
+    low = p.lower()
+    if low.endswith(".npy"):
         return np.load(p)
+    if low.endswith((".tif", ".tiff")):
+        try:
+            import tifffile
+        except ImportError:
+            tifffile = None
+        if tifffile is not None:
+            return np.asarray(tifffile.imread(p))
     from PIL import Image
     im = Image.open(p)
     frames = getattr(im, "n_frames", 1)
@@ -37,8 +48,20 @@ def read_image(path: str) -> np.ndarray:
         for i in range(frames):
             im.seek(i)
             planes.append(np.array(im))
+        if len({pl.shape for pl in planes}) != 1:
+            raise ValueError(f"{p}: pages of different shapes cannot be stacked into (C, H, W)")
         return np.stack(planes, axis=0)
     return np.array(im)
+
+
+def as_channel_planes(image: np.ndarray, path: str = "") -> np.ndarray:
+    """The hot path indexes the image as (C, H, W) (reference preprocess.py:214-239 loops ``for i in range(img.shape[0])``): a single
+    2-D page becomes one plane; anything that is not 3-D afterwards is rejected here instead of failing inside a kernel."""
+    if image.ndim == 2:
+        image = image[None]
+    if image.ndim != 3:
+        raise ValueError(f"{path}: expected an image of shape (C, H, W), got {image.shape}")
+    return image
 
 
 class LazyCellPositions(Mapping):
@@ -153,7 +176,7 @@ class ImageProcessor(object):
         ``gather_fn(local (n_local, C) fp64 tensor, n) -> (n, C)`` reassembles per-cell rows across ranks."""
         dev = _lib.require_gpu()
         for i, (image_path, mask_path) in enumerate(zip(self.image_paths, self.mask_paths)):
-            image = read_image(image_path)
+            image = as_channel_planes(read_image(image_path), image_path)
             mask = read_image(mask_path)
             if mask.ndim == 3:
                 mask = mask[:, :, 0]                      # the reference assumes the first channel holds the labels

@@ -324,6 +324,39 @@ def make_mask_and_image(h: int, w: int, n_cells: int, n_channels: int, seed: int
     return mask.to(torch.int32), acc.clamp(0, 65535).to(torch.int32)
 
 
+def make_image_for_mask(mask: torch.Tensor, n_channels: int, seed: int, positive_frac: float = 0.3) -> torch.Tensor:
+    """Raw image ``(C, H, W)`` (int32 tensor holding uint16 values) for a GIVEN label mask (e.g. the reference's
+    ``examples/example_1_cell_mask.png``, BASELINE config 1 stand-in): every (label, channel) is positive with probability
+    ``positive_frac`` with a flat in-cell intensity drawn like ``make_mask_and_image``'s peaks (200 .. 12800), on the same kind of
+    smooth hashed background + noise.  Counter-based hashes only: identical on every box."""
+    device = mask.device
+    h, w = mask.shape
+    top = int(mask.max()) + 1
+    cc = torch.arange(top * n_channels, dtype=torch.int64, device=device)
+    pos = hash_u24(stream_key(seed, "gimg/pos"), cc) < int(positive_frac * (1 << 24))
+    e = hash_u24(stream_key(seed, "gimg/peak"), cc)
+    octv = (e >> 21) % 6
+    mant = e & ((1 << 21) - 1)
+    peak = (200 << octv) + (((200 << octv) * mant) >> 21)
+    peak = torch.where(pos, peak, torch.zeros_like(peak)).reshape(top, n_channels)
+    peak[0] = 0
+    acc = peak[mask.to(torch.int64)].permute(2, 0, 1).contiguous()
+    ys = torch.arange(h, dtype=torch.int64, device=device)
+    xs = torch.arange(w, dtype=torch.int64, device=device)
+    pitch = 64
+    ly, lx = h // pitch + 2, w // pitch + 2
+    fy, fx = (ys % pitch)[:, None], (xs % pitch)[None, :]
+    iy, ix = (ys // pitch)[:, None], (xs // pitch)[None, :]
+    for c in range(n_channels):
+        lat = 50 + (hash_u24(stream_key(seed, "gimg/bg", c), torch.arange(ly * lx, dtype=torch.int64, device=device)) * 301 >> 24)
+        lat = lat.reshape(ly, lx)
+        bg = (lat[iy, ix] * (pitch - fy) * (pitch - fx) + lat[iy, ix + 1] * (pitch - fy) * fx + lat[iy + 1, ix] * fy * (pitch - fx)
+              + lat[iy + 1, ix + 1] * fy * fx) // (pitch * pitch)
+        pix = (ys[:, None] * w + xs[None, :]) + c * h * w
+        acc[c] += bg + (hash_u24(stream_key(seed, "gimg/noise"), pix) * 31 >> 24)
+    return acc.clamp(0, 65535).to(torch.int32)
+
+
 FULL_PANEL_MARKERS: List[str] = ['DAPI', 'CD3', 'CD4', 'CD8', 'CD11c', 'CD15', 'CD20', 'CD45', 'CD56', 'CD68', 'CD138',
                                  'CD163', 'FoxP3', 'Granzyme B', 'Trypase']
 BASIC_PANEL_MARKERS: List[str] = ['CD45', 'CD20', 'CD4', 'CD8', 'DAPI', 'CD11c', 'CD3']

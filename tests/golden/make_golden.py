@@ -161,6 +161,10 @@ def golden_cellpos():
     d2 = pre.ImageProcessor._cell_pos_dict(dummy, ex, n_jobs=0)
     out["example2_mask"] = ex.astype(np.uint16)
     out["example2_ids"], out["example2_table"] = table_from_dict(d2)
+    ex1 = np.array(Image.open(os.path.join(REF, "examples/example_1_cell_mask.png"))).astype(np.int32)    # BASELINE config 1 mask (1850 cells)
+    d1 = pre.ImageProcessor._cell_pos_dict(dummy, ex1, n_jobs=0)
+    out["example1_mask"] = ex1.astype(np.uint16)
+    out["example1_ids"], out["example1_table"] = table_from_dict(d1)
     ms, _ = synth.make_mask_and_image(160, 200, 60, 1, synth.SEED_BASE + 111, want_image=False)
     d3 = pre.ImageProcessor._cell_pos_dict(dummy, ms.numpy(), n_jobs=0)
     out["synth_ids"], out["synth_table"] = table_from_dict(d3)
@@ -518,6 +522,62 @@ def golden_e2e():
     print("e2e", {k: len(v["labels"]) for k, v in meta.items()})
 
 
+# ---------------------------------------------------------------------------------------------- BASELINE config 1 stand-in
+def golden_config1():
+    """BASELINE.json configs[0] stand-in (examples/example_1.tif is a missing blob): the reference's own
+    ``Annotator`` on ``examples/example_1_cell_mask.png`` (600 x 600, 1850 cells) + a synthetic 7-channel image in Basic-panel
+    marker order, strict, blur 0.3, amax 99.8, confidence 0.3, ``predict(8)``, device cpu -- reference main.py:9-36."""
+    from PIL import Image
+    model = ref("model")
+    seed = synth.SEED_BASE + 1            # config k uses seed base + k (SURVEY 8(d))
+    markers = synth.BASIC_PANEL_MARKERS
+    mask = np.array(Image.open(os.path.join(REF, "examples/example_1_cell_mask.png"))).astype(np.int32)
+    img = synth.make_image_for_mask(torch.from_numpy(mask), len(markers), seed).numpy().astype(np.uint16)
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)
+    try:
+        mdir = "src/multiplexed_image_annotator/cell_type_annotation/models"
+        os.makedirs(mdir)
+        sd = synth.make_vit_state_dict("immune_base", seed)
+        torch.save({"model": sd}, os.path.join(mdir, "immune_base.pth"))
+        np.save("img.npy", img)
+        np.save("mask.npy", mask)
+        with open("markers.txt", "w") as f:
+            f.write("\n".join(markers) + "\n")
+        with open("images.csv", "w") as f:
+            f.write("image_path,mask_path\nimg.npy,mask.npy\n")
+        a = model.Annotator("markers.txt", "images.csv", "cpu", "./", "c1", True, False, -1, True, 0.3, 99.8, 0.3, 30, None, n_jobs=0)
+        a.preprocess()
+        net = build_ref_model(model, "immune_base")
+        net.load_state_dict(sd)
+        net.eval()
+        x = torch.load(os.path.join("tmp", "c1_0_immune_base_batch_0.pt"))
+        with torch.no_grad():
+            feats = torch.cat([net.forward_features(x[i:i + 128]) for i in range(0, x.shape[0], 128)])
+        sd["head.bias"] = synth.calibrate_head_bias(sd, feats)
+        torch.save({"model": sd}, os.path.join(mdir, "immune_base.pth"))
+        a.predict(8)
+        a.export_annotations()
+        a.logger.close()
+        names = ["B cell", "CD4 T cell", "CD8 T cell", "Others", "Dendritic cell"]
+        probs = np.array([[d[k] for k in names] for d in a.immune_base_pred[0]], np.float32)
+        csv = open("results/c1_annotation_0.csv").read()
+        meta = {"markers": markers, "seed": seed, "cells": len(a.annotations[0]), "labels": list(a.annotations[0]),
+                "cell_types": [str(s) for s in a.cell_types], "csv": csv, "img_sha": sha(img), "mask_sha": sha(mask),
+                "strict": True, "blur": 0.3, "amax": 99.8, "conf": 0.3, "batch_size": 8}
+        np.savez_compressed(os.path.join(HERE, "config1.npz"), head_bias=sd["head.bias"].numpy(), probs=probs,
+                            conf=np.array([np.float32(c) for c in a.confidence[0]], np.float32), intensity=a.preprocessor.intensity_full[0])
+        with open(os.path.join(HERE, "config1.json"), "w") as f:
+            json.dump(meta, f, indent=0, sort_keys=True)
+        srt = np.sort(probs, axis=1)
+        print("config1", meta["cells"], "cells;", {t: meta["labels"].count(t) for t in set(meta["labels"])},
+              "min top-2 margin %.2e" % float((srt[:, -1] - srt[:, -2]).min()))
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp)
+
+
 # ---------------------------------------------------------------------------------------------- colorize (SURVEY 8(f) rank 4)
 def golden_colorize():
     """Annotator.colorize (model.py:806-858) and utils.get_colors / number_to_rgb, driven with the labels / confidences of the
@@ -685,6 +745,6 @@ def golden_mae():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["normalize", "cellpos", "patches", "patches_scaled", "parser", "vote", "vit", "e2e", "mae", "colorize", "neighborhood", "tissue"]
+    which = sys.argv[1:] or ["normalize", "cellpos", "patches", "patches_scaled", "parser", "vote", "vit", "e2e", "mae", "colorize", "neighborhood", "tissue", "config1"]
     for w in which:
         globals()["golden_" + w]()

@@ -1,0 +1,46 @@
+"""bench.py's own N-rank launch path: ``--gpus N`` without WORLD_SIZE must start N ranks itself, and a
+rank count that does not match ``--gpus`` must fail instead of printing a mislabeled line.  ``--launch-check`` runs the
+rendezvous + the padded all-gather of dist.all_gather_rows only, so this runs on the CPU (gloo)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env():
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["RIBCA_DIST_BACKEND"] = "gloo"
+    return env
+
+
+def _last_json(stdout: str) -> dict:
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert lines, stdout
+    return json.loads(lines[-1])
+
+
+def test_gpus2_launches_two_ranks():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=_env(), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _last_json(r.stdout)
+    assert out["n_gpus"] == 2 and out["gather_ok"] is True
+
+
+def test_gpus1_stays_in_process():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--launch-check"], env=_env(), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _last_json(r.stdout)["n_gpus"] == 1
+
+
+def test_rank_count_mismatch_is_an_error():
+    env = _env()
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr

@@ -429,3 +429,58 @@ def test_config3_full_size_properties():
             ref = ref_vit.predict_proba(sd, x, 8)
             assert (p_part[:24].cpu() - ref).abs().max().item() < 1e-3 and torch.equal(p_part[:24].cpu().argmax(1), ref.argmax(1))
         del model, p_full
+
+
+def test_tiff_and_png_inputs_match_reference_golden(golden_dir, tmp_path):
+    """The reference reads a multi-channel TIFF and a label PNG (preprocess.py:244-250).  Same tile as the 'basic' golden, written
+    as a 7-page uint16 TIFF and as an (H, W, 3) uint8 PNG whose first channel holds the labels (40 cells < 256): the CSV must be
+    the reference's."""
+    from PIL import Image
+    from multiplexed_image_annotator_amd.annotator import Annotator
+    meta = json.load(open(os.path.join(golden_dir, "e2e.json")))["basic"]
+    arrs = np.load(os.path.join(golden_dir, "e2e.npz"))
+    mask, img = synth.make_mask_and_image(meta["h"], meta["w"], meta["cells"], len(meta["markers"]), meta["seed"])
+    raw = img.numpy().astype(np.uint16)
+    pages = [Image.fromarray(p) for p in raw]
+    pages[0].save(tmp_path / "img.tif", save_all=True, append_images=pages[1:])
+    m8 = mask.numpy().astype(np.uint8)
+    assert int(mask.max()) < 256
+    Image.fromarray(np.stack([m8, 255 - m8, np.zeros_like(m8)], axis=-1)).save(tmp_path / "mask.png")
+    (tmp_path / "markers.txt").write_text("\n".join(meta["markers"]) + "\n")
+    (tmp_path / "images.csv").write_text(f"image_path,mask_path\n{tmp_path / 'img.tif'},{tmp_path / 'mask.png'}\n")
+    sd = synth.make_vit_state_dict("immune_base", meta["seed"])
+    sd["head.bias"] = torch.from_numpy(arrs["basic__head_bias_immune_base"])
+    a = Annotator(str(tmp_path / "markers.txt"), str(tmp_path / "images.csv"), "cuda", str(tmp_path), "g", meta["strict"], False, -1, True,
+                  meta["blur"], meta["amax"], meta["conf"], 30, None)
+    a.set_weights({"immune_base": sd})
+    a.preprocess()
+    a.predict(8)
+    a.export_annotations()
+    assert a.preprocessor.masks[0].dtype == np.int32 and a.preprocessor.masks[0].ndim == 2
+    assert a.annotations[0] == meta["labels"]
+    csv_equal_up_to_conf(open(tmp_path / "results" / "g_annotation_0.csv").read(), meta["csv"], 1.5e-3)
+    # the reference's own post-predict call sequence (main.py:21-27) completes: plotting steps log and return
+    assert a.generate_heatmap(integrate=True) is None and a.cell_type_composition() is None
+    a.merge_by_voting()
+
+
+def test_config1_matches_reference_golden(golden_dir, tmp_path):
+    """BASELINE.json configs[0] stand-in: the reference's examples/example_1_cell_mask.png (600 x 600, 1850 cells)
+    + seeded 7-channel image, Basic panel, predict(8): labels identical to the reference Annotator's CPU run, confidences < 1e-3."""
+    from multiplexed_image_annotator_amd.annotator import Annotator
+    from test_oracle_e2e import load_config1
+    meta, arrs, raw, mask, weights, mf = load_config1(golden_dir, tmp_path)
+    _, csv = write_case(tmp_path, raw, mask, meta["markers"])
+    a = Annotator(mf, csv, "cuda", str(tmp_path), "c1", True, False, -1, True, meta["blur"], meta["amax"], meta["conf"], 30, None)
+    a.set_weights(weights)
+    a.preprocess()
+    a.predict(meta["batch_size"])
+    a.export_annotations()
+    got = a.probs[0]["immune_base"]
+    err = np.abs(got - arrs["probs"]).max()
+    assert err < 1e-3, err                                   # north-star tolerance
+    assert err < 2e-4, err                                   # what the split-operand MFMA path actually holds
+    assert a.annotations[0] == meta["labels"]                # 1850 cell-type assignments identical (smallest top-2 margin 8e-5)
+    assert [str(s) for s in a.cell_types] == meta["cell_types"]
+    np.testing.assert_allclose(a.preprocessor.intensity_full[0], arrs["intensity"], rtol=1e-12, atol=1e-14)
+    csv_equal_up_to_conf(open(tmp_path / "results" / "c1_annotation_0.csv").read(), meta["csv"], 1.5e-3)

@@ -203,7 +203,8 @@ def test_blank_and_aliased_channels(dev):
 def test_label_table_golden(dev, golden_dir):
     ops = _ops()
     g = np.load(os.path.join(golden_dir, "cellpos.npz"))
-    for key, mask in (("odd", g["odd_mask"]), ("example2", g["example2_mask"].astype(np.int32))):
+    for key, mask in (("odd", g["odd_mask"]), ("example2", g["example2_mask"].astype(np.int32)),
+                      ("example1", g["example1_mask"].astype(np.int32))):       # example1 = BASELINE config 1's mask (1850 cells)
         ids, tab = ops.label_table(torch.from_numpy(mask.astype(np.int32)).to(dev))
         np.testing.assert_array_equal(ids, g[key + "_ids"])
         np.testing.assert_array_equal(tab, g[key + "_table"])

@@ -50,3 +50,39 @@ def test_e2e_matches_reference(golden_dir, tmp_path, name):
         fa, fb = a.split(","), b.split(",")
         assert fa[:2] == fb[:2] and fa[3:] == fb[3:]
         assert abs(float(fa[2]) - float(fb[2])) <= 1.5e-3
+
+
+def load_config1(golden_dir, tmp_path):
+    """BASELINE.json configs[0] stand-in: the reference's example_1 mask (1850 cells, from cellpos.npz) + the seeded 7-channel image."""
+    import torch
+    meta = json.load(open(os.path.join(golden_dir, "config1.json")))
+    arrs = np.load(os.path.join(golden_dir, "config1.npz"))
+    mask = np.load(os.path.join(golden_dir, "cellpos.npz"))["example1_mask"].astype(np.int32)
+    raw = synth.make_image_for_mask(torch.from_numpy(mask), len(meta["markers"]), meta["seed"]).numpy().astype(np.uint16)
+    assert hashlib.sha256(raw.tobytes()).hexdigest() == meta["img_sha"]
+    assert hashlib.sha256(mask.tobytes()).hexdigest() == meta["mask_sha"]
+    sd = synth.make_vit_state_dict("immune_base", meta["seed"])
+    sd["head.bias"] = torch.from_numpy(arrs["head_bias"])
+    mf = tmp_path / "markers.txt"
+    mf.write_text("\n".join(meta["markers"]) + "\n")
+    return meta, arrs, raw, mask, {"immune_base": sd}, str(mf)
+
+
+def test_config1_matches_reference(golden_dir, tmp_path):
+    """The oracle pipeline on BASELINE config 1's stand-in against the reference Annotator's own run of it (CPU, bs = 8)."""
+    import torch
+    torch.set_num_threads(min(8, len(os.sched_getaffinity(0))))
+    meta, arrs, raw, mask, weights, mf = load_config1(golden_dir, tmp_path)
+    r = ref_pipeline.run_image(raw, mask, mf, weights, strict=True, normalize=True, blur=meta["blur"], amax=meta["amax"],
+                               confidence=meta["conf"], batch_size=meta["batch_size"])
+    assert len(r["ids"]) == meta["cells"] == 1850
+    np.testing.assert_allclose(r["probs"]["immune_base"], arrs["probs"], rtol=0, atol=5e-6)
+    assert r["labels"] == meta["labels"]
+    assert [str(s) for s in r["cell_types"]] == meta["cell_types"]
+    np.testing.assert_array_equal(r["intensity"], arrs["intensity"])
+    got, exp = r["csv"].splitlines(), meta["csv"].splitlines()
+    assert len(got) == len(exp) and got[0] == exp[0]
+    for a, b in zip(got[1:], exp[1:]):
+        fa, fb = a.split(","), b.split(",")
+        assert fa[:2] == fb[:2] and fa[3:] == fb[3:]
+        assert abs(float(fa[2]) - float(fb[2])) <= 1.5e-3

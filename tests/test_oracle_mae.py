@@ -31,3 +31,68 @@ def test_mae_matches_reference(golden_dir, panel):
     assert torch.equal(y[:, present], x[:, present])                  # kept channels pass through untouched
     np.testing.assert_allclose(y[:, missing].numpy(), g[panel + "_pred"], rtol=0, atol=5e-5)
     assert np.abs(g[panel + "_pred"]).max() > 0.5                     # predictions are not degenerate
+
+
+def test_mae_matches_hf_implementation():
+    """Independent check of the restated third-party arithmetic (timm PatchEmbed / Block inside the reference's
+    MaskedAutoencoderViT, markerImputer.py:69-232): ``transformers.ViTMAEForPreTraining`` is the same published MAE (conv patch
+    embedding, cls + kept tokens through a pre-LN encoder, mask tokens restored by ids_restore, pre-LN decoder, linear pixel
+    prediction).  Channel tokens are laid out as a 3 x 3 mosaic of 40 x 40 tiles (HF builds its sin-cos tables for square grids
+    only; the tables are overwritten with the state dict's anyway) and the masking is driven by an explicit ``noise``."""
+    transformers = pytest.importorskip("transformers")
+    L, present = 9, [0, 1, 3, 4, 5, 7, 8]
+    missing = [c for c in range(L) if c not in present]
+    seed = synth.SEED_BASE + 311
+    sd = synth.make_mae_state_dict("immune_base", seed, enc_depth=2, dec_depth=2)
+    sd["pos_embed"] = (synth.uniform(synth.stream_key(seed, "hf/pos"), (L + 1) * 768) * 2 - 1).to(torch.float32).reshape(1, L + 1, 768)
+    sd["decoder_pos_embed"] = (synth.uniform(synth.stream_key(seed, "hf/dpos"), (L + 1) * 512) * 2 - 1).to(torch.float32).reshape(1, L + 1, 512)
+    cfg = transformers.ViTMAEConfig(hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=3072, hidden_act="gelu",
+                                    image_size=120, patch_size=40, num_channels=1, decoder_hidden_size=512, decoder_num_hidden_layers=2,
+                                    decoder_num_attention_heads=8, decoder_intermediate_size=2048, mask_ratio=0.2, layer_norm_eps=1e-6,
+                                    qkv_bias=True, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    hf = transformers.ViTMAEForPreTraining(cfg).eval()
+    have = set(hf.state_dict().keys())
+    new_names = "vit.layers.0.attention.q_proj.weight" in have
+    m = {"vit.embeddings.cls_token": sd["cls_token"], "vit.embeddings.position_embeddings": sd["pos_embed"],
+         "vit.embeddings.patch_embeddings.projection.weight": sd["patch_embed.proj.weight"],
+         "vit.embeddings.patch_embeddings.projection.bias": sd["patch_embed.proj.bias"],
+         "vit.layernorm.weight": sd["norm.weight"], "vit.layernorm.bias": sd["norm.bias"],
+         "decoder.mask_token": sd["mask_token"], "decoder.decoder_pos_embed": sd["decoder_pos_embed"],
+         "decoder.decoder_embed.weight": sd["decoder_embed.weight"], "decoder.decoder_embed.bias": sd["decoder_embed.bias"],
+         "decoder.decoder_norm.weight": sd["decoder_norm.weight"], "decoder.decoder_norm.bias": sd["decoder_norm.bias"],
+         "decoder.decoder_pred.weight": sd["decoder_pred.weight"], "decoder.decoder_pred.bias": sd["decoder_pred.bias"]}
+    for src, dst_new, dst_old, d in (("blocks.", "vit.layers.", "vit.encoder.layer.", 768),
+                                     ("decoder_blocks.", "decoder.decoder_layers.", "decoder.decoder_layers.", 512)):
+        for i in range(2):
+            p, q = f"{src}{i}.", (dst_new if new_names else dst_old) + f"{i}."
+            w, b = sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]
+            for j, nm in enumerate(("q_proj", "k_proj", "v_proj") if new_names else ("query", "key", "value")):
+                pre = q + (f"attention.{nm}." if new_names else f"attention.attention.{nm}.")
+                m[pre + "weight"], m[pre + "bias"] = w[j * d:(j + 1) * d], b[j * d:(j + 1) * d]
+            o = q + ("attention.o_proj." if new_names else "attention.output.dense.")
+            m[o + "weight"], m[o + "bias"] = sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"]
+            m[q + "layernorm_before.weight"], m[q + "layernorm_before.bias"] = sd[p + "norm1.weight"], sd[p + "norm1.bias"]
+            m[q + "layernorm_after.weight"], m[q + "layernorm_after.bias"] = sd[p + "norm2.weight"], sd[p + "norm2.bias"]
+            f1 = q + ("mlp.fc1." if new_names else "intermediate.dense.")
+            f2 = q + ("mlp.fc2." if new_names else "output.dense.")
+            m[f1 + "weight"], m[f1 + "bias"] = sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]
+            m[f2 + "weight"], m[f2 + "bias"] = sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"]
+    missing_keys, unexpected = hf.load_state_dict(m, strict=False)
+    assert not missing_keys and not unexpected, (missing_keys, unexpected)
+    n = 5
+    u = synth.uniform(synth.stream_key(seed, "hf/x"), n * L * 1600).reshape(n, L, 40, 40).to(torch.float32) * 2 - 1
+    x = torch.where(u > 0.0, u, torch.full_like(u, -1.0))
+    x[:, missing] = -1.0
+    mosaic = x.reshape(n, 3, 3, 40, 40).permute(0, 1, 3, 2, 4).reshape(n, 1, 120, 120)          # token j at tile (j // 3, j % 3)
+    noise = torch.zeros(n, L)
+    noise[:, present] = torch.arange(len(present), dtype=torch.float32) / 100.0               # kept, in ascending channel order
+    noise[:, missing] = 1.0 + torch.arange(len(missing), dtype=torch.float32)
+    with torch.no_grad():
+        out = hf(pixel_values=mosaic, noise=noise)
+    assert torch.equal(out.mask[0], torch.tensor([0.0 if c in present else 1.0 for c in range(L)]))
+    got = ref_mae.impute(sd, x, present, batch_size=3)
+    ref = out.logits.reshape(n, L, 40, 40)
+    assert torch.equal(got[:, present], x[:, present])
+    err = (got[:, missing] - ref[:, missing]).abs().max().item()
+    assert err < 1e-4, err
+    assert ref[:, missing].abs().max() > 0.3

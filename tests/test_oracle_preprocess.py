@@ -48,6 +48,14 @@ def test_cell_table_example_mask(g_cell):
     np.testing.assert_array_equal(tab, g_cell["example2_table"])
 
 
+def test_cell_table_example1_mask(g_cell):
+    """BASELINE config 1's mask (examples/example_1_cell_mask.png, 1850 cells)."""
+    ids, tab = rp.cell_table(g_cell["example1_mask"].astype(np.int32))
+    assert len(ids) == 1850
+    np.testing.assert_array_equal(ids, g_cell["example1_ids"])
+    np.testing.assert_array_equal(tab, g_cell["example1_table"])
+
+
 def test_cell_positions_scan_order(g_cell):
     d = rp.cell_positions(g_cell["odd_mask"])
     assert list(d.keys()) == g_cell["odd_ids"].tolist()
