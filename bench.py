@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-dropin", action="store_true", help="skip the Annotator (boundary path) timing")
     ap.add_argument("--impute", action="store_true", help="BASELINE config 5: last full-panel marker missing, imputed by the MAE (infer=True)")
     ap.add_argument("--cpu-sample", type=int, default=512, help="cells of the CPU-oracle sample")
+    ap.add_argument("--config1", action="store_true", help="BASELINE configs[0] stand-in (example_1 mask, Basic panel, bs 8): drop-in on the GPU "
+                                                            "beside the CPU oracle timed IN FULL")
     ap.add_argument("--launch-check", action="store_true", help="rendezvous + one all-gather only (no GPU work): CPU test of the N-rank launch path")
     return ap.parse_args()
 
@@ -101,6 +103,8 @@ def main():
     backend = os.environ.get("RIBCA_DIST_BACKEND", "nccl")     # "gloo" + RIBCA_SHARE_GPU=1: rehearsal of the N > 1 path on a 1-GPU box
     if args.launch_check:
         sys.exit(launch_check(args, world, rank, backend))
+    if args.config1:
+        sys.exit(config1_bench(args))
     if world > 1:
         import torch.distributed as tdist
         if os.environ.get("RIBCA_SHARE_GPU") == "1":
@@ -119,20 +123,32 @@ def main():
     from multiplexed_image_annotator_amd.annotator import CLASS_NAMES
     from multiplexed_image_annotator_amd.marker_parse import PANELS
     dev = _lib.require_gpu()
-    seed = synth.SEED_BASE + 3
+    # config 3/4: one tile, seed base + 3, cells sharded over the ranks; config 5 (--impute): one tile PER RANK (seed base + 5 + rank),
+    # replicas only -- no data-path collective
+    seed = synth.SEED_BASE + (5 + rank if args.impute else 3)
+    sharded = world > 1 and not args.impute
 
     # ---- synthetic inputs, generated on the device (bit-identical on every rank) ------------------------------------
     mask, img = synth.make_mask_and_image(args.size, args.size, args.cells, args.channels, seed, device=dev)
     raw = img.to(torch.int16)            # uint16 bit pattern (values < 65536)
     del img
-    markers = synth.FULL_PANEL_MARKERS[:args.channels]
+    markers = list(synth.FULL_PANEL_MARKERS[:args.channels])
+    imputer, imp_present = None, None
+    if args.impute:
+        # BASELINE config 5: the last full-panel marker ('Trypase') is replaced by a marker outside the panel,
+        # so the full panel's index list is [0..13, -1] and the MAE imputer fills the missing plane of every cell (infer=True)
+        if args.channels != 15:
+            raise SystemExit("--impute needs the 15-channel full panel")
+        markers[-1] = "CollagenIV"
+        imputer = ops.MaeModel(synth.make_mae_state_dict("immune_full", seed), dev)
+        imp_present = list(range(14))
     models, srcs = {}, {}
     for name, (d, c, k) in synth.VIT_CONFIGS.items():
         if c > args.channels:
             continue
         models[name] = ops.VitModel(synth.make_vit_state_dict(name, seed), dev)
         panel = {"immune_base": "immune_base", "immune_extended": "immune_extended", "immune_full": "immune_full"}.get(name)
-        if panel and all(m in markers for m in PANELS[panel]):
+        if panel and all(m in markers for m in PANELS[panel]):      # (with --impute the full panel misses one marker: handled in one_pass)
             srcs[name] = [markers.index(m) for m in PANELS[panel]]
         else:
             srcs[name] = list(range(c))  # struct / nerve markers are not in a 15-marker immune panel: fixed synthetic mapping
@@ -141,25 +157,34 @@ def main():
     tc = [-1.0] * 18
     vote_pair = ("immune_full", "struct") if "immune_full" in models and "struct" in models else (next(iter(models)), None)
 
-    def one_pass(streams=None):
+    def one_pass(streams=None, models_sel=None):
         streams = args.streams if streams is None else streams
         image = ops.normalize_image(raw, blur=0.3, amax=99.8, u16_bits=True)
         ids, tab = ops.label_table(mask)
         n = len(ids)
-        lo, hi = dist.shard_bounds(n, rank, world)
+        lo, hi = dist.shard_bounds(n, rank, world) if sharded else (0, n)
         cmin = ops.channel_min(image)
         ids_d = torch.from_numpy(ids[lo:hi].astype(np.int32)).to(dev)
         bb_d = torch.from_numpy(tab[lo:hi, :4].astype(np.int32)).to(dev)
         patches, _ = ops.extract_patches(image, mask, cmin, ids_d, bb_d)
         probs = {}
         for name, model in models.items():
+            if models_sel is not None and name not in models_sel:
+                continue
+            if imputer is not None and name == "immune_full":
+                # reference preprocess.py:268-281: the panel tensor with its missing plane imputed feeds that panel's classifier
+                panel = patches[:, :15].contiguous()
+                imputer.impute(panel, imp_present, chunk_cells=args.chunk)
+                probs[name] = model.predict_proba(panel, list(range(15)), chunk_cells=args.chunk, streams=streams)
+                del panel
+                continue
             probs[name] = model.predict_proba(patches, srcs[name], chunk_cells=args.chunk, streams=streams)
-        if world > 1:       # ONE all-gather per tile: the five models' probability columns side by side (33 floats per cell)
+        if sharded:         # ONE all-gather per tile: the five models' probability columns side by side (33 floats per cell)
             names = list(probs)
             widths = [probs[k].shape[1] for k in names]
             full = dist.all_gather_rows(torch.cat([probs[k] for k in names], dim=1), n)
             probs = {k: t.contiguous() for k, t in zip(names, torch.split(full, widths, dim=1))}
-        a, b = vote_pair
+        a, b = vote_pair if models_sel is None else (next(iter(probs)), None)
         lab, conf = ops.vote(probs[a], [gid[c] for c in CLASS_NAMES[a]], probs[b] if b else None,
                              [gid[c] for c in CLASS_NAMES[b]] if b else None, tc, 0.3)
         return n, lab.cpu(), conf.cpu()
@@ -191,16 +216,26 @@ def main():
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    value = n_cells * args.steps / dt
+    total_cells = n_cells
+    if world > 1 and args.impute:       # replicas: every rank annotated its own tile
+        t = torch.tensor([n_cells], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        tdist.all_reduce(t, op=tdist.ReduceOp.SUM)
+        total_cells = int(t.item())
+    value = total_cells * args.steps / dt
 
     out = {
         "metric": "cells/sec annotated (whole node)", "value": round(value, 2), "unit": "cells/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak" if args.impute else "strong", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"synthetic {args.channels}-ch {args.size}x{args.size} tile, {n_cells} cells, Full Panel, "
-                               f"{len(models)} ViT classifiers per cell (normalise + label table + crop/soft-mask + ViT + vote)",
-                   "cells": n_cells, "models": list(models), "chunk_cells": args.chunk, "segment_streams": args.streams, "precision": "bf16x3 split MFMA, fp32 accumulate",
-                   "parallelism": f"cells sharded over {world} rank(s), all-gather of per-cell probabilities" if world > 1 else "single GPU"},
+                               + ("one marker missing -> MAE imputer (infer=True) + " if args.impute else "")
+                               + f"{len(models)} ViT classifiers per cell (normalise + label table + crop/soft-mask + ViT + vote)",
+                   "baseline_config": "configs[4] (one tile per GPU, imputation)" if args.impute else ("configs[2]" if world == 1 else "configs[3]"),
+                   "cells": n_cells, "models": list(models), "chunk_cells": args.chunk, "segment_streams": args.streams,
+                   "precision": "fp16 hi+lo split operands, 3 MFMA passes per product, fp32 accumulate",
+                   "parallelism": ("single GPU" if world == 1 else f"one tile per rank x {world} (replicas only)" if args.impute
+                                   else f"cells sharded over {world} rank(s), one all-gather of per-cell probabilities")},
         "vit_gflop_per_cell": round(flops_cell / 1e9, 4),
         "vit_mfma_util_vs_bf16_dense": round(value * flops_cell / (world * PEAK_BF16_DENSE_TFLOPS * 1e12), 5),
     }
@@ -212,7 +247,7 @@ def main():
         torch.cuda.synchronize()
         prof = ops.prof_read()
         ops.prof_enable(False)
-        lo, hi = dist.shard_bounds(n_cells, rank, world)
+        lo, hi = dist.shard_bounds(n_cells, rank, world) if sharded else (0, n_cells)
         n_local = hi - lo
         gemm_flops = 0.0
         for name, model in models.items():
@@ -233,6 +268,10 @@ def main():
                            "algorithmic_gflop_per_launch": round(gemm_flops / max(g_n, 1) / 1e9, 4), "mfma_passes_per_product": 3,
                            "per_kernel_ms": {k: round(v[0], 3) for k, v in prof.items() if v[1]}}
 
+    # ---- the boundary itself: Annotator.preprocess -> predict -> export_annotations from host files ------------------------
+    if not args.no_dropin and rank == 0 and world == 1 and not args.impute:
+        out["dropin"] = dropin_bench(args, raw, mask, markers, models, srcs, one_pass_models=lambda sel: one_pass(models_sel=sel))
+
     # ---- CPU baseline: the oracle (numpy/scipy/torch fp32 restatement of the reference path) on a bounded sample ------------
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, raw, mask, markers, seed, n_cells)
@@ -241,6 +280,139 @@ def main():
         print(json.dumps(out))
     if world > 1:
         tdist.destroy_process_group()
+
+
+def config1_bench(args):
+    """BASELINE.json configs[0] (reference main.py:9-36 on examples/example_1.*, batch_size=8, device=cpu) through its stand-in
+    (the reference's example_1 mask, 1850 cells, + the seeded 7-channel Basic-panel image; the .tif is a missing
+    blob).  GPU: the drop-in Annotator end to end from host .npy files; CPU: the oracle pipeline timed in full on the same inputs."""
+    import shutil
+    import tempfile
+    import __graft_entry__
+    __graft_entry__.build()
+    from multiplexed_image_annotator_amd import _lib, synth
+    from multiplexed_image_annotator_amd.annotator import Annotator
+    _lib.require_gpu()
+    gdir = os.path.join(ROOT, "tests", "golden")
+    meta = json.load(open(os.path.join(gdir, "config1.json")))
+    arrs = np.load(os.path.join(gdir, "config1.npz"))
+    mask = np.load(os.path.join(gdir, "cellpos.npz"))["example1_mask"].astype(np.int32)
+    raw = synth.make_image_for_mask(torch.from_numpy(mask), len(meta["markers"]), meta["seed"]).numpy().astype(np.uint16)
+    sd = synth.make_vit_state_dict("immune_base", meta["seed"])
+    sd["head.bias"] = torch.from_numpy(arrs["head_bias"])
+    tmp = tempfile.mkdtemp(prefix="ribca_c1_")
+    try:
+        np.save(os.path.join(tmp, "img.npy"), raw)
+        np.save(os.path.join(tmp, "mask.npy"), mask)
+        mf = os.path.join(tmp, "markers.txt")
+        with open(mf, "w") as f:
+            f.write("\n".join(meta["markers"]) + "\n")
+        with open(os.path.join(tmp, "images.csv"), "w") as f:
+            f.write("image_path,mask_path\n%s,%s\n" % (os.path.join(tmp, "img.npy"), os.path.join(tmp, "mask.npy")))
+        shared = {}
+
+        def run_once():
+            a = Annotator(mf, os.path.join(tmp, "images.csv"), "cuda", tmp, "c1", True, False, -1, True, meta["blur"], meta["amax"], meta["conf"],
+                          30, None)
+            if shared:
+                a.models, a._loaded = dict(shared), True
+            else:
+                a.set_weights({"immune_base": sd})
+            a.preprocess()
+            a.predict(meta["batch_size"])
+            a.export_annotations()
+            shared.update(a.models)
+            labels = list(a.annotations[0])
+            a.clear_tmp()
+            a.logger.close()
+            return labels
+
+        for _ in range(max(args.warmup, 1)):
+            labels = run_once()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            labels = run_once()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        n = len(labels)
+        out = {"metric": "cells/sec annotated (whole node)", "value": round(n / dt, 2), "unit": "cells/s", "n_gpus": 1, "steps": args.steps,
+               "warmup": max(args.warmup, 1), "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f16", "data": "synthetic image on the reference's examples/example_1_cell_mask.png",
+               "config": {"workload": "BASELINE configs[0] stand-in: 600x600 example_1 mask, 1850 cells, 7-marker Basic panel, immune_base ViT, "
+                                      "Annotator.preprocess -> predict(8) -> export_annotations from host .npy files",
+                          "baseline_config": "configs[0]", "cells": n},
+               "labels_identical_to_reference_golden": labels == meta["labels"]}
+        if not args.no_cpu_baseline:
+            from oracle import ref_pipeline
+            threads = min(16, len(os.sched_getaffinity(0)))
+            torch.set_num_threads(threads)
+            t0 = time.perf_counter()
+            r = ref_pipeline.run_image(raw, mask, mf, {"immune_base": sd}, strict=True, normalize=True, blur=meta["blur"], amax=meta["amax"],
+                                       confidence=meta["conf"], batch_size=meta["batch_size"])
+            t_cpu = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": round(n / t_cpu, 3), "unit": "cells/s", "cores": threads, "kind": "port",
+                                   "sample": f"the whole config (all {n} cells, batch_size 8) timed in full: {t_cpu:.1f} s; labels equal the "
+                                             f"reference golden: {r['labels'] == meta['labels']}"}
+        print(json.dumps(out))
+        return 0
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def dropin_bench(args, raw_dev, mask_dev, markers, models, srcs, one_pass_models):
+    """Times the drop-in class itself on the same tile: inputs are HOST files (uint16 .npy image, int32 .npy mask, marker list),
+    the timed region is ``Annotator(...)`` -> ``preprocess()`` (file read, H2D, normalise, label table, crop + intensity table)
+    -> ``predict()`` -> ``export_annotations()`` (CSV on disk) -> ``clear_tmp()``.  With this 15-marker file the reference's model
+    choice (model.py:241-349) runs ONE classifier, immune_full (struct / nerve markers cannot be named by a 15-marker panel), so
+    the same model set is also timed through the kernel-path ``one_pass`` for a like-for-like ratio.  Packed weights stay
+    resident across passes, as in the kernel path."""
+    import shutil
+    import tempfile
+    from multiplexed_image_annotator_amd.annotator import Annotator
+    tmp = tempfile.mkdtemp(prefix="ribca_dropin_")
+    try:
+        np.save(os.path.join(tmp, "img.npy"), raw_dev.cpu().numpy().view(np.uint16))
+        np.save(os.path.join(tmp, "mask.npy"), mask_dev.cpu().numpy())
+        with open(os.path.join(tmp, "markers.txt"), "w") as f:
+            f.write("\n".join(markers) + "\n")
+        with open(os.path.join(tmp, "images.csv"), "w") as f:
+            f.write("image_path,mask_path\n%s,%s\n" % (os.path.join(tmp, "img.npy"), os.path.join(tmp, "mask.npy")))
+
+        def run_once():
+            a = Annotator(os.path.join(tmp, "markers.txt"), os.path.join(tmp, "images.csv"), "cuda", tmp, "bench", True, False, -1, True, 0.3,
+                          99.8, 0.3, 30, None)
+            a.chunk_cells, a.streams = args.chunk, args.streams
+            a.models = {k: v for k, v in models.items() if k == "immune_full"}
+            a._loaded = True
+            a.preprocess()
+            a.predict(128)
+            a.export_annotations()
+            n = len(a.annotations[0])
+            a.clear_tmp()
+            a.logger.close()
+            return n
+
+        run_once()
+        torch.cuda.synchronize()
+        reps = 2
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            n = run_once()
+        torch.cuda.synchronize()
+        t_api = (time.perf_counter() - t0) / reps
+        one_pass_models(["immune_full"])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            one_pass_models(["immune_full"])
+        torch.cuda.synchronize()
+        t_ops = (time.perf_counter() - t0) / reps
+        return {"value": round(n / t_api, 2), "unit": "cells/s", "ms_per_tile": round(t_api * 1e3, 2), "models": ["immune_full"],
+                "includes": "np.load of image + mask, H2D, normalise, label table, crop + intensity table, ViT, vote, CSV write",
+                "kernel_path_same_models": round(n / t_ops, 2), "ratio_to_kernel_path": round(t_ops / t_api, 4)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def cpu_baseline(args, raw_dev, mask_dev, markers, seed, n_cells):
@@ -260,7 +432,7 @@ def cpu_baseline(args, raw_dev, mask_dev, markers, seed, n_cells):
     t = time.perf_counter()
     ids, tab = rp.cell_table(mask)
     t_label = (time.perf_counter() - t) * area_scale
-    k = min(48, len(ids))
+    k = min(args.cpu_sample, len(ids))
     sel = np.linspace(0, len(ids) - 1, k).astype(int)
     t = time.perf_counter()
     patches, _ = rp.patches_for_panel(image, mask, list(range(raw.shape[0])), ids[sel], tab[sel], want_intensity=False)
@@ -273,14 +445,14 @@ def cpu_baseline(args, raw_dev, mask_dev, markers, seed, n_cells):
             continue
         sd = synth.make_vit_state_dict(name, seed)
         t = time.perf_counter()
-        ref_vit.predict_proba(sd, x[:, :c], 48)
+        ref_vit.predict_proba(sd, x[:, :c], 128)
         t_vit += (time.perf_counter() - t) / k
         n_models += 1
     per_cell = (t_norm + t_label) / n_cells + n_models * t_crop + t_vit     # the reference crops once per applicable panel
     return {"value": round(1.0 / per_cell, 3), "unit": "cells/s", "cores": threads, "kind": "port",
             "sample": f"oracle on a {side}x{side} corner: normalise+label scan scaled by area to the full tile ({t_norm:.1f}s+{t_label:.2f}s), "
                       f"crop/soft-mask {t_crop*1e3:.2f} ms/cell/panel (1 thread, as the reference) and {n_models} fp32 ViTs "
-                      f"{t_vit*1e3:.1f} ms/cell ({threads} threads, batch 48) on {k} cells"}
+                      f"{t_vit*1e3:.1f} ms/cell ({threads} threads, batch 128) on {k} cells"}
 
 
 if __name__ == "__main__":

@@ -11,10 +11,10 @@
 //
 // Per 16-query tile:  S^T = K * Q^T (keys on MFMA rows, queries on lanes) -> each lane holds, for ITS query, keys
 // {16*kt + 4g + r}: the softmax reduction over keys is 28 in-register values + two xor-shuffles (lanes 16/32 apart);
-// the normalised probabilities are split to bf16 hi/lo IN PLACE and are already the B operand of  O^T = V^T * P^T
+// the normalised probabilities are split to fp16 hi/lo IN PLACE and are already the B operand of  O^T = V^T * P^T
 // (k index = key, column = query) -- no cross-lane movement, no LDS round trip.  O^T tiles put 4 consecutive head
 // dims of one query in a lane: one 8-byte hi + one 8-byte lo store into the packed-split attention output.
-// All three products use the bf16x3 split (ribca_common.h).  Q is pre-scaled by hd^-0.5 by the producer.
+// All three products use the fp16x3 split (ribca_common.h).  Q is pre-scaled by hd^-0.5 by the producer.
 #include <cstdlib>
 
 #include "ribca_common.h"
@@ -37,15 +37,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
   const int r16 = lane & 15, g = lane >> 4;
   constexpr int KST = (NT + 1) / 2;         // 32-key steps of the P*V product
   constexpr int TP = 16 * NT;
-  constexpr int ROW = 2 * hdq;              // bf16 per Q/K row
+  constexpr int ROW = 2 * hdq;              // 16-bit elements per Q/K row
   constexpr int ngrp = hdq >> 3;            // stored k-groups per row
-  constexpr int VROW = 2 * 32 * KST;        // bf16 per V^T row
+  constexpr int VROW = 2 * 32 * KST;        // 16-bit elements per V^T row
   const uint16_t* qb = Q + (size_t)pair * TP * ROW;
   const uint16_t* kb = K + (size_t)pair * TP * ROW;
   const uint16_t* vb = Vt + (size_t)pair * (DT * 16) * VROW;
 
   // K fragments stay in registers for all query tiles
-  bf16x8 khi[NT][KS], klo[NT][KS];
+  f16x8 khi[NT][KS], klo[NT][KS];
 #pragma unroll
   for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
@@ -55,12 +55,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
         const uint4* p = reinterpret_cast<const uint4*>(kb + (size_t)(kt * 16 + r16) * ROW + (ks * 4 + g) * 16);
         h4 = p[0]; l4 = p[1];
       }
-      khi[kt][ks] = __builtin_bit_cast(bf16x8, h4);
-      klo[kt][ks] = __builtin_bit_cast(bf16x8, l4);
+      khi[kt][ks] = __builtin_bit_cast(f16x8, h4);
+      klo[kt][ks] = __builtin_bit_cast(f16x8, l4);
     }
 
   for (int qt = 0; qt < q_tiles; ++qt) {
-    bf16x8 qhi[KS], qlo[KS];
+    f16x8 qhi[KS], qlo[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       uint4 h4 = {0u, 0u, 0u, 0u}, l4 = {0u, 0u, 0u, 0u};
@@ -68,8 +68,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
         const uint4* p = reinterpret_cast<const uint4*>(qb + (size_t)(qt * 16 + r16) * ROW + (ks * 4 + g) * 16);
         h4 = p[0]; l4 = p[1];
       }
-      qhi[ks] = __builtin_bit_cast(bf16x8, h4);
-      qlo[ks] = __builtin_bit_cast(bf16x8, l4);
+      qhi[ks] = __builtin_bit_cast(f16x8, h4);
+      qlo[ks] = __builtin_bit_cast(f16x8, l4);
     }
     f32x4 s[2 * KST];
 #pragma unroll
@@ -77,9 +77,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
       s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        s[kt] = mfma_bf16(klo[kt][ks], qhi[ks], s[kt]);
-        s[kt] = mfma_bf16(khi[kt][ks], qlo[ks], s[kt]);
-        s[kt] = mfma_bf16(khi[kt][ks], qhi[ks], s[kt]);
+        s[kt] = mfma_f16(klo[kt][ks], qhi[ks], s[kt]);
+        s[kt] = mfma_f16(khi[kt][ks], qlo[ks], s[kt]);
+        s[kt] = mfma_f16(khi[kt][ks], qhi[ks], s[kt]);
       }
     }
     // keys >= T (only possible in the last tile) are padding
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     const float inv = 1.0f / sum;
     if (NT & 1) s[NT] = f32x4{0.f, 0.f, 0.f, 0.f};
     // P fragments: k-step t covers key tiles 2t (elements 0..3) and 2t+1 (elements 4..7)
-    bf16x8 phi[KST], plo[KST];
+    f16x8 phi[KST], plo[KST];
 #pragma unroll
     for (int t = 0; t < KST; ++t) {
       float pa[4], pb[4];
@@ -116,8 +116,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
       uint2 ha, la, hb, lb;
       split4(pa, ha, la);
       split4(pb, hb, lb);
-      phi[t] = __builtin_bit_cast(bf16x8, uint4{ha.x, ha.y, hb.x, hb.y});
-      plo[t] = __builtin_bit_cast(bf16x8, uint4{la.x, la.y, lb.x, lb.y});
+      phi[t] = __builtin_bit_cast(f16x8, uint4{ha.x, ha.y, hb.x, hb.y});
+      plo[t] = __builtin_bit_cast(f16x8, uint4{la.x, la.y, lb.x, lb.y});
     }
     const int qtok = qt * 16 + r16;
     uint16_t* orow = out + ((size_t)cell * T + qtok) * ldo;
@@ -131,11 +131,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
           const uint4* p = reinterpret_cast<const uint4*>(vb + (size_t)(dt * 16 + r16) * VROW + (4 * t + g) * 16);
           h4 = p[0]; l4 = p[1];
         }
-        const bf16x8 vhi = __builtin_bit_cast(bf16x8, h4);
-        const bf16x8 vlo = __builtin_bit_cast(bf16x8, l4);
-        o = mfma_bf16(vlo, phi[t], o);
-        o = mfma_bf16(vhi, plo[t], o);
-        o = mfma_bf16(vhi, phi[t], o);
+        const f16x8 vhi = __builtin_bit_cast(f16x8, h4);
+        const f16x8 vlo = __builtin_bit_cast(f16x8, l4);
+        o = mfma_f16(vlo, phi[t], o);
+        o = mfma_f16(vhi, plo[t], o);
+        o = mfma_f16(vhi, phi[t], o);
       }
       const int d = dt * 16 + 4 * g;  // o[r] = O[query = qtok][head dim d + r]
       if (qtok < T && d < hd) {
@@ -162,9 +162,9 @@ __global__ __launch_bounds__(64 * WPP) void attention_lds_kernel(const uint16_t*
   constexpr int hdq = (HD + 7) / 8 * 8;
   constexpr int KST = (NT + 1) / 2;
   constexpr int TP = 16 * NT;
-  constexpr int ROW = 2 * hdq;                       // bf16 per Q/K row
+  constexpr int ROW = 2 * hdq;                       // 16-bit elements per Q/K row
   constexpr int ngrp = hdq >> 3;
-  constexpr int VROW = 2 * 32 * KST;                 // bf16 per V^T row
+  constexpr int VROW = 2 * 32 * KST;                 // 16-bit elements per V^T row
   constexpr int K_BYTES = TP * ROW * 2;
   constexpr int V_BYTES = hd * VROW * 2;             // only the hd real rows
   constexpr int K_LDS = (K_BYTES + 1023) / 1024 * 1024;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64 * WPP) void attention_lds_kernel(const uint16_t*
                                      (__attribute__((address_space(3))) void*)(lds + K_LDS + i * 1024), 16, 0, 0);
   }
   // first Q tile of this wave while the copies fly
-  auto load_q = [&](int qt, bf16x8 (&qh)[KS], bf16x8 (&ql)[KS]) __attribute__((always_inline)) {
+  auto load_q = [&](int qt, f16x8 (&qh)[KS], f16x8 (&ql)[KS]) __attribute__((always_inline)) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       uint4 h4 = {0u, 0u, 0u, 0u}, l4 = {0u, 0u, 0u, 0u};
@@ -207,11 +207,11 @@ __global__ __launch_bounds__(64 * WPP) void attention_lds_kernel(const uint16_t*
         const uint4* p = reinterpret_cast<const uint4*>(qb + (size_t)(qt * 16 + r16) * ROW + (ks * 4 + g) * 16);
         h4 = p[0]; l4 = p[1];
       }
-      qh[ks] = __builtin_bit_cast(bf16x8, h4);
-      ql[ks] = __builtin_bit_cast(bf16x8, l4);
+      qh[ks] = __builtin_bit_cast(f16x8, h4);
+      ql[ks] = __builtin_bit_cast(f16x8, l4);
     }
   };
-  bf16x8 qhi[KS], qlo[KS], qhi_n[KS], qlo_n[KS];
+  f16x8 qhi[KS], qlo[KS], qhi_n[KS], qlo_n[KS];
   if (wave < q_tiles) load_q(wave, qhi, qlo);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -233,10 +233,10 @@ __global__ __launch_bounds__(64 * WPP) void attention_lds_kernel(const uint16_t*
           const uint4* p = reinterpret_cast<const uint4*>(kl + ((kt * 16 + r16) * ROW + (ks * 4 + g) * 16) * 2);
           h4 = p[0]; l4 = p[1];
         }
-        const bf16x8 kh = __builtin_bit_cast(bf16x8, h4), klo_ = __builtin_bit_cast(bf16x8, l4);
-        s[kt] = mfma_bf16(klo_, qhi[ks], s[kt]);
-        s[kt] = mfma_bf16(kh, qlo[ks], s[kt]);
-        s[kt] = mfma_bf16(kh, qhi[ks], s[kt]);
+        const f16x8 kh = __builtin_bit_cast(f16x8, h4), klo_ = __builtin_bit_cast(f16x8, l4);
+        s[kt] = mfma_f16(klo_, qhi[ks], s[kt]);
+        s[kt] = mfma_f16(kh, qlo[ks], s[kt]);
+        s[kt] = mfma_f16(kh, qhi[ks], s[kt]);
       }
     }
 #pragma unroll
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64 * WPP) void attention_lds_kernel(const uint16_t*
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
     if (NT & 1) s[NT] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 phi[KST], plo[KST];
+    f16x8 phi[KST], plo[KST];
 #pragma unroll
     for (int t = 0; t < KST; ++t) {
       float pa[4], pb[4];
@@ -271,8 +271,8 @@ __global__ __launch_bounds__(64 * WPP) void attention_lds_kernel(const uint16_t*
       uint2 ha, la, hb, lb;
       split4(pa, ha, la);
       split4(pb, hb, lb);
-      phi[t] = __builtin_bit_cast(bf16x8, uint4{ha.x, ha.y, hb.x, hb.y});
-      plo[t] = __builtin_bit_cast(bf16x8, uint4{la.x, la.y, lb.x, lb.y});
+      phi[t] = __builtin_bit_cast(f16x8, uint4{ha.x, ha.y, hb.x, hb.y});
+      plo[t] = __builtin_bit_cast(f16x8, uint4{la.x, la.y, lb.x, lb.y});
     }
     const int qtok = qt * 16 + r16;
     uint16_t* orow = out + ((size_t)cell * T + qtok) * ldo;
@@ -286,10 +286,10 @@ __global__ __launch_bounds__(64 * WPP) void attention_lds_kernel(const uint16_t*
           const uint4* p = reinterpret_cast<const uint4*>(vl + (dt * 16 + r16) * (VROW * 2) + (((4 * t + g) ^ r16) << 5));   // row & 15 == r16
           h4 = p[0]; l4 = p[1];
         }
-        const bf16x8 vhi = __builtin_bit_cast(bf16x8, h4), vlo = __builtin_bit_cast(bf16x8, l4);
-        o = mfma_bf16(vlo, phi[t], o);
-        o = mfma_bf16(vhi, plo[t], o);
-        o = mfma_bf16(vhi, phi[t], o);
+        const f16x8 vhi = __builtin_bit_cast(f16x8, h4), vlo = __builtin_bit_cast(f16x8, l4);
+        o = mfma_f16(vlo, phi[t], o);
+        o = mfma_f16(vhi, plo[t], o);
+        o = mfma_f16(vhi, phi[t], o);
       }
       const int d = dt * 16 + 4 * g;
       if (qtok < T && d < hd) {

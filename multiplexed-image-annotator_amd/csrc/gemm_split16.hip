@@ -1,8 +1,8 @@
-// bf16x3 MFMA GEMM for the ViT linears (timm Attention.qkv / Attention.proj / Mlp.fc1 / Mlp.fc2; the imputer's embeddings and
+// fp16x3 (split-operand) MFMA GEMM for the ViT linears (timm Attention.qkv / Attention.proj / Mlp.fc1 / Mlp.fc2; the imputer's embeddings and
 // prediction head too), reached from reference cell_type_annotation/model.py:402 ``model(x)``).
 //
-//   C[m][n] = sum_k A[m][k] * W[n][k]        A: activations  [M ][2*Kp] packed-split bf16 (ribca_common.h)
-//                                            W: nn.Linear wt [Np][2*Kp] packed-split bf16, Np = N padded to the tile
+//   C[m][n] = sum_k A[m][k] * W[n][k]        A: activations  [M ][2*Kp] packed-split fp16 (ribca_common.h)
+//                                            W: nn.Linear wt [Np][2*Kp] packed-split fp16, Np = N padded to the tile
 //
 // Shape regime: M = cells*101 is huge (1e4..1e6), N in {144..2304}, K in {160..2304}: short K loops and a weight matrix
 // that lives in L2 / Infinity Cache, so the kernel is built around keeping the MFMA pipe fed from a deep LDS ring:
@@ -405,17 +405,17 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  bf16x8 ahi[4], alo[4], whi[TN], wlo[TN];
+  f16x8 ahi[4], alo[4], whi[TN], wlo[TN];
   auto read_frags = [&](const char* st) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ahi[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + a_rd[i]));
-      alo[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + (a_rd[i] ^ 16)));
+      ahi[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(st + a_rd[i]));
+      alo[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(st + (a_rd[i] ^ 16)));
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      whi[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + w_rd[j]));
-      wlo[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + (w_rd[j] ^ 16)));
+      whi[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(st + w_rd[j]));
+      wlo[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(st + (w_rd[j] ^ 16)));
     }
   };
   auto mfmas = [&]() {
@@ -423,18 +423,18 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(wlo[j], ahi[i], acc[i][j]);
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_f16(wlo[j], ahi[i], acc[i][j]);
     }
     if constexpr (abl_passes(ABL) >= 2) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(whi[j], alo[i], acc[i][j]);
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_f16(whi[j], alo[i], acc[i][j]);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(whi[j], ahi[i], acc[i][j]);
+      for (int j = 0; j < TN; ++j) acc[i][j] = mfma_f16(whi[j], ahi[i], acc[i][j]);
   };
 
   int cur = 0;

@@ -1,14 +1,18 @@
 // Shared device helpers for the RIBCA hot-path kernels (gfx950 / CDNA4 only).
 //
-// Numerics ("bf16x3"): every matrix product on the path runs on the bf16 matrix cores with each fp32
-// operand split as x = hi + lo (hi = bf16(x), lo = bf16(x - hi)) and three MFMA passes
+// Numerics ("fp16x3"): every matrix product on the path runs on the 16-bit matrix cores with each fp32 operand split as
+// x = hi + lo (hi = fp16(x), lo = fp16(x - hi)) and three MFMA passes
 //     acc += hi_a*hi_b ; acc += lo_a*hi_b ; acc += hi_a*lo_b        (fp32 accumulate)
-// which carries ~16 mantissa bits per operand.  A single bf16 or fp16 pass misses the reference's 1e-3
-// confidence tolerance by 3-16x after 12 blocks (DESIGN.md "precision study"); the split form meets it with
-// 30x margin at 3x the MFMA work.
+// which carries ~22 mantissa bits per operand (the dropped lo*lo term is 2^-22 relative).  A single bf16 or fp16 pass misses
+// the reference's 1e-3 confidence tolerance by 3-16x after 12 blocks; the round-1 bf16 split (16 bits) met it with 30x margin;
+// the fp16 split costs the same three v_mfma_f32_16x16x32 passes and the same 4 bytes per element and is ~5x closer to the
+// fp32 reference (tests/precision_study.py): max |dp| 4-6e-6 instead of 2-2.5e-5.
+// Range: fp16 saturates at 65504, so values are clamped to +-65504 before the split (no inf / NaN can enter an MFMA); lo is
+// usually SUBNORMAL in fp16 (|lo| <= 2^-12 |x|): v_mfma_f32_16x16x32_f16 and the VALU keep fp16 subnormals on gfx950
+// (tools/f16_probe.hip: exact), and lo of a subnormal-range hi is exactly zero.
 //
-// "Packed split" (PS) layout: a logical row of Kp elements (Kp % 32 == 0) is stored as 2*Kp bf16:
-//     group g = k / 8 occupies 16 consecutive bf16: [hi(8g..8g+7) | lo(8g..8g+7)]
+// "Packed split" (PS) layout: a logical row of Kp elements (Kp % 32 == 0) is stored as 2*Kp fp16:
+//     group g = k / 8 occupies 16 consecutive fp16: [hi(8g..8g+7) | lo(8g..8g+7)]
 // so one lane's MFMA fragment (8 consecutive k of one row) is a 16-byte hi vector followed by a 16-byte lo
 // vector, and a 32-deep K step of one row is one 128-byte line.
 #pragma once
@@ -17,7 +21,7 @@
 
 namespace ribca {
 
-typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(8 * sizeof(_Float16)))) _Float16 f16x8;
 typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
 
 constexpr int kTokens = 101;   // 10x10 patches + CLS (reference model.py:66-88 with img_size=40, patch 4)
@@ -25,33 +29,39 @@ constexpr int kHeads = 12;
 constexpr int kTokPad = 112;   // tokens padded to 7 MFMA tiles of 16 for attention operands
 constexpr int kKeyPad = 128;   // keys padded to 4 MFMA K-steps of 32 for the P*V product
 
-__device__ __forceinline__ uint16_t bf16_bits(float x) {
-  return __builtin_bit_cast(uint16_t, (__bf16)x);
+constexpr float kF16Max = 65504.0f;
+__device__ __forceinline__ float clamp_f16_range(float x) { return __builtin_amdgcn_fmed3f(x, -kF16Max, kF16Max); }
+__device__ __forceinline__ uint16_t f16_bits(float x) {
+  return __builtin_bit_cast(uint16_t, (_Float16)x);
 }
-__device__ __forceinline__ float bf16_to_f32(uint16_t b) {
-  return __uint_as_float(((uint32_t)b) << 16);
+__device__ __forceinline__ float f16_to_f32(uint16_t b) {
+  return (float)__builtin_bit_cast(_Float16, b);
 }
-// x = hi + lo split, both as bf16 bit patterns
-__device__ __forceinline__ void split_bf16(float x, uint16_t& hi, uint16_t& lo) {
-  hi = bf16_bits(x);
-  lo = bf16_bits(x - bf16_to_f32(hi));
+// x = hi + lo split, both as fp16 bit patterns (round to nearest even; x clamped to the fp16 range first)
+__device__ __forceinline__ void split_f16(float x, uint16_t& hi, uint16_t& lo) {
+  x = clamp_f16_range(x);
+  hi = f16_bits(x);
+  lo = f16_bits(x - f16_to_f32(hi));
 }
-// four consecutive values -> 8 bytes of hi and 8 bytes of lo.  Packed conversions: one v_cvt_pk_bf16_f32 per value pair.
-typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 bf16x2;
+// four consecutive values -> 8 bytes of hi and 8 bytes of lo
+typedef __attribute__((__vector_size__(2 * sizeof(_Float16)))) _Float16 f16x2;
 typedef __attribute__((__vector_size__(2 * sizeof(float)))) float f32x2;
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+__device__ __forceinline__ uint32_t cvt_pk_f16(float a, float b) {
   const f32x2 v = {a, b};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));     // round to nearest even
+}
+__device__ __forceinline__ f32x2 unpack_f16(uint32_t p) {
+  return __builtin_convertvector(__builtin_bit_cast(f16x2, p), f32x2);
 }
 __device__ __forceinline__ void split4(const float v[4], uint2& hi, uint2& lo) {
-  hi.x = cvt_pk_bf16(v[0], v[1]);
-  hi.y = cvt_pk_bf16(v[2], v[3]);
-  const float r0 = v[0] - __uint_as_float(hi.x << 16), r1 = v[1] - __uint_as_float(hi.x & 0xFFFF0000u);
-  const float r2 = v[2] - __uint_as_float(hi.y << 16), r3 = v[3] - __uint_as_float(hi.y & 0xFFFF0000u);
-  lo.x = cvt_pk_bf16(r0, r1);
-  lo.y = cvt_pk_bf16(r2, r3);
+  const float c0 = clamp_f16_range(v[0]), c1 = clamp_f16_range(v[1]), c2 = clamp_f16_range(v[2]), c3 = clamp_f16_range(v[3]);
+  hi.x = cvt_pk_f16(c0, c1);
+  hi.y = cvt_pk_f16(c2, c3);
+  const f32x2 h01 = unpack_f16(hi.x), h23 = unpack_f16(hi.y);
+  lo.x = cvt_pk_f16(c0 - h01[0], c1 - h01[1]);
+  lo.y = cvt_pk_f16(c2 - h23[0], c3 - h23[1]);
 }
-// element offset (in bf16 units) of the hi part of logical column k in a PS row; lo part is +8
+// element offset (in fp16 units) of the hi part of logical column k in a PS row; lo part is +8
 __device__ __host__ __forceinline__ int ps_off(int k) { return ((k >> 3) << 4) + (k & 7); }
 
 // store 4 consecutive logical columns k..k+3 (k % 4 == 0) of a PS row
@@ -82,8 +92,8 @@ __device__ __forceinline__ void ps_store4_pair(uint16_t* row, int k, const float
   else *dst = o;
 }
 
-__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+__device__ __forceinline__ f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -98,7 +108,7 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // erf to ~2e-7 absolute (Abramowitz & Stegun 7.1.26 evaluated in fp32): 1 rcp + 1 exp2 + 7 fma, branch-free.  The GELU
-// output is re-quantised to a bf16 hi/lo pair (2^-17 relative) right after, so the libm erff's last bits would be
+// output is re-quantised to an fp16 hi/lo pair right after, so the libm erff's last bits would be
 // discarded anyway while costing ~3x the instructions in the fc1 epilogue.
 __device__ __forceinline__ float erf_fast(float x) {
   const float ax = fabsf(x);

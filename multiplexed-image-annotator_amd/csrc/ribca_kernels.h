@@ -6,14 +6,14 @@
 
 namespace ribca {
 
-// ----- GEMM (gemm_bf16x3.hip): C = A * W^T with A [M][2*Kp] and W [Np][2*Kp] in packed-split bf16 ---------------
+// ----- GEMM (gemm_split16.hip): C = A * W^T with A [M][2*Kp] and W [Np][2*Kp] in packed-split fp16 ---------------
 int gemm_pick_bn(int N);            // column-tile width used for an N-wide weight (64 / 96 / 128)
 int gemm_padded_n(int N);
 int gemm_set_stamp_buffer(void* dev_ptr);   // diagnostics (variant 12): 6 x uint64 per workgroup
 void gemm_set_variant(int v);      // 0 = production; 3/4/5/7/9 = A/B and timing-ablation forms of the same kernel           // N rounded up to that tile width (rows the packed weight must have)
 
 struct GemmArgs {
-  const uint16_t* A; int lda;       // activations, row stride in bf16 elements (= 2*Kp)
+  const uint16_t* A; int lda;       // activations, row stride in 16-bit elements (= 2*Kp)
   const uint16_t* W; int ldw;       // packed weight, Np rows
   int M, N, Kp;
   const float* bias;                // [N]

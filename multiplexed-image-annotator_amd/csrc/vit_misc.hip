@@ -61,7 +61,7 @@ void launch_layernorm_ps(const float* z, int ldz, const float* gamma, const floa
 //   z[cell*101 + 1 + t][n] = sum_{c,ky,kx} W[n][c][ky][kx] * x[cell][src[c]][4py+ky][4px+kx] + bias[n] + pos[1+t][n]
 // It is 1-2 % of the FLOPs but feeds the first LayerNorm directly: background tokens embed to ~pos_embed (|z| ~ 0.02) by
 // cancellation of O(1) terms, and LayerNorm rescales that row to unit variance, so a 2^-16-relative product error
-// (bf16x3) is amplified ~50x there.  fp32 FMA keeps this stage at the reference's own precision.
+// (split 16-bit operands) is amplified ~50x there.  fp32 FMA keeps this stage at the reference's own precision.
 // Classic 64x64 LDS-tiled SGEMM, one input channel (16 taps) per K step, im2col done on the fly from the fp32 patches.
 __global__ __launch_bounds__(256) void embed_f32_kernel(const float* __restrict__ patches, int c_img, const int* __restrict__ src_chan,
                                                         int C, const float* __restrict__ w /*[D][C*16]*/, const float* __restrict__ bias,
@@ -287,7 +287,7 @@ void launch_head_softmax(const float* z, int ldz, const float* gamma, const floa
   hipLaunchKernelGGL(head_softmax_kernel, dim3((cells + 3) / 4), dim3(256), 0, s, z, ldz, gamma, beta, hw, hb, probs, D, K, cells);
 }
 
-// fp32 nn.Linear weight [N][K] -> packed-split bf16 [Np][2*Kp], zero padded.  One thread per 4 consecutive k.
+// fp32 nn.Linear weight [N][K] -> packed-split fp16 [Np][2*Kp], zero padded.  One thread per 4 consecutive k.
 __global__ void pack_weight_kernel(const float* __restrict__ w, int N, int K, uint16_t* __restrict__ out, int Np, int Kp) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int kq = Kp >> 2;

@@ -11,6 +11,14 @@ from multiplexed_image_annotator_amd import synth
 
 pytestmark = pytest.mark.gpu
 
+#: End-to-end bound on |dp| against an fp32 CPU run of the same model.  The split-operand blocks hold ~3e-6 (test_gpu_kernels.py),
+#: but on real patches most tokens are background (-1 everywhere): their patch embedding cancels to ~pos_embed (0.02) out of O(10)
+#: terms, so the fp32 rounding of that conv is divided by a 0.02 scale in the first LayerNorm.  Measured on BASELINE config 1's
+#: patches (CPU, oracle): the fp32 forward sits 7.8e-5 from the fp64 forward, 2.4e-6 once the conv alone is done in fp64 -- the
+#: reference's own fp32 conv error, which another correct summation order (embed_f32_kernel) cannot reproduce bit for bit.
+#: North star: 1e-3.
+E2E_TOL = 2e-4
+
 
 def write_case(tmp_path, raw, mask, markers):
     np.save(tmp_path / "img.npy", raw)
@@ -50,7 +58,7 @@ def test_annotator_matches_reference_golden(golden_dir, tmp_path, name):
     for m in meta["models"]:
         got = a.probs[0][m]
         assert np.abs(got - arrs[f"{name}__p_{m}"]).max() < 1e-3          # north-star tolerance (observed ~1e-5)
-        assert np.abs(got - arrs[f"{name}__p_{m}"]).max() < 2e-4
+        assert np.abs(got - arrs[f"{name}__p_{m}"]).max() < 2e-4         # fp32 summation-order floor of real patches, see E2E_TOL
     assert a.annotations[0] == meta["labels"]                             # cell-type assignments identical
     assert [str(s) for s in a.cell_types] == meta["cell_types"]
     assert [int(r["Cell type"]) for r in a.annotations_all[0]] == meta["type_ints"]
@@ -215,9 +223,8 @@ def test_annotator_with_imputation_matches_oracle(tmp_path):
     # without imputer weights the reference raises ValueError("Panel not found") (markerImputer.py:276)
     b = Annotator(mf, csv, "cuda", str(tmp_path), "j", False, True, -1, True, 0.3, 99.8, 0.3, 30, None)
     b.set_weights(weights)
-    b.preprocess()
-    with pytest.raises(ValueError, match="Panel not found"):
-        b.predict(32)
+    with pytest.raises(ValueError, match="Panel not found"):       # raised while pre-processing, as in the reference (preprocess.py:272)
+        b.preprocess()
 
 
 @pytest.mark.gpu
@@ -479,8 +486,100 @@ def test_config1_matches_reference_golden(golden_dir, tmp_path):
     got = a.probs[0]["immune_base"]
     err = np.abs(got - arrs["probs"]).max()
     assert err < 1e-3, err                                   # north-star tolerance
-    assert err < 2e-4, err                                   # what the split-operand MFMA path actually holds
+    assert err < E2E_TOL, err                                # fp32 summation-order floor of real patches (E2E_TOL)
     assert a.annotations[0] == meta["labels"]                # 1850 cell-type assignments identical (smallest top-2 margin 8e-5)
     assert [str(s) for s in a.cell_types] == meta["cell_types"]
     np.testing.assert_allclose(a.preprocessor.intensity_full[0], arrs["intensity"], rtol=1e-12, atol=1e-14)
     csv_equal_up_to_conf(open(tmp_path / "results" / "c1_annotation_0.csv").read(), meta["csv"], 1.5e-3)
+
+
+def _config3_inputs(dev, n_cells=100000, seed_offset=3, markers_last=None):
+    """BASELINE config 3 / 5 inputs as bench.py builds them: 15-channel 4096^2 tile, normalised image, label table."""
+    from multiplexed_image_annotator_amd import ops
+    seed = synth.SEED_BASE + seed_offset
+    mask, img = synth.make_mask_and_image(4096, 4096, n_cells, 15, seed, device=dev)
+    mask = mask.to(torch.int32)
+    image = ops.normalize_image(img.to(torch.int16), blur=0.3, amax=99.8, u16_bits=True)
+    del img
+    ids, tab = ops.label_table(mask)
+    return seed, mask, image, ids, tab, ops.channel_min(image)
+
+
+def test_config3_parity_audit_2000_cells():
+    """at BASELINE config 3's inputs, 2000 cells spread over the tile through ALL FIVE full-depth classifiers
+    against the fp32 CPU oracle: cell-type argmax identical, max |dp| under the north-star 1e-3 (and under the 2e-5 this path
+    holds), plus the top-2 margin histogram of the synthetic weights that SURVEY 8(d) asks to report."""
+    from multiplexed_image_annotator_amd import _lib, ops
+    from oracle import ref_vit
+    dev = _lib.require_gpu()
+    seed, mask, image, ids, tab, cmin = _config3_inputs(dev)
+    n = len(ids)
+    sel = np.linspace(0, n - 1, 2000).astype(np.int64)
+    ids_d = torch.from_numpy(ids[sel].astype(np.int32)).to(dev)
+    bb_d = torch.from_numpy(tab[sel, :4].astype(np.int32)).to(dev)
+    patches, _ = ops.extract_patches(image, mask, cmin, ids_d, bb_d)
+    x_cpu = patches.cpu()
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    report = {}
+    edges = [0.0, 1e-4, 1e-3, 1e-2, 0.1, 0.3, 0.6, 1.0001]
+    for name, (d, c, k) in synth.VIT_CONFIGS.items():
+        sd = synth.make_vit_state_dict(name, seed)
+        got = ops.VitModel(sd, dev).predict_proba(patches, list(range(c)), chunk_cells=1024, streams=3).cpu()
+        ref = ref_vit.predict_proba(sd, x_cpu[:, :c], 128)
+        err = (got - ref).abs().max().item()
+        srt = ref.sort(dim=1, descending=True).values
+        margin = (srt[:, 0] - srt[:, 1]).numpy()
+        hist = np.histogram(margin, bins=edges)[0].tolist()
+        flips = int((got.argmax(1) != ref.argmax(1)).sum())
+        report[name] = {"max_abs_dp": err, "label_flips": flips, "min_top2_margin": float(margin.min()), "margin_hist_edges": edges,
+                        "margin_hist": hist, "classes_used": int(len(torch.unique(ref.argmax(1))))}
+        print(f"[parity audit] {name}: 2000 cells, max|dp| {err:.2e}, flips {flips}, top-2 margin min {margin.min():.2e} hist {hist}")
+        assert flips == 0, (name, flips)
+        assert err < 1e-3, (name, err)          # north star
+        assert err < E2E_TOL, (name, err)       # fp32 summation-order floor of real patches (E2E_TOL)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        json.dump(report, open(os.path.join(out_dir, "parity_audit_config3.json"), "w"), indent=1)
+
+
+def test_config5_full_size_properties():
+    """BASELINE config 5 on one GPU (one 15-ch 4096^2 tile, ~100 k cells, last full-panel marker missing, infer=True) with the
+    FULL-DEPTH imputer (12 + 8 blocks) and classifier: present planes pass through bit-identically, a shard equals the slice of
+    the whole run, rows sum to 1, and a 24-cell sample matches the CPU oracle (imputed plane and confidences)."""
+    from multiplexed_image_annotator_amd import _lib, ops
+    from oracle import ref_mae, ref_vit
+    dev = _lib.require_gpu()
+    seed, mask, image, ids, tab, cmin = _config3_inputs(dev, seed_offset=5)
+    n = len(ids)
+    ids_d = torch.from_numpy(ids.astype(np.int32)).to(dev)
+    bb_d = torch.from_numpy(tab[:, :4].astype(np.int32)).to(dev)
+    patches, _ = ops.extract_patches(image, mask, cmin, ids_d, bb_d)
+    present = list(range(14))
+    imp_sd = synth.make_mae_state_dict("immune_full", seed)
+    imputer = ops.MaeModel(imp_sd, dev)
+    panel = patches.clone()
+    panel[:, 14] = -1.0                               # what the reference feeds: a blank plane where the marker is missing
+    before = panel[:, :14].clone()
+    imputer.impute(panel, present, chunk_cells=1024)
+    assert torch.equal(panel[:, :14], before)         # present planes untouched
+    del before
+    assert torch.isfinite(panel[:, 14]).all()
+    lo, hi = 43210, 43210 + 700
+    part = patches[lo:hi].clone()
+    part[:, 14] = -1.0
+    imputer.impute(part, present, chunk_cells=256)
+    assert torch.equal(part, panel[lo:hi])            # shard == slice, any chunking
+    sd = synth.make_vit_state_dict("immune_full", seed)
+    model = ops.VitModel(sd, dev)
+    probs = model.predict_proba(panel, list(range(15)), chunk_cells=1024, streams=3)
+    assert probs.shape == (n, 12) and torch.isfinite(probs).all() and (probs.sum(1) - 1).abs().max().item() < 1e-5
+    assert torch.equal(model.predict_proba(part, list(range(15)), chunk_cells=300), probs[lo:hi])
+    x = patches[lo:lo + 24].cpu().clone()
+    x[:, 14] = -1.0
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    ref_panel = ref_mae.impute(imp_sd, x, present, batch_size=8)
+    d_imp = (part[:24, 14].cpu() - ref_panel[:, 14]).abs().max().item()
+    assert d_imp < 1e-4, d_imp                        # imputed pixels (values in [-1, 1])
+    ref = ref_vit.predict_proba(sd, ref_panel, 8)
+    got = probs[lo:lo + 24].cpu()
+    assert (got - ref).abs().max().item() < 1e-3 and torch.equal(got.argmax(1), ref.argmax(1))

@@ -25,7 +25,7 @@ def _ops():
 
 
 def ps_encode(x: torch.Tensor, kp: int, rows_pad: int = None) -> torch.Tensor:
-    """fp32 [R, K] -> packed-split bf16 bits [Rp, 2*Kp] (int16 storage) via the library's own packer."""
+    """fp32 [R, K] -> packed-split fp16 bits [Rp, 2*Kp] (int16 storage) via the library's own packer."""
     from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
     r, k = x.shape
     rp = rows_pad or r
@@ -37,10 +37,15 @@ def ps_encode(x: torch.Tensor, kp: int, rows_pad: int = None) -> torch.Tensor:
 def ps_decode(buf: torch.Tensor, k: int) -> torch.Tensor:
     """packed-split [R, 2*Kp] int16 -> fp64 [R, K] (hi + lo)."""
     r = buf.shape[0]
-    b = buf.view(r, -1, 2, 8).to(torch.int32) & 0xFFFF
-    f = (b << 16).view(torch.float32)
+    f = buf.view(torch.float16).view(r, -1, 2, 8)
     hi, lo = f[:, :, 0, :].reshape(r, -1), f[:, :, 1, :].reshape(r, -1)
     return (hi.double() + lo.double())[:, :k]
+
+
+def note_err(tag, err):
+    """RIBCA_TEST_REPORT=1: print the measured error next to each bound (how the bounds below were checked on hardware)."""
+    if os.environ.get("RIBCA_TEST_REPORT"):
+        print(f"[measured] {tag}: {err:.3e}")
 
 
 def rnd(shape, seed, dev, scale=1.0):
@@ -52,8 +57,9 @@ def test_pack_roundtrip(dev):
     x = rnd((37, 100), 1, dev)
     buf = ps_encode(x, 128, 48)
     y = ps_decode(buf, 100)
-    # two bf16 terms carry >= 16 mantissa bits: relative error <= 2^-16
-    assert torch.all((y[:37] - x.double()).abs() <= x.double().abs() * 2.0 ** -16 + 1e-30)
+    # hi = fp16(x) (11 bits), lo = fp16(x - hi): |x - hi - lo| <= 2^-11 |lo| <= 2^-23 |x| while lo is a normal fp16; below 2^-14 lo
+    # is subnormal with quantum 2^-24, i.e. an absolute error of at most 2^-25
+    assert torch.all((y[:37] - x.double()).abs() <= x.double().abs() * 2.0 ** -23 + 2.0 ** -25)
     assert torch.all(y[37:] == 0) and torch.all(ps_decode(buf, 128)[:, 100:] == 0)
 
 
@@ -69,7 +75,10 @@ def test_layernorm(dev, d):
     check(lib().ribca_test_layernorm(ptr(z), d, ptr(g), ptr(b), ptr(out), 2 * dp, m, d, stream_ptr()), "ln")
     ref = torch.nn.functional.layer_norm(z.double(), (d,), g.double(), b.double(), 1e-6)
     got = ps_decode(out, d)
-    assert (got - ref).abs().max().item() < 2e-5   # fp32 statistics + 2^-16 split error on |y| <~ 5
+    err = (got - ref).abs().max().item()
+    note_err(f"layernorm d={d}", err)
+    # fp32 mean / variance / affine: a handful of roundings at |y| <~ 6 (ulp 4.8e-7), then the hi+lo split (2^-23 relative)
+    assert err < 3e-6, err
     assert torch.all(ps_decode(out, dp)[:, d:] == 0)
 
 
@@ -93,7 +102,11 @@ def test_gemm_residual(dev, m, n, k):
     check(lib().ribca_test_gemm(0, ptr(a_ps), 2 * kp, ptr(w_ps), 2 * kp, m, n, kp, ptr(bias), ptr(z), n, stream_ptr()), "gemm")
     ref = z0.double() + a.double() @ w.double().t() + bias.double()
     err = (z.double() - ref).abs().max().item()
-    assert err < 5e-5, err   # bf16x3: ~2^-16 per operand, fp32 accumulate; |terms| ~ 1
+    note_err(f"gemm_residual {m}x{n}x{k}", err)
+    # Operands enter at 2^-23 relative (hi+lo fp16), so what is left is the fp32 accumulation of K products of O(K^-1/2) terms
+    # plus the residual add at |z| <~ 5: std ~ sqrt(K) 2^-24 |partial sum| ~ 3e-6 at K = 2304; 7 sigma over <= 2e7 outputs.
+    # Measured on MI355X (RIBCA_TEST_REPORT=1): 0.8e-6 (K = 64) ... 7.8e-6 (K = 2304).
+    assert err < 2e-5, err
 
 
 @pytest.mark.parametrize("m,n,k", [(150, 1152, 288), (101, 576, 144), (260, 2304, 576), (7001, 1152, 288), (3000, 2304, 576), (20000, 1152, 288), (12000, 2304, 576)])
@@ -109,7 +122,9 @@ def test_gemm_gelu(dev, m, n, k):
     check(lib().ribca_test_gemm(1, ptr(a_ps), 2 * kp, ptr(w_ps), 2 * kp, m, n, kp, ptr(bias), ptr(out), 2 * n, stream_ptr()), "gemm")
     ref = torch.nn.functional.gelu(a.double() @ w.double().t() + bias.double())
     err = (ps_decode(out, n) - ref).abs().max().item()
-    assert err < 1e-4, err
+    note_err(f"gemm_gelu {m}x{n}x{k}", err)
+    # as test_gemm_residual (pre-activations ~ N(0, 4)), GELU slope <= 1.13, erf_fast 6e-7 absolute x |x| / 2; measured 3.6e-6 ... 6.6e-6
+    assert err < 2e-5, err
 
 
 @pytest.mark.parametrize("d,cells", [(144, 3), (288, 3), (384, 3), (576, 3), (288, 130), (384, 130), (576, 131), (288, 400)])
@@ -136,8 +151,8 @@ def test_qkv_attention(dev, d, cells):
     # intermediate layouts first (localises a failure): Q rows pre-scaled, K rows, V transposed + key-permuted
     qd = ps_decode(q.reshape(-1, 2 * hdp), hdp).reshape(cells, heads, 112, hdp)
     kd = ps_decode(k.reshape(-1, 2 * hdp), hdp).reshape(cells, heads, 112, hdp)
-    def close(got, ref):   # stored as hi+lo bf16 (2^-16 relative) + GEMM error ~ sqrt(K) * 2^-16 * |a||w| (4-sigma over 5e5 outputs)
-        return bool(torch.all((got - ref).abs() <= ref.abs() * 2.0 ** -15 + 1e-4))
+    def close(got, ref):   # stored as hi+lo fp16 (2^-23 relative) + fp32 accumulation of K <= 576 products (measured <= 2.6e-6 relative to 1 + |ref|)
+        return bool(torch.all((got - ref).abs() <= (ref.abs() + 1.0) * 1e-5))
     assert close(qd[:, :, :ntok, :hd], qq * hd ** -0.5)
     assert close(kd[:, :, :ntok, :hd], kk)
     assert torch.all(qd[:, :, ntok:] == 0) and torch.all(qd[..., hd:] == 0)
@@ -149,7 +164,14 @@ def test_qkv_attention(dev, d, cells):
     att = torch.softmax((qq * hd ** -0.5) @ kk.transpose(-1, -2), dim=-1)
     ref = (att @ vv).transpose(1, 2).reshape(m, d)
     err = (ps_decode(out, d) - ref).abs().max().item()
-    assert err < 2e-4, err     # |out| <~ 5; softmax of O(10) scores amplifies the 2^-16 operand error a few times
+    note_err(f"qkv_attention d={d} cells={cells}", err)
+    note_err(f"qkv_attention d={d} q/k/v rel", max(((qd[:, :, :ntok, :hd] - qq * hd ** -0.5).abs() / ((qq * hd ** -0.5).abs() + 1)).max().item(),
+                                                    ((kd[:, :, :ntok, :hd] - kk).abs() / (kk.abs() + 1)).max().item()))
+    # Derived, not fitted: q, k, v reach the attention kernel with delta <= 2.6e-6 (1 + |x|) (asserted above).  A score is a sum of
+    # hd <= 48 products, so |ds| <~ sqrt(hd) * 2 delta |q||k| ~ 7 * 5e-6 * 3 = 1e-4 worst case, ~1e-5 typical; softmax turns it into
+    # a relative error ds on every P, and o = sum P v inherits |do| <= max|ds| * max|v - o| <~ 1e-5 * 4.  Bound 4e-5; measured
+    # 1.1e-6 ... 3.1e-6 on MI355X (the round-1 bf16 split needed 2e-4 here).
+    assert err < 4e-5, err
     assert torch.all(ps_decode(out, dp)[:, d:] == 0)
 
 
@@ -166,7 +188,10 @@ def test_vit_forward_vs_oracle(dev, name):
     model = ops.VitModel(sd, dev)
     got = model.predict_proba(x.to(dev), list(range(c)), chunk_cells=8).cpu()   # 3 chunks, last one ragged
     err = (got - ref).abs().max().item()
-    assert err < 1e-4, err            # north-star tolerance is 1e-3 on confidences
+    note_err(f"vit_forward {name}", err)
+    # north-star tolerance is 1e-3 on confidences; the fp16 hi+lo split holds 2e-5 through 12 blocks (emulated on the oracle:
+    # tests/precision_study.py f16x3 3.7e-6 ... 5.4e-6 over 256 cells; measured here 1.2e-6 ... 3.4e-6)
+    assert err < 2e-5, err
     assert torch.equal(got.argmax(1), ref.argmax(1))
     got2 = model.predict_proba(x.to(dev), list(range(c)), chunk_cells=64).cpu()
     assert torch.equal(got, got2)     # chunking does not change results
