@@ -82,7 +82,8 @@ struct EpiGelu {
   template <int PX = 16>
   __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx&) const {
     if (m >= M || n >= N) return;
-    float t[4] = {gelu_erf(v[0] + b.x), gelu_erf(v[1] + b.y), gelu_erf(v[2] + b.z), gelu_erf(v[3] + b.w)};
+    const f32x2v u0 = gelu_erf2(f32x2v{v[0] + b.x, v[1] + b.y}), u1 = gelu_erf2(f32x2v{v[2] + b.z, v[3] + b.w});
+    float t[4] = {u0.x, u0.y, u1.x, u1.y};
     ps_store4_pair<PX>(out + (size_t)m * ldo, n, t, nt != 0);      // N % 8 == 0: the partner lane (n ^ 4, same m) passed the same guard
   }
 };
@@ -91,14 +92,18 @@ struct EpiQKV {
   uint16_t* q; uint16_t* k; uint16_t* vt; const float* bias; int D, hd, hdp /* stored dims per Q/K row = AttnGeom::hdq */, hdv; float scale; int M, N;
   int T, TP, H, KP;   // tokens per cell, padded token rows of Q/K, heads, padded keys per V^T row
   int nt = 0;
+  unsigned magicT = 0;   // ceil(2^32 / T): m / T as one v_mul_hi + a fix-up (the epilogue does one such division per output row)
   struct Ctx {};
   // row / column decompositions are computed once per accumulator row (4) and column group (TN), not once per tile
   struct Row { int cell, t, vpos; };
   struct Col { int which, head, d; };
   __device__ __forceinline__ Row row(int m) const {
     Row r;
-    r.cell = m / T;
+    // m * ceil(2^32 / T) >> 32 is m / T or one more (m < 2^32): a runtime integer division costs ~25 VALU instructions, and the
+    // drain evaluates it 8-11 times per thread
+    r.cell = (int)__umulhi((unsigned)m, magicT);
     r.t = m - r.cell * T;
+    if (r.t < 0) { r.cell -= 1; r.t += T; }
     // V^T key order permuted inside each 32-key block so that the 8 keys a lane group owns after the K*Q^T MFMA (two
     // 16-key tiles, rows 4g..4g+3 of each) are contiguous: key = 32s+16u+4g+r -> 32s+8g+4u+r
     r.vpos = ps_off((r.t & ~31) | (((r.t >> 2) & 3) << 3) | (((r.t >> 4) & 1) << 2) | (r.t & 3));
@@ -500,6 +505,162 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------- persistent form
+// Same tile, ring, roles and stagger as gemm_ps_split_kernel, but ONE workgroup per CU walks a sequence of tiles (tile ids
+// blockIdx.x, blockIdx.x + gridDim.x, ...; the XCD-aware id -> (m, n) map is unchanged, so a workgroup's tiles stay on its XCD and
+// mostly share their A tile) and the K steps of consecutive tiles form one continuous stream through the ring: while the
+// consumers write tile t out of their accumulator registers, the loader waves have already issued the first two K steps of
+// tile t + 1, so the 2 us "first stage in flight" prologue and the 0.5-3 us workgroup-launch gap that every tile of the
+// one-tile-per-workgroup kernel pays (tools/stamp_gemm.py) are hidden behind the epilogue.  The epilogue cannot park the tile
+// in the ring (it is live), so it is the register form: each lane writes its 4 x TN accumulator tiles directly.
+// Barrier accounting (raw s_barrier counts arrivals of all 12 waves): every wave executes 2 barriers per K step of every tile
+// of this workgroup, plus one: late consumers (waves 4-7) take theirs before the first step, everyone else after the last.
+template <int BN, class Epi>
+__global__ __launch_bounds__(768) void gemm_ps_persist_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw,
+                                                              int M, int Kp, int mtiles, int ntiles, Epi epi) {
+  constexpr int BM = 256, NST = 3, NLW = 4;
+  constexpr int TN = BN / 32;
+  constexpr int ROWS = BM + BN;
+  constexpr int STAGE = ROWS * ROWB;
+  constexpr int NGRP = ROWS / 8;
+  constexpr int GPL = (NGRP + NLW - 1) / NLW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nblk = mtiles * ntiles;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nk = Kp / BK;
+  const int my_tiles = (int)blockIdx.x < nblk ? (nblk - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  auto tile_origin = [&](int seq, int& m0, int& n0) {      // seq-th tile of this workgroup
+    int bid = (int)blockIdx.x + seq * (int)gridDim.x;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int mt = bid / ntiles, nt = bid - mt * ntiles;
+    m0 = mt * BM; n0 = nt * BN;
+  };
+
+  if (wave >= 8) {
+    // ------------------------------------------------------------------ loader: issue iterator runs two K steps ahead
+    const int lw = wave - 8;
+    const uint16_t* src[GPL];
+    int dst[GPL];
+    auto set_tile = [&](int seq) {
+      int m0, n0;
+      tile_origin(seq, m0, n0);
+#pragma unroll
+      for (int i = 0; i < GPL; ++i) {
+        int grp = lw + NLW * i;
+        grp = grp < NGRP ? grp : NGRP - 1;
+        const int row = grp * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ swz_f(row);
+        if (row < BM) {
+          int gm = m0 + row;
+          gm = gm < M ? gm : M - 1;
+          src[i] = A + (size_t)gm * lda + ch * 8;
+        } else {
+          src[i] = W + (size_t)(n0 + row - BM) * ldw + ch * 8;
+        }
+        dst[i] = grp * 1024;
+      }
+    };
+    int iss_seq = 0, iss_kk = 0, iss_stage = 0;            // next (tile, K step) to issue and the ring slot it goes to
+    const long long total = (long long)my_tiles * nk;
+    long long issued = 0;
+    auto issue_next = [&]() {
+      if (issued >= total) return;
+      if (iss_kk == 0) set_tile(iss_seq);
+      char* st = smem + iss_stage * STAGE;
+      const int ko = iss_kk * (2 * BK);
+#pragma unroll
+      for (int i = 0; i < GPL; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + ko),
+                                         (__attribute__((address_space(3))) void*)(st + dst[i]), 16, 0, 0);
+      ++issued;
+      iss_stage = iss_stage + 1 == NST ? 0 : iss_stage + 1;
+      if (++iss_kk == nk) { iss_kk = 0; ++iss_seq; }
+    };
+    issue_next();
+    issue_next();
+    for (long long g = 0; g < total; ++g) {
+      if (issued > g + 1) wait_vmcnt<GPL>();               // one younger stage may stay in flight
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();                        // opens step g: slot (g + 2) % 3 was read in step g - 1 and is free
+      asm volatile("" ::: "memory");
+      issue_next();
+      __builtin_amdgcn_s_barrier();                        // phase 2g + 1
+    }
+    __builtin_amdgcn_s_barrier();                          // the "+ 1"
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumer
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r16 = lane & 15, g = lane >> 4;
+  int a_rd[4], w_rd[TN];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_rd[i] = lds_off(wm * 64 + i * 16 + r16, 2 * g);
+#pragma unroll
+  for (int i = 0; i < TN; ++i) w_rd[i] = BM * ROWB + lds_off(wn * (BN / 2) + i * 16 + r16, 2 * g);
+  // Barrier schedule (B0, B1, ... counted over the whole workgroup; step g of the continuous K-step stream):
+  //   loaders      : B(2g)  issue(g + 2)  B(2g+1)                                   ... final B(2 total)
+  //   waves 0-3    : B0 | read(g)  B(2g+1)  mfma(g)  B(2g+2)                         -> epilogue AFTER the barrier that ends the tile
+  //   waves 4-7    : B0 | B(2g+1)  read(g)  B(2g+2)  mfma(g)                         -> epilogue after the tile's last mfma
+  // so an early wave has already released its partner's last MFMA phase when it starts writing its tile out, exactly as in
+  // the one-tile kernel, and every wave executes 2 total + 1 barriers.
+  const bool late = wave >= 4;
+  __builtin_amdgcn_s_barrier();                              // B0
+  int cur = 0;
+  for (int seq = 0; seq < my_tiles; ++seq) {
+    f32x4 acc[4][TN];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kk = 0; kk < nk; ++kk) {
+      f16x8 ahi[4], alo[4], whi[TN], wlo[TN];
+      if (late) __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char* st = smem + cur * STAGE;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ahi[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(st + a_rd[i]));
+        alo[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(st + (a_rd[i] ^ 16)));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        whi[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(st + w_rd[j]));
+        wlo[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(st + (w_rd[j] ^ 16)));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_f16(wlo[j], ahi[i], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_f16(whi[j], alo[i], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_f16(whi[j], ahi[i], acc[i][j]);
+      if (!late) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      cur = cur + 1 == NST ? 0 : cur + 1;
+    }
+    int m0, n0;
+    tile_origin(seq, m0, n0);
+    run_epilogue<TN>(epi, m0 + wm * 64 + r16, n0 + wn * (BN / 2) + 4 * g, acc);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- host side
 int gemm_pick_bn(int N) {
   if (N % 128 == 0) return 128;
@@ -537,8 +698,35 @@ static void launch_split(const GemmArgs& g, const Epi& epi, hipStream_t s) {
                      ntiles, epi, deph);
 }
 
+static int persist_mode() {       // RIBCA_GEMM_PERSIST=1 (or variant 30): persistent workgroups with cross-tile prefetch
+  static const int m = getenv("RIBCA_GEMM_PERSIST") ? atoi(getenv("RIBCA_GEMM_PERSIST")) : 0;
+  return m;
+}
+template <int BN, class Epi>
+static void launch_persist(const GemmArgs& g, const Epi& epi, hipStream_t s) {
+  const int mtiles = (g.M + 255) / 256;
+  const int ntiles = gemm_padded_n(g.N) / BN;
+  const size_t lds = (size_t)3 * (256 + BN) * ROWB;
+  static bool attr_set = false;
+  static int n_cu = 0;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ps_persist_kernel<BN, Epi>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu <= 0) n_cu = 256;
+    attr_set = true;
+  }
+  const int grid = mtiles * ntiles < n_cu ? mtiles * ntiles : n_cu;
+  hipLaunchKernelGGL((gemm_ps_persist_kernel<BN, Epi>), dim3(grid), dim3(768), lds, s, g.A, g.lda, g.W, g.ldw, g.M, g.Kp, mtiles, ntiles, epi);
+}
+
 template <int BN, class Epi>
 static void launch_bn(const GemmArgs& g, const Epi& epi, hipStream_t s) {
+  if ((g_variant == 30 || (g_variant == 0 && persist_mode())) && (g.M + 255) / 256 * (gemm_padded_n(g.N) / BN) >= 512) {
+    launch_persist<BN, Epi>(g, epi, s);
+    return;
+  }
   switch (g_variant) {
     case 3: launch_split<BN, Epi, 0, false>(g, epi, s); break;   // no stagger (A/B reference)
     case 4: launch_split<BN, Epi, 1, false>(g, epi, s); break;   // ablation: no loads
@@ -578,7 +766,8 @@ void launch_gemm_gelu(const GemmArgs& g, uint16_t* out, int ldo, hipStream_t s) 
   launch_any(g, EpiGelu{out, ldo, g.bias, g.M, g.N, nt_mask() & 1}, s);
 }
 void launch_gemm_qkv(const GemmArgs& g, uint16_t* q, uint16_t* k, uint16_t* vt, const AttnGeom& a, float scale, hipStream_t s) {
-  launch_any(g, EpiQKV{q, k, vt, g.bias, a.D, a.hd, a.hdq /* Q/K row pitch: compact */, a.hdv, scale, g.M, g.N, a.T, a.TP, a.H, a.KP, (nt_mask() >> 1) & 1}, s);
+  launch_any(g, EpiQKV{q, k, vt, g.bias, a.D, a.hd, a.hdq /* Q/K row pitch: compact */, a.hdv, scale, g.M, g.N, a.T, a.TP, a.H, a.KP, (nt_mask() >> 1) & 1,
+                       (unsigned)((0x100000000ull + (unsigned long long)a.T - 1) / (unsigned long long)a.T)}, s);
 }
 void launch_gemm_rowmap(const GemmArgs& g, float* out, int ldo, const float* add, int ldadd, const int* slot, const int* addrow, int R,
                         int dst_per_cell, hipStream_t s) {

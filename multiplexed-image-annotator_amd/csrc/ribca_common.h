@@ -107,22 +107,31 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// erf to ~2e-7 absolute (Abramowitz & Stegun 7.1.26 evaluated in fp32): 1 rcp + 1 exp2 + 7 fma, branch-free.  The GELU
-// output is re-quantised to an fp16 hi/lo pair right after, so the libm erff's last bits would be
-// discarded anyway while costing ~3x the instructions in the fc1 epilogue.
-__device__ __forceinline__ float erf_fast(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  p *= t;
-  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
-  const float r = fmaf(-p, e, 1.0f);
-  return copysignf(r, x);
+// exact-erf GELU (nn.GELU() default used by timm Mlp): 0.5 x (1 + erf(x / sqrt(2))), two values at a time.
+// erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7) on z = |x| / sqrt(2):  erf(z) = 1 - q,  q = poly(t) exp(-z^2),
+// t = 1 / (1 + 0.3275911 z).  With a = |x|:   gelu = 0.5 x + a (0.5 - 0.5 q)  -- no sign select, no branch, and every
+// multiply-add is a PACKED fp32 op (v_pk_fma_f32 / v_pk_mul_f32: two lanes-worth per instruction); only the reciprocal and the
+// exponential are per value.  8.5 VALU instructions per value instead of 15: the fc1 epilogue is VALU-bound (round-2
+// measurement, tools/epilogue_scaling.py: 8.7 us per 256 x 128 tile with 18 workgroups on an idle chip, independent of K).
+// The output is re-quantised to an fp16 hi/lo pair right after, so libm erff's last bits would be discarded anyway.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2v gelu_erf2(f32x2v x) {
+  f32x2v a;
+  a.x = fabsf(x.x); a.y = fabsf(x.y);
+  const f32x2v den = a * 0.23164188814f + 1.0f;                 // 0.3275911 / sqrt(2)
+  f32x2v t;
+  t.x = __builtin_amdgcn_rcpf(den.x); t.y = __builtin_amdgcn_rcpf(den.y);
+  f32x2v p = t * 0.5307027145f + -0.7265760135f;                // 0.5 x (1.061405429, -1.453152027, 1.421413741, -0.284496736, 0.254829592)
+  p = p * t + 0.7107068705f;
+  p = p * t + -0.142248368f;
+  p = p * t + 0.127414796f;
+  p = p * t;
+  const f32x2v ea = (x * x) * -0.72134752044f;                  // -log2(e) / 2
+  f32x2v e;
+  e.x = __builtin_amdgcn_exp2f(ea.x); e.y = __builtin_amdgcn_exp2f(ea.y);
+  const f32x2v s = 0.5f - p * e;                                // 0.5 erfc-complement: 0.5 - 0.5 q
+  return a * s + x * 0.5f;
 }
-// exact-erf GELU (nn.GELU() default used by timm Mlp): 0.5 x (1 + erf(x / sqrt(2)))
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2(f32x2v{x, x}).x; }
 
 }  // namespace ribca

@@ -12,11 +12,11 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 echo "[prof] kernel trace"; date
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --streams 1 > "$OUT/bench_line_under_rocprof.json" 2> "$OUT/trace.log"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-dropin --streams 1 > "$OUT/bench_line_under_rocprof.json" 2> "$OUT/trace.log"
 echo "[prof] FETCH_SIZE"; date
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o fetch -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --cells 8000 --size 1280 > "$OUT/fetch.json" 2> "$OUT/fetch.log"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o fetch -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-dropin --cells 8000 --size 1280 > "$OUT/fetch.json" 2> "$OUT/fetch.log"
 echo "[prof] WRITE_SIZE"; date
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -o write -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --cells 8000 --size 1280 > "$OUT/write.json" 2> "$OUT/write.log"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -o write -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-dropin --cells 8000 --size 1280 > "$OUT/write.json" 2> "$OUT/write.log"
 echo "[prof] summarising"; date
 python3 "$ROOT/tools/summarize_pmc.py" "$OUT" "$TAG"
 # keep what travels back small: the per-dispatch traces are hundreds of MB
