@@ -257,15 +257,37 @@ def main():
         g_ms = sum(prof[k][0] for k in ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2"))
         g_n = sum(prof[k][1] for k in ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2"))
         achieved = gemm_flops / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_final", "gemm_traffic.json")
-        if os.path.exists(tpath):                      # HBM/fabric bytes per launch from the committed rocprofv3 PMC passes
-            traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"])
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_ps_split_kernel (qkv/proj/fc1/fc2, bf16x3)", "achieved": round(achieved, 2),
+        # committed rocprofv3 evidence for the same kernels (tools/collect_profiles.sh, tools/collect_pmc_sq.sh): HBM/fabric bytes per
+        # launch from the FETCH_SIZE / WRITE_SIZE passes, MFMA-busy and LDS-active fractions from the SQ counter passes
+        traffic, traffic_src, busy, lds = None, None, None, None
+        for tag in ("r2", "r1_final"):
+            tpath = os.path.join(ROOT, "profiles", tag, "gemm_traffic.json")
+            if os.path.exists(tpath):
+                traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"])
+                traffic_src = f"profiles/{tag}/gemm_traffic.json"
+                break
+        spath = os.path.join(ROOT, "profiles", "r2", "sq_summary.json")
+        if os.path.exists(spath):
+            sq = json.load(open(spath))
+            gem = [v for k, v in sq.items() if k.startswith("gemm_ps_split_kernel")]
+            cyc = sum(v["kernel_cycles"] for v in gem)
+            if cyc > 0:
+                busy = round(sum(v["mfma_busy_frac"] * v["kernel_cycles"] for v in gem) / cyc, 4)
+                lds = round(sum(v["lds_active_frac"] * v["kernel_cycles"] for v in gem) / cyc, 4)
+        alg_bytes = 0.0
+        for name, model in models.items():      # algorithmic bytes per pass of the four GEMMs: A read once, output written once, z RMW
+            d = model.D
+            per_row = 4.0 * d * (1 + 3) + 4.0 * d * (1 + 2) + 4.0 * d * (1 + 4) + 4.0 * d * (4 + 2)      # qkv, proj, fc1, fc2
+            alg_bytes += n_local * 101 * (model.depth - 1) * per_row + 12.0 * d * d * 4.0 * model.depth * ((n_local + args.chunk - 1) // args.chunk)
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_ps_split_kernel (qkv/proj/fc1/fc2, fp16x3)", "achieved": round(achieved, 2),
                            "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 5),
-                           "traffic": traffic, "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r1_final/gemm_traffic.json)",
+                           "traffic": traffic, "traffic_unit": f"bytes/launch (2*FETCH_SIZE + WRITE_SIZE, {traffic_src})",
+                           "algorithmic_bytes_per_launch": round(alg_bytes / max(g_n, 1)),
+                           "mfma_busy_frac": busy, "lds_active_frac": lds,
+                           "counters": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), SQ_LDS_IDX_ACTIVE / (256 CUs x ...): profiles/r2/sq_summary.json",
                            "launches": int(g_n), "avg_launch_ms": round(g_ms / max(g_n, 1), 5),
                            "algorithmic_gflop_per_launch": round(gemm_flops / max(g_n, 1) / 1e9, 4), "mfma_passes_per_product": 3,
+                           "issued_mfma_frac_of_peak": round(3 * achieved / PEAK_BF16_DENSE_TFLOPS, 4),
                            "per_kernel_ms": {k: round(v[0], 3) for k, v in prof.items() if v[1]}}
 
     # ---- the boundary itself: Annotator.preprocess -> predict -> export_annotations from host files ------------------------

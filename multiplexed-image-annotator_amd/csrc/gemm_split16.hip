@@ -172,6 +172,14 @@ struct EpiRowMap {
   }
 };
 
+// Values that came from global loads are passed through an empty asm statement before the store loop of the LDS drain: the
+// compiler's wait-count pass then settles them once (one s_waitcnt), instead of re-emitting s_waitcnt vmcnt(0) at their first use
+// in every exec-masked iteration -- where it would also wait for the store issued by the previous iteration.
+__device__ __forceinline__ void settle(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+template <class Ctx> __device__ __forceinline__ void settle_ctx(Ctx&) {}
+template <> __device__ __forceinline__ void settle_ctx<EpiResid::Ctx>(EpiResid::Ctx& c) { settle(c.zv); }
+template <> __device__ __forceinline__ void settle_ctx<EpiRowMap::Ctx>(EpiRowMap::Ctx& c) { settle(c.a); }
+
 // two-sweep driver shared by the kernels: lane owns rows m_i = mbase + 16 i and column groups n_j = nbase + 16 j
 template <class Epi, class = void> struct has_rowcol : std::false_type {};
 template <class Epi> struct has_rowcol<Epi, std::void_t<typename Epi::Row>> : std::true_type {};
@@ -186,6 +194,13 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, int mbase, int nbas
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) epi.fetch(mbase + 16 * i, nbase + 16 * j, ctx[i][j]);
+  // one wait for everything that was loaded, before the first store (see settle())
+#pragma unroll
+  for (int j = 0; j < TN; ++j) settle(b4[j]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) settle_ctx(ctx[i][j]);
   if constexpr (has_rowcol<Epi>::value) {
     typename Epi::Row rows[4];
     typename Epi::Col cols[TN];
@@ -262,32 +277,45 @@ __device__ __forceinline__ void lds_drain(const Epi& epi, const char* smem, int 
   static_assert(768 % CPR == 0, "a thread keeps its column chunk across passes");
   const int c = tid % CPR, row0 = tid / CPR;
   const int n = n0 + 4 * c;
-  const float4 b4 = epi.fetch_bias(n);
+  float4 b4 = epi.fetch_bias(n);
   typename Epi::Ctx ctx[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int row = row0 + it * RSTEP;
     if (NIT * RSTEP == 256 || row < 256) epi.fetch(m0 + row, n, ctx[it]);
   }
+  // ALL of this thread's chunks leave LDS before the first store is issued.  The kernel contains LDS-DMA, so hipcc guards every
+  // use of a ds_read result with s_waitcnt vmcnt(0) (an LDS-DMA could be pending for all it knows) -- interleaved with the stores
+  // (read, compute, store, read, ...) that wait also drained the PREVIOUS iteration's global store, i.e. one HBM write round
+  // trip per iteration, 8-11 times per tile: most of the 6-9 us the epilogue took (tools/epilogue_scaling.py).  With the reads
+  // hoisted the single wait sits before any store and the stores stream out back to back.
   const char* src = smem + row0 * SROW + c * 16;
+  f32x4 vals[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int row = row0 + it * RSTEP;
+    vals[it] = (NIT * RSTEP == 256 || row < 256) ? *reinterpret_cast<const f32x4*>(src + it * RSTEP * SROW) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // Passing the values through an (empty) asm statement makes the compiler's wait-count pass settle every LDS read HERE; without
+  // it each first use inside the store loop re-emits s_waitcnt vmcnt(0) and serialises on the store issued just before.
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(vals[it]));
+  settle(b4);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) settle_ctx(ctx[it]);
+  __builtin_amdgcn_sched_barrier(0);
   if constexpr (has_rowcol<Epi>::value) {
     const typename Epi::Col col = epi.col(n);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int row = row0 + it * RSTEP;
-      if (NIT * RSTEP == 256 || row < 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + it * RSTEP * SROW);
-        epi.template apply<1>(m0 + row, n, v, b4, ctx[it], epi.row(m0 + row), col);
-      }
+      if (NIT * RSTEP == 256 || row < 256) epi.template apply<1>(m0 + row, n, vals[it], b4, ctx[it], epi.row(m0 + row), col);
     }
   } else {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int row = row0 + it * RSTEP;
-      if (NIT * RSTEP == 256 || row < 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + it * RSTEP * SROW);
-        epi.template apply<1>(m0 + row, n, v, b4, ctx[it]);
-      }
+      if (NIT * RSTEP == 256 || row < 256) epi.template apply<1>(m0 + row, n, vals[it], b4, ctx[it]);
     }
   }
 }

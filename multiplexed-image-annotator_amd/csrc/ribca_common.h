@@ -84,8 +84,14 @@ __device__ __forceinline__ void ps_store4_pair(uint16_t* row, int k, const float
   const bool odd = (k & 4) != 0;
   const uint2 send = odd ? hi : lo;
   uint2 recv;
-  recv.x = __shfl_xor(send.x, PX, 64);
-  recv.y = __shfl_xor(send.y, PX, 64);
+  if constexpr (PX == 1) {
+    // neighbour lane inside a quad: one DPP move (quad_perm [1,0,3,2]) instead of a ds_bpermute round trip through the LDS unit
+    recv.x = (uint32_t)__builtin_amdgcn_mov_dpp((int)send.x, 0xB1, 0xF, 0xF, true);
+    recv.y = (uint32_t)__builtin_amdgcn_mov_dpp((int)send.y, 0xB1, 0xF, 0xF, true);
+  } else {
+    recv.x = __shfl_xor(send.x, PX, 64);
+    recv.y = __shfl_xor(send.y, PX, 64);
+  }
   const u32x4 o = odd ? u32x4{recv.x, recv.y, lo.x, lo.y} : u32x4{hi.x, hi.y, recv.x, recv.y};
   u32x4* dst = reinterpret_cast<u32x4*>(row + ps_off(k & ~7) + (odd ? 8 : 0));
   if (nt) __builtin_nontemporal_store(o, dst);      // streamed once, read by a later launch: keep it out of this XCD's L2
