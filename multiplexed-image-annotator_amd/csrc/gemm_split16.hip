@@ -637,6 +637,7 @@ __global__ __launch_bounds__(768) void gemm_ps_persist_kernel(const uint16_t* __
   // so an early wave has already released its partner's last MFMA phase when it starts writing its tile out, exactly as in
   // the one-tile kernel, and every wave executes 2 total + 1 barriers.
   const bool late = wave >= 4;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   __builtin_amdgcn_s_barrier();                              // B0
   int cur = 0;
   for (int seq = 0; seq < my_tiles; ++seq) {
@@ -649,16 +650,18 @@ __global__ __launch_bounds__(768) void gemm_ps_persist_kernel(const uint16_t* __
       f16x8 ahi[4], alo[4], whi[TN], wlo[TN];
       if (late) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      const char* st = smem + cur * STAGE;
+      // Fragment reads as inline asm: for a plain LDS load hipcc would put s_waitcnt vmcnt(0) in front of the first MFMA of every
+      // tile (the kernel contains LDS-DMA), i.e. wait for the previous tile's epilogue stores -- the very overlap this form exists for.
+      const unsigned st = lds_base + (unsigned)(cur * STAGE);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        ahi[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(st + a_rd[i]));
-        alo[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(st + (a_rd[i] ^ 16)));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(ahi[i]) : "v"(st + (unsigned)a_rd[i]) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(alo[i]) : "v"(st + (unsigned)(a_rd[i] ^ 16)) : "memory");
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        whi[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(st + w_rd[j]));
-        wlo[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(st + (w_rd[j] ^ 16)));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(whi[j]) : "v"(st + (unsigned)w_rd[j]) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(wlo[j]) : "v"(st + (unsigned)(w_rd[j] ^ 16)) : "memory");
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
