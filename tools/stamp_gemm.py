@@ -18,9 +18,9 @@ cells = 1024
 M = cells * 101
 g = torch.Generator().manual_seed(0)
 for name, d, n, kp, kind in (("proj576", 576, 576, 576, 0), ("fc1_576", 576, 2304, 576, 1), ("fc2_576", 576, 576, 2304, 0), ("fc1_288", 288, 1152, 288, 1)):
-    a = (torch.randn((M, 2 * kp), generator=g) * 0.1).to(torch.bfloat16).view(torch.int16).to(dev)
+    a = (torch.randn((M, 2 * kp), generator=g) * 0.1).to(torch.float16).view(torch.int16).to(dev)
     npad = lib().ribca_gemm_padded_n(n)
-    w = (torch.randn((npad, 2 * kp), generator=g) * 0.1).to(torch.bfloat16).view(torch.int16).to(dev)
+    w = (torch.randn((npad, 2 * kp), generator=g) * 0.1).to(torch.float16).view(torch.int16).to(dev)
     bias = torch.zeros(n, device=dev)
     out = torch.zeros((M, n if kind == 0 else 2 * n), dtype=torch.float32 if kind == 0 else torch.int16, device=dev)
     ldo = n if kind == 0 else 2 * n
