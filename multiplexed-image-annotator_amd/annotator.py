@@ -106,6 +106,7 @@ class Annotator(object):
         self.imputers: Dict[str, ops.MaeModel] = {}
         self._weights: Dict[str, Dict[str, torch.Tensor]] = {}
         self.probs: List[Dict[str, np.ndarray]] = []       # per image: model -> (n, K) fp32 host table
+        self._conf_arrays: List[np.ndarray] = []           # per image: the float32 confidences behind self.confidence (-1.0 = thresholded)
         self.label_ids: List[np.ndarray] = []
         self.chunk_cells = int(os.environ.get("RIBCA_CHUNK_CELLS", "1024"))
         self.streams = int(os.environ.get("RIBCA_STREAMS", "3"))      # cell segments in flight per classifier (ops.VitModel.predict_proba)
@@ -180,6 +181,7 @@ class Annotator(object):
         self.immune_base_pred, self.immune_extended_pred, self.immune_full_pred = [], [], []
         self.struct_pred, self.nerve_pred = [], []
         self.annotations = []
+        self._conf_arrays = []
 
     def _active_models(self) -> Dict[str, Optional[str]]:
         """model.py:241-349: one immune model (full > extended > base) plus struct / nerve when their panels apply."""
@@ -270,6 +272,7 @@ class Annotator(object):
             names = np.array(ops.GLOBAL_NAMES, dtype=object)
             self.annotations.append(names[lab_h].tolist())
             self.confidence.append([-1 if c == -1 else c for c in conf_h])    # int -1 marks a thresholded cell, as in model.py:507
+            self._conf_arrays.append(conf_h)
         self.logger.log("Finished predicting cell types and tissue structures.")
         self.cell_types = self._get_unique_cell_types()
         self.cell_types = np.delete(self.cell_types, np.where(self.cell_types == "Others"))
@@ -326,14 +329,22 @@ class Annotator(object):
             rows = np.round(tab[:, 4].astype(np.float64) / tab[:, 6].astype(np.float64), 2)
             cols = np.round(tab[:, 5].astype(np.float64) / tab[:, 6].astype(np.float64), 2)
             regions = getattr(self, "tissue_regions", None)
+            # The reference prints ``round(np.float32, 3)`` through an f-string (the float32 widened to double, e.g.
+            # 0.5360000133514404) and the int -1 of a thresholded cell as "-1".  Same text, rounded and widened in one numpy call
+            # instead of 100 k Python round() calls when the confidences are still the float32 table predict() produced.
+            arr = self._conf_arrays[i] if i < len(getattr(self, "_conf_arrays", [])) and len(self._conf_arrays[i]) == len(conf) else None
+            if arr is not None:
+                conf_txt = ["-1" if v == -1.0 else repr(v) for v in np.round(arr, 3).tolist()]
+            else:
+                conf_txt = [f"{round(c, 3)}" for c in conf]
+            keys, labs, rl, cl = ids.tolist(), self.annotations[i], rows.tolist(), cols.tolist()
             with open(path, "w") as f:
                 f.write("Cell Index,Cell Type,Confidence,Row,Column,Tissue Region\n")
-                lines = []
-                for j, key in enumerate(ids.tolist()):
-                    c = round(conf[j], 3)
-                    region = "Region " + str(regions[i][key]) if regions is not None else None
-                    lines.append(f"{key},{self.annotations[i][j]},{c},{rows[j]},{cols[j]},{region}\n")
-                f.write("".join(lines))
+                if regions is None:
+                    f.write("".join([f"{k},{l},{c},{r},{cc},None\n" for k, l, c, r, cc in zip(keys, labs, conf_txt, rl, cl)]))
+                else:
+                    reg = regions[i]
+                    f.write("".join([f"{k},{l},{c},{r},{cc},Region {reg[k]}\n" for k, l, c, r, cc in zip(keys, labs, conf_txt, rl, cl)]))
             self.logger.log(f"Exported annotations for image {i} to {path}")
 
     def clear_tmp(self):
