@@ -104,7 +104,17 @@ def main():
     if args.launch_check:
         sys.exit(launch_check(args, world, rank, backend))
     if args.config1:
-        sys.exit(config1_bench(args))
+        import contextlib
+        import io
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):             # the Annotator's own prints go to stderr, the JSON line alone to stdout
+            rc = config1_bench(args)
+        lines = buf.getvalue().splitlines()
+        print("\n".join(l for l in lines if not l.startswith("{")), file=sys.stderr)
+        for l in lines:
+            if l.startswith("{"):
+                print(l)
+        sys.exit(rc)
     if world > 1:
         import torch.distributed as tdist
         if os.environ.get("RIBCA_SHARE_GPU") == "1":
@@ -292,7 +302,9 @@ def main():
 
     # ---- the boundary itself: Annotator.preprocess -> predict -> export_annotations from host files ------------------------
     if not args.no_dropin and rank == 0 and world == 1 and not args.impute:
-        out["dropin"] = dropin_bench(args, raw, mask, markers, models, srcs, one_pass_models=lambda sel: one_pass(models_sel=sel))
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):      # the Annotator prints the reference's panel messages: keep stdout to ONE JSON line
+            out["dropin"] = dropin_bench(args, raw, mask, markers, models, srcs, one_pass_models=lambda sel: one_pass(models_sel=sel))
 
     # ---- CPU baseline: the oracle (numpy/scipy/torch fp32 restatement of the reference path) on a bounded sample ------------
     if not args.no_cpu_baseline and rank == 0 and world == 1:

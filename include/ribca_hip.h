@@ -180,8 +180,9 @@ int32_t ribca_gemm_padded_n(int32_t N);
 /* Measurement hook: 0 = production GEMM; 3 = without the half-step stagger; 4/5/7/9 = timing ablations (no loads / loads
  * only / no loads + stagger / no epilogue) whose RESULTS ARE WRONG by construction -- used by tools/bench_gemm.py only. */
 int ribca_set_gemm_variant(int32_t v);
-/* Diagnostics for variant 12: device buffer of 6 x uint64 per workgroup receiving 100 MHz time stamps (entry, first stage
- * landed, K loop done, epilogue stores accepted) and the XCC / HW id the workgroup ran on.  NULL disables. */
+/* Diagnostics for variant 12: device buffer of 20 x uint64 per workgroup receiving 100 MHz time stamps (entry, first stage
+ * landed, K loop done, epilogue stores accepted), the XCC / HW id the workgroup ran on, and in [6..17] the time each of the 12
+ * waves had its epilogue stores accepted.  NULL disables. */
 int ribca_set_gemm_stamps(void* dev_buffer);
 
 #ifdef __cplusplus

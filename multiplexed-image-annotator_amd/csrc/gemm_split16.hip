@@ -244,6 +244,7 @@ template <int CNT> __device__ __forceinline__ void wait_vmcnt() {
 // entry, after the first stage has landed, after the K loop and after its epilogue, plus the XCC/CU it ran on, into a
 // buffer nothing else reads.
 __device__ unsigned long long* g_stamps = nullptr;
+constexpr int kStampStride = 20;   // per workgroup: t0..t3, xcc, hw id, then the epilogue end of each of the 12 waves
 __device__ __forceinline__ unsigned long long stamp_now() { return __builtin_amdgcn_s_memrealtime(); }
 
 // ---------------------------------------------------------------------------------------------- epilogue through LDS
@@ -419,6 +420,10 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
         lds_drain<BN>(epi, smem, m0, n0, tid);
       }
     }
+    if (ABL == 4 && g_stamps != nullptr && lane == 0) {      // per-wave end of the epilogue (stores accepted)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      g_stamps[(size_t)blockIdx.x * kStampStride + 6 + wave] = stamp_now();
+    }
     return;
   }
 
@@ -521,10 +526,15 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
   } else {
     run_epilogue<TN>(epi, m0 + wm * 64 + r16, n0 + wn * (BN / 2) + 4 * g, acc);
   }
+  if (ABL == 4 && g_stamps != nullptr && lane == 0 && tid != 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    g_stamps[(size_t)blockIdx.x * kStampStride + 6 + wave] = stamp_now();
+  }
   if (ABL == 4 && g_stamps != nullptr && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // epilogue stores of this wave have been accepted
     const unsigned long long t3 = stamp_now();
-    unsigned long long* o = g_stamps + (size_t)blockIdx.x * 6;
+    unsigned long long* o = g_stamps + (size_t)blockIdx.x * kStampStride;
+    o[6] = t3;
     o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3;
     unsigned int xcc, hwid;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));

@@ -374,6 +374,40 @@ def test_normalize_large_matches_oracle(dev):
     np.testing.assert_array_equal(got, ref_preprocess.normalize_image(raw, blur=0.3, amax=99.8))
 
 
+def test_normalize_threshold_branches_match_oracle(dev):
+    """the three per-plane scalars of the finalise kernel (mode, clip, denom) must reach it un-aliased.  Planes chosen so
+    that every branch of preprocess.py:228-239 differs between them: the amax percentile lies in (20, 25) (clip at t, divide by 25),
+    no positive pixel at all (plane of -1), t > 25 (clip at t, divide by t), and t <= 20 (no clip, divide by max(25, max)).  The
+    oracle is bit-exact against the reference's own _normalize (tests/golden/normalize.npz)."""
+    from oracle import ref_preprocess
+    ops = _ops()
+    h, w = 256, 320
+    rng = np.random.default_rng(5)
+    flat = rng.integers(40, 60, (h, w)).astype(np.float64)               # background ~50, removed by the sigma-20 filter
+    def plane(peak, frac):
+        x = flat.copy()
+        m = rng.random((h, w)) < frac
+        x[m] += peak * rng.random(int(m.sum()))
+        return x
+    raw = np.stack([plane(24, 0.02),        # t in (20, 25): 23.2, plane maximum 32
+                    np.zeros((h, w)),        # nothing positive -> -1
+                    plane(4000, 0.05),       # t > 25
+                    plane(8, 0.01)]          # t <= 20
+                   ).astype(np.uint16)
+    ref = ref_preprocess.normalize_image(raw, blur=0, amax=99.8)
+    # the planes really take four different branches
+    x = raw.astype(np.float32)
+    from scipy.ndimage import gaussian_filter
+    ts = []
+    for c in range(4):
+        v = np.clip(x[c] - np.minimum(gaussian_filter(x[c], 20), 125), 0, None)
+        ts.append(float(np.percentile(v, 99.8)) if (v > 0).any() else None)
+    assert 20 < ts[0] < 25 and ts[1] is None and ts[2] > 25 and ts[3] <= 20, ts
+    got = ops.normalize_image(raw, blur=0, amax=99.8).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    assert (got[1] == -1).all()
+
+
 # ------------------------------------------------------------------------------------------- marker imputer
 def _mae_inputs(panel, n, seed):
     L = synth.MAE_PANELS[panel]

@@ -26,7 +26,7 @@ for name, d, n, kp, kind in (("proj576", 576, 576, 576, 0), ("fc1_576", 576, 230
     ldo = n if kind == 0 else 2 * n
     bn = 128 if n % 128 == 0 else (96 if n % 96 == 0 else 64)
     nblk = ((M + 255) // 256) * (npad // bn)
-    stamps = torch.zeros((nblk, 6), dtype=torch.int64, device=dev)
+    stamps = torch.zeros((nblk, 20), dtype=torch.int64, device=dev)
     lib().ribca_set_gemm_stamps(ptr(stamps))
     lib().ribca_set_gemm_variant(12)
     for _ in range(2):
@@ -50,3 +50,13 @@ for name, d, n, kp, kind in (("proj576", 576, 576, 576, 0), ("fc1_576", 576, 230
                      ("gap to next workgroup on the same CU", np.array(gaps))):
         if len(v):
             print(f"   {label:44s} median {np.median(v):7.2f}  p10 {np.percentile(v, 10):7.2f}  p90 {np.percentile(v, 90):7.2f} us")
+    ends = (t[:, 6:18] - t2[:, None]) * us            # every wave's "stores accepted" relative to the end of wave 0's K loop
+    print("   per-wave epilogue end after K loop (median us): consumers " + " ".join(f"{np.median(ends[:, w]):.2f}" for w in range(8))
+          + " | loaders " + " ".join(f"{np.median(ends[:, w]):.2f}" for w in range(8, 12)))
+    last = ends.max(axis=1)
+    gaps2 = []
+    for key in np.unique(cu):
+        sel = np.flatnonzero(cu == key)
+        order = sel[np.argsort(t0[sel])]
+        gaps2 += list((t0[order][1:] - (t2[order][:-1] + last[order][:-1] / us)) * us)
+    print(f"   last wave done {np.median(last):.2f} us after the K loop; next workgroup enters {np.median(gaps2):.2f} us after that (median)")
