@@ -1,0 +1,377 @@
+// "Duo" form of the fp16x3 GEMM: TWO 256-thread workgroups per CU, each a whole 256 x BN tile (same numerics, operand formats and
+// epilogue functors as gemm_split16.hip; reached from reference cell_type_annotation/model.py:402 ``model(x)`` through the timm
+// Linear layers of every Block).
+//
+// Why: round-2 counters and ablations show the one-workgroup-per-CU kernel spending a third of a launch in
+// phases in which the matrix pipe is idle by construction -- the tile's epilogue (park, GELU / residual, 128 KB of stores), the
+// next workgroup's start and its first ring stage in flight -- because a 144 KB ring leaves no LDS for a second workgroup.  Here
+// the LDS footprint of a tile is cut to 64 KB so that two independent workgroups share a CU: while one writes its tile out or
+// waits for its first operands, the other owns the matrix pipe; the hardware scheduler does the overlap, no persistent-kernel
+// hand-offs.
+//
+// * A (activations, 256 rows x 128 B per 32-deep K step) goes through a 2-stage LDS ring filled by global_load_lds_dwordx4, issued
+//   by the four waves themselves (8 per wave and step), XOR-swizzled exactly as in gemm_split16.hip.
+// * W never touches LDS: the weights are static, so ribca keeps a second copy in FRAGMENT ORDER (pack_wf_kernel): for n-tile jt (16
+//   output columns) and K step s a 2 KB block [hi: 64 lanes x 16 B | lo: 64 lanes x 16 B], lane (r16, g) holding W[16 jt + r16][32 s +
+//   8 g .. + 7].  A wave's W fragment is then ONE fully coalesced 1 KB global_load_dwordx4 straight into the MFMA operand
+//   registers, prefetched one K step ahead into a second register set.  The two waves that share columns request the same lines
+//   back to back (L1 / L2 hits).
+// * 4 waves as 2 (M) x 2 (N): a wave owns 128 x BN/2 outputs = 8 x TN accumulator tiles (128 registers at BN = 128).  A fragments
+//   are streamed from LDS one m-tile ahead of their 3 TN MFMAs (inline-asm ds_read_b128 + counted lgkmcnt: with LDS-DMA in the
+//   kernel hipcc would guard every LDS read with s_waitcnt vmcnt(0), i.e. wait for the prefetch just issued).
+// * One s_barrier per K step (4 waves): "stage k landed for everyone, stage k - 1 read by everyone".
+// * Accumulation order per output element is the one of gemm_split16.hip (per K step: lo*hi, hi*lo, hi*hi), so results are
+//   bit-identical to that kernel's.
+// * Epilogue straight from the accumulator registers (run_epilogue): its latency chain and store shape now overlap the other
+//   workgroup's K loop.
+#include <cstdlib>
+#include <map>
+#include <tuple>
+#include <utility>
+
+#include "gemm_epi.h"
+
+namespace ribca {
+
+namespace {
+
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_read16(f16x8& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void gload16(f16x8& dst, unsigned voff, const void* sbase) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+
+}  // namespace
+
+// weight [Np][2*Kp] packed-split  ->  fragment order (see the header comment); one thread per 16-byte vector
+__global__ void pack_wf_kernel(const uint16_t* __restrict__ W, int ldw, int Np, int nk, uint16_t* __restrict__ WF) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)(Np / 16) * nk * 128;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63), hl = (int)((idx >> 6) & 1);
+  const long long blk = idx >> 7;
+  const int s = (int)(blk % nk), jt = (int)(blk / nk);
+  const int r16 = lane & 15, g = lane >> 4;
+  const uint4* src = reinterpret_cast<const uint4*>(W + (size_t)(16 * jt + r16) * ldw + (4 * s + g) * 16 + hl * 8);
+  reinterpret_cast<uint4*>(WF)[idx] = *src;
+}
+void launch_pack_wf(const uint16_t* W, int ldw, int Np, int Kp, uint16_t* WF, hipStream_t s) {
+  const int nk = Kp / BK;
+  const long long total = (long long)(Np / 16) * nk * 128;
+  hipLaunchKernelGGL(pack_wf_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W, ldw, Np, nk, WF);
+}
+
+// Diagnostic stamps (ABL = 4, variant 44): same record as gemm_split16.hip's variant 12 -- per workgroup t0 entry, t1 first stage
+// landed, t2 K loop done, t3 stores accepted (wave 0), XCC id, HW id, then each wave's "stores accepted" -- into a buffer nothing reads.
+static __device__ unsigned long long* g_duo_stamps = nullptr;
+int duo_set_stamp_buffer(void* dev_ptr) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_duo_stamps), &dev_ptr, sizeof(dev_ptr)); }
+
+// ABL bit mask (timing ablations, results wrong on purpose): 1 = no epilogue, 2 = no A loads, 4 = no W loads; 8 = stamps (results correct)
+// BM = rows of the tile: 256 with a 2-stage A ring (64 KB; operands of step k + 1 in flight during step k), or 192 with a 3-stage ring
+//      (72 KB) and three W register sets: operands of steps k + 1 and k + 2 in flight.  One K step of one workgroup is 0.55-0.75 us
+//      of MFMA issue, an L2 round trip under load 1-1.5 us: with one step of prefetch a workgroup that has the CU's matrix pipe to
+//      itself (its neighbour is in its epilogue) is latency-bound (measured 1.6 us per step), with two steps it is not.
+// WM = waves along M: 2 -> waves as 2 (M) x 2 (N), a wave owns BM/2 rows x BN/2 columns, the two waves of a column half request the
+//                          same W fragments;
+//                     1 -> waves as 1 x 4, a wave owns ALL rows x BN/4 columns: every W fragment is requested once per workgroup,
+//                          every wave reads the whole A stage from LDS (96-128 KB of LDS reads per workgroup and step, 1/3 of the array).
+// NW = waves per workgroup (4 or 8: two workgroups per CU either way, by LDS), WM x WN = NW their layout, NWS = W register sets.
+// With 4 waves a workgroup has ONE wave per SIMD: its epilogue (GELU + split, ~80 VALU instructions per 16 x 16 tile) then issues
+// from a single in-order wave beside the neighbour workgroup's MFMA stream -- measured 14.5 cycles per VALU instruction, 13 us per
+// tile against 5.4 us with the CU to itself, and the neighbour's K loop a third slower.  8 waves (128 registers each) put two
+// waves per SIMD on every phase.
+template <int BM, int NW, int WM, int TN, int NWS, class Epi, int ABL>
+__global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ WF, int M,
+                                                                       int Kp, int mtiles, int ntiles, Epi epi, int mode, int delay) {
+  static_assert(BM == 256 || BM == 192, "tile rows");
+  constexpr int NST = BM == 256 ? 2 : 3;      // ring stages
+  static_assert(NWS == NST || (NST == 3 && NWS == 2), "W register sets");
+  constexpr int WN = NW / WM, BN = 16 * TN * WN;
+  constexpr int MT = BM / 16 / WM;            // m-tiles per wave
+  // epilogue blocks of RB row tiles: the whole wave tile at once where its residual / table loads fit beside the accumulators
+  // (all of them in flight together: one round trip instead of one per block), else 4 or 3 row tiles at a time
+  constexpr int RB = MT * TN <= (NW == 8 ? 12 : 24) ? MT : (MT % 4 == 0 ? 4 : 3), NB = MT / RB;
+  static_assert(NB * RB == MT, "row tiles per wave");
+  constexpr int STAGE = BM * ROWB;            // A only
+  constexpr int GPW = BM / 8 / NW;            // 8-row DMA groups per wave and stage
+  static_assert(GPW * 8 * NW == BM, "DMA groups");
+  constexpr int NA = (ABL & 2) ? 0 : GPW, NWL = (ABL & 4) ? 0 : 2 * TN;   // vector-memory operations per K step and wave: A, W
+  // issue order inside a step: W (for step k + NWS - 1), then A (for step k + NST - 1); what may stay in flight at the top of step k
+  constexpr int FLY = NST == 2 ? 0 : (NWS == 3 ? NA + NWL : NA);
+  constexpr int PERIOD = NST == NWS ? NST : NST * NWS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nblk = mtiles * ntiles;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int mt = bid / ntiles, nt = bid - mt * ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int nk = Kp / BK;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+  if (ABL & 8) ts0 = __builtin_amdgcn_s_memrealtime();
+  // mode bit 0: static wave priority by the CU's workgroup slot (TG_ID of HW_ID, bits 19:16); bit 1: the first round's odd-slot
+  // workgroups start `delay` x 10 ns late; bit 2: epilogue at raised priority (A/B switches: none paid)
+  if (mode & 3) {
+    unsigned int hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    const bool odd_slot = ((hwid >> 16) & 1u) != 0;
+    if (mode & 1) {
+      if (odd_slot) __builtin_amdgcn_s_setprio(0);
+      else __builtin_amdgcn_s_setprio(2);
+    }
+    if ((mode & 2) && odd_slot && (int)blockIdx.x < 1024) {
+      const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)delay;
+      while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(16);
+    }
+  }
+
+  // ---- A ring: wave w loads the 8-row groups w, w + NW, ... of every stage (1 KB per instruction) through a buffer descriptor
+  // over the tile's rows: ONE per-lane offset register, everything that varies (group, K step) in the scalar offset, and rows beyond
+  // M read as zeros by the descriptor's range check (their outputs are dropped by the epilogue guards).
+  const int rows_here = (M - m0) < BM ? (M - m0) : BM;
+  const __amdgpu_buffer_rsrc_t a_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A + (size_t)m0 * lda), 0, rows_here * lda * 2, 0x00020000);
+  int a_voff;
+  {
+    const int drow = wave * 8 + (lane >> 3);
+    const int dch = (lane & 7) ^ swz_f(drow);   // swz_f(row + 32 i) == swz_f(row): the stride between a wave's groups is 8 NW rows
+    a_voff = drow * lda * 2 + dch * 16;
+  }
+  const int a_gstride = 8 * NW * lda * 2;       // bytes between the groups of one wave
+  auto issue_a = [&](int kk, int slot) {
+    if (ABL & 2) return;
+    char* st = smem + slot * STAGE + wave * 1024;
+    const int ko = kk * (4 * BK);
+#pragma unroll
+    for (int i = 0; i < GPW; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(st + i * (1024 * NW)), 16, a_voff, i * a_gstride + ko, 0,
+                                               0);
+  };
+  // ---- W fragments: n-tiles jt0 .. jt0 + TN - 1 of this wave, 2 KB per (n-tile, K step)
+  const unsigned wvoff = (unsigned)lane * 16u;
+  const char* wbase = reinterpret_cast<const char*>(WF) + (size_t)((n0 >> 4) + wn * TN) * (size_t)nk * 2048;
+  const size_t wjstride = (size_t)nk * 2048;
+  f16x8 whi[NWS][TN], wlo[NWS][TN];
+  auto issue_w = [&](int kk, f16x8 (&hi)[TN], f16x8 (&lo)[TN]) {
+    if (ABL & 4) return;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const char* p = wbase + (size_t)j * wjstride + (size_t)kk * 2048;
+      gload16<0>(hi[j], wvoff, p);
+      gload16<1024>(lo[j], wvoff, p);
+    }
+  };
+
+  f32x4 acc[NB][RB][TN];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (ABL & 4) {
+#pragma unroll
+    for (int s = 0; s < NWS; ++s)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) whi[s][j] = wlo[s][j] = f16x8{};
+  }
+
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned a_hi = lds_base + (unsigned)lds_off(wm * (16 * MT) + r16, 2 * g);     // + 2048 per m-tile, + STAGE per slot
+  const unsigned a_lo = a_hi ^ 16u;
+
+  // K step kk on ring slot SA = kk % NST with W set SW = kk % NWS
+  auto step = [&](auto sa_c, auto sw_c, int kk) {
+    constexpr int SA = decltype(sa_c)::value, SW = decltype(sw_c)::value;
+    // the operands of step kk have landed; younger ones (FLY operations: issued one step ago) may stay in flight
+    if (FLY > 0 && kk + 1 < nk) wait_vmcnt<FLY>();
+    else wait_vmcnt<0>();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(whi[SW][j]), "+v"(wlo[SW][j]));
+    __builtin_amdgcn_s_barrier();             // stage kk landed for every wave; the slot of stage kk - 1 read by all
+    asm volatile("" ::: "memory");
+    if ((ABL & 8) && kk == 0) ts1 = __builtin_amdgcn_s_memrealtime();
+    if (kk + NWS - 1 < nk) {
+      constexpr int SN = (SW + NWS - 1) % NWS;
+      issue_w(kk + NWS - 1, whi[SN], wlo[SN]);
+    }
+    if (kk + NST - 1 < nk) issue_a(kk + NST - 1, (SA + NST - 1) % NST);
+    __builtin_amdgcn_sched_barrier(0);
+    f16x8 ah[2], al[2];
+    const unsigned a_hi_s = a_hi + (unsigned)(SA * STAGE), a_lo_s = a_lo + (unsigned)(SA * STAGE);   // (the 16-bit offset field cannot hold slot 2)
+    lds_read16<0>(ah[0], a_hi_s);
+    lds_read16<0>(al[0], a_lo_s);
+    static_for<MT>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int cur = i & 1, nxt = cur ^ 1;
+      if constexpr (i + 1 < MT) {
+        lds_read16<(i + 1) * 2048>(ah[nxt], a_hi_s);
+        lds_read16<(i + 1) * 2048>(al[nxt], a_lo_s);
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[cur]), "+v"(al[cur])::"memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[cur]), "+v"(al[cur])::"memory");
+      }
+      f32x4(&a)[TN] = acc[i / RB][i % RB];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) a[j] = mfma_f16(wlo[SW][j], ah[cur], a[j]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) a[j] = mfma_f16(whi[SW][j], al[cur], a[j]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) a[j] = mfma_f16(whi[SW][j], ah[cur], a[j]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  // prologue, in the steady-state order (W of step s before A of step s + (NST - NWS) ...): steps 0 .. NST - 2 of A, 0 .. NWS - 2 of W
+  static_for<NST - 1>([&](auto s_c) {
+    constexpr int S = decltype(s_c)::value;
+    if (S < NWS - 1 && S < nk) issue_w(S, whi[S], wlo[S]);
+    if (S < nk) issue_a(S, S);
+  });
+  int kk = 0;
+  for (; kk + PERIOD <= nk; kk += PERIOD)
+    static_for<PERIOD>([&](auto p_c) {
+      constexpr int P = decltype(p_c)::value;
+      step(std::integral_constant<int, P % NST>{}, std::integral_constant<int, P % NWS>{}, kk + P);
+    });
+  static_for<PERIOD - 1>([&](auto p_c) {
+    constexpr int P = decltype(p_c)::value;
+    if (kk + P < nk) step(std::integral_constant<int, P % NST>{}, std::integral_constant<int, P % NWS>{}, kk + P);
+  });
+
+  if (ABL & 8) ts2 = __builtin_amdgcn_s_memrealtime();
+  if (ABL & 1) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[b][i][j]));
+    if ((ABL & 8) && g_duo_stamps != nullptr && lane == 0) {
+      unsigned long long* o = g_duo_stamps + (size_t)blockIdx.x * 20;
+      o[6 + wave] = ts2;
+      if (wave == 0) {
+        o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts2;
+        unsigned int xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        o[4] = xcc; o[5] = hwid;
+      }
+    }
+    return;
+  }
+  if (mode & 4) __builtin_amdgcn_s_setprio(3);
+  const int mbase = m0 + wm * (16 * MT) + r16, nbase = n0 + wn * (16 * TN) + 4 * g;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) run_epilogue<TN, Epi, RB>(epi, mbase + 16 * RB * b, nbase, acc[b]);
+  if ((ABL & 8) && g_duo_stamps != nullptr && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long ts3 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* o = g_duo_stamps + (size_t)blockIdx.x * 20;
+    o[6 + wave] = ts3;
+    if (wave == 0) {
+      o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3;
+      unsigned int xcc, hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      o[4] = xcc; o[5] = hwid;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+// Fragment-order copies made on demand for weights that were not created through ribca_vit_create (tests, tools): keyed by the
+// packed weight's device address.  Model weights carry their own copy (GemmArgs::WF).
+static const uint16_t* wf_for(const GemmArgs& g, hipStream_t s) {
+  if (g.WF != nullptr) return g.WF;
+  static std::map<std::tuple<const void*, int, int>, uint16_t*> cache;
+  const int Np = gemm_padded_n(g.N);
+  const auto key = std::make_tuple((const void*)g.W, Np, g.Kp);
+  auto it = cache.find(key);
+  if (it != cache.end()) {
+    // the same address can be reused for different contents (test tensors): repack every time in this fallback path
+    launch_pack_wf(g.W, g.ldw, Np, g.Kp, it->second, s);
+    return it->second;
+  }
+  uint16_t* wf = nullptr;
+  if (hipMalloc(&wf, (size_t)Np * 2 * g.Kp * sizeof(uint16_t)) != hipSuccess) return nullptr;
+  launch_pack_wf(g.W, g.ldw, Np, g.Kp, wf, s);
+  cache[key] = wf;
+  return wf;
+}
+
+template <int BM, int NW, int WM, int NWS, int BN, class Epi>
+static void launch_duo_impl(const GemmArgs& g, const Epi& epi, hipStream_t s, int abl) {
+  static const int mode = getenv("RIBCA_DUO_MODE") ? atoi(getenv("RIBCA_DUO_MODE")) : 0;
+  static const int delay_per_step = getenv("RIBCA_DUO_DELAY") ? atoi(getenv("RIBCA_DUO_DELAY")) : 40;   // 10 ns ticks per K step
+  static const int lds_pad = getenv("RIBCA_DUO_SOLO") ? 1 : 0;      // diagnostics: one workgroup per CU (LDS padded past half)
+  constexpr int TN = BN / (16 * (NW / WM));
+  constexpr int NST = BM == 256 ? 2 : 3;
+  const int mtiles = (g.M + BM - 1) / BM;
+  const int ntiles = gemm_padded_n(g.N) / BN;
+  const size_t lds = lds_pad ? (size_t)100 * 1024 : (size_t)NST * BM * ROWB;
+  const uint16_t* wf = wf_for(g, s);
+  if (wf == nullptr) return;
+  const dim3 grid(mtiles * ntiles), block(64 * NW);
+  const int delay = delay_per_step * (g.Kp / BK);
+  auto go = [&](auto abl_c) {
+    constexpr int ABL = decltype(abl_c)::value;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ps_duo_kernel<BM, NW, WM, TN, NWS, Epi, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(100 * 1024));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_ps_duo_kernel<BM, NW, WM, TN, NWS, Epi, ABL>), grid, block, lds, s, g.A, g.lda, wf, g.M, g.Kp, mtiles, ntiles, epi, mode, delay);
+  };
+  switch (abl) {
+    case 1: go(std::integral_constant<int, 1>{}); break;
+    case 8: go(std::integral_constant<int, 8>{}); break;
+    case 9: go(std::integral_constant<int, 9>{}); break;
+    default: go(std::integral_constant<int, 0>{}); break;
+  }
+}
+
+template <int BN, class Epi>
+void launch_duo(const GemmArgs& g, const Epi& epi, hipStream_t s, int abl) {
+  // RIBCA_DUO_FORM (A/B): 0 = 192-row tiles, 3-stage ring, 4 waves as 1 x 4 (2 x 2 for 96-wide tiles), 3 W sets (production);
+  // 1 = the same tile with 8 waves as 2 x 4 (4 x 2), 2 W sets; 2 = 256 rows, 2-stage ring, 4 waves
+  static const int form = getenv("RIBCA_DUO_FORM") ? atoi(getenv("RIBCA_DUO_FORM")) : 0;
+  if constexpr (BN % 64 == 0) {
+    if (form == 2) launch_duo_impl<256, 4, 1, 2, BN, Epi>(g, epi, s, abl);
+    else if (form == 1) launch_duo_impl<192, 8, 2, 2, BN, Epi>(g, epi, s, abl);
+    else launch_duo_impl<192, 4, 1, 3, BN, Epi>(g, epi, s, abl);
+  } else {   // BN = 96
+    if (form == 2) launch_duo_impl<256, 4, 2, 2, BN, Epi>(g, epi, s, abl);
+    else if (form == 1) launch_duo_impl<192, 8, 4, 2, BN, Epi>(g, epi, s, abl);
+    else launch_duo_impl<192, 4, 2, 3, BN, Epi>(g, epi, s, abl);
+  }
+}
+
+#define RIBCA_DUO_INST(BN, EPI) template void launch_duo<BN, EPI>(const GemmArgs&, const EPI&, hipStream_t, int);
+RIBCA_DUO_INST(128, EpiResid) RIBCA_DUO_INST(96, EpiResid) RIBCA_DUO_INST(64, EpiResid)
+RIBCA_DUO_INST(128, EpiGelu) RIBCA_DUO_INST(96, EpiGelu) RIBCA_DUO_INST(64, EpiGelu)
+RIBCA_DUO_INST(128, EpiQKV) RIBCA_DUO_INST(96, EpiQKV) RIBCA_DUO_INST(64, EpiQKV)
+RIBCA_DUO_INST(128, EpiRowMap) RIBCA_DUO_INST(96, EpiRowMap) RIBCA_DUO_INST(64, EpiRowMap)
+#undef RIBCA_DUO_INST
+
+}  // namespace ribca

@@ -1,0 +1,205 @@
+// Epilogue functors, the two-sweep register epilogue driver and the LDS tile addressing shared by the GEMM kernels
+// (gemm_split16.hip: one 768-thread workgroup per CU; gemm_duo.hip: two 256-thread workgroups per CU).
+#pragma once
+#include <type_traits>
+
+#include "ribca_common.h"
+#include "ribca_kernels.h"
+
+namespace ribca {
+
+constexpr int BK = 32;
+constexpr int ROWB = 128;  // bytes per LDS tile row
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  const int f = ((row >> 1) & 7) ^ ((((row + 12) & 15) < 8) ? 2 : 0);
+  return row * ROWB + ((chunk ^ f) << 4);
+}
+
+// ---------------------------------------------------------------------------------------------- epilogues
+// Every epilogue runs in two sweeps over the wave's 4 x TN accumulator tiles: `fetch` issues ALL the loads it needs
+// (bias once per column group, the residual z tile) back to back, `apply` then computes and stores.  A single sweep
+// that loads, waits and stores per tile costs one L2/HBM round trip per tile (16 dependent round trips ~ 11 us per
+// 256 x 128 tile, as much as 14 K-steps of MFMAs).
+struct EpiResid {
+  float* z; int ldz; const float* bias; int M, N; int nt = 0;
+  struct Ctx { float4 zv; };
+  __device__ __forceinline__ float4 fetch_bias(int n) const {
+    return n < N ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  __device__ __forceinline__ void fetch(int m, int n, Ctx& c) const {
+    c.zv = (m < M && n < N) ? *reinterpret_cast<const float4*>(z + (size_t)m * ldz + n) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  template <int PX = 16>
+  __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx& c) const {
+    if (m >= M || n >= N) return;
+    f32x4 o;
+    o[0] = c.zv.x + (v[0] + b.x); o[1] = c.zv.y + (v[1] + b.y); o[2] = c.zv.z + (v[2] + b.z); o[3] = c.zv.w + (v[3] + b.w);
+    f32x4* dst = reinterpret_cast<f32x4*>(z + (size_t)m * ldz + n);
+    if (nt) __builtin_nontemporal_store(o, dst);
+    else *dst = o;
+  }
+};
+
+struct EpiGelu {
+  uint16_t* out; int ldo; const float* bias; int M, N; int nt = 0;
+  struct Ctx {};
+  __device__ __forceinline__ float4 fetch_bias(int n) const {
+    return n < N ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  __device__ __forceinline__ void fetch(int, int, Ctx&) const {}
+  template <int PX = 16>
+  __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx&) const {
+    if (m >= M || n >= N) return;
+    const f32x2v u0 = gelu_erf2(f32x2v{v[0] + b.x, v[1] + b.y}), u1 = gelu_erf2(f32x2v{v[2] + b.z, v[3] + b.w});
+    float t[4] = {u0.x, u0.y, u1.x, u1.y};
+    ps_store4_pair<PX>(out + (size_t)m * ldo, n, t, nt != 0);      // N % 8 == 0: the partner lane (n ^ 4, same m) passed the same guard
+  }
+};
+
+struct EpiQKV {
+  uint16_t* q; uint16_t* k; uint16_t* vt; const float* bias; int D, hd, hdp /* stored dims per Q/K row = AttnGeom::hdq */, hdv; float scale; int M, N;
+  int T, TP, H, KP;   // tokens per cell, padded token rows of Q/K, heads, padded keys per V^T row
+  int nt = 0;
+  unsigned magicT = 0;   // ceil(2^32 / T): m / T as one v_mul_hi + a fix-up (the epilogue does one such division per output row)
+  struct Ctx {};
+  // row / column decompositions are computed once per accumulator row (4) and column group (TN), not once per tile
+  struct Row { int cell, t, vpos; };
+  struct Col { int which, head, d; };
+  __device__ __forceinline__ Row row(int m) const {
+    Row r;
+    // m * ceil(2^32 / T) >> 32 is m / T or one more (m < 2^32): a runtime integer division costs ~25 VALU instructions, and the
+    // drain evaluates it 8-11 times per thread
+    r.cell = (int)__umulhi((unsigned)m, magicT);
+    r.t = m - r.cell * T;
+    if (r.t < 0) { r.cell -= 1; r.t += T; }
+    // V^T key order permuted inside each 32-key block so that the 8 keys a lane group owns after the K*Q^T MFMA (two
+    // 16-key tiles, rows 4g..4g+3 of each) are contiguous: key = 32s+16u+4g+r -> 32s+8g+4u+r
+    r.vpos = ps_off((r.t & ~31) | (((r.t >> 2) & 3) << 3) | (((r.t >> 4) & 1) << 2) | (r.t & 3));
+    return r;
+  }
+  __device__ __forceinline__ Col col(int n) const {
+    Col c;
+    c.which = n / D;
+    const int f = n - c.which * D;
+    c.head = f / hd;
+    c.d = f - c.head * hd;   // multiple of 4, d+3 < hd (hd % 4 == 0)
+    return c;
+  }
+  __device__ __forceinline__ float4 fetch_bias(int n) const {
+    return n < N ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  __device__ __forceinline__ void fetch(int, int, Ctx&) const {}
+  template <int PX = 16>
+  __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx&, const Row& r, const Col& c) const {
+    if (m >= M || n >= N) return;
+    float x[4] = {v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w};
+    const size_t ch = (size_t)r.cell * H + c.head;
+    if (c.which < 2) {
+      if (c.which == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] *= scale;
+      }
+      uint16_t* rowp = (c.which == 0 ? q : k) + (ch * TP + r.t) * (size_t)(2 * hdp);
+      if ((hd & 7) == 0) ps_store4_pair<PX>(rowp, c.d, x, nt != 0);   // the partner lane's 4 columns are in the same head
+      else ps_store4(rowp, c.d, x);
+    } else {
+      uint2 hi, lo;
+      split4(x, hi, lo);
+      uint16_t* base = vt + (ch * hdv + c.d) * (size_t)(2 * KP) + r.vpos;
+      const size_t st = (size_t)(2 * KP);
+      base[0] = (uint16_t)hi.x;          base[8] = (uint16_t)lo.x;
+      base[st] = (uint16_t)(hi.x >> 16); base[st + 8] = (uint16_t)(lo.x >> 16);
+      base[2 * st] = (uint16_t)hi.y;     base[2 * st + 8] = (uint16_t)lo.y;
+      base[3 * st] = (uint16_t)(hi.y >> 16); base[3 * st + 8] = (uint16_t)(lo.y >> 16);
+    }
+  }
+};
+
+// fp32 output with a per-cell row map (marker imputer): GEMM row m = cell * R + j is written to row
+// cell * dst_per_cell + slot[j] of `out`, plus bias and an optional table row add[addrow[j]] (positional embeddings).
+struct EpiRowMap {
+  float* out; int ldo; const float* bias; const float* add; int ldadd; const int* slot; const int* addrow; int R, dst_per_cell; int M, N;
+  struct Ctx { float4 a; };
+  __device__ __forceinline__ float4 fetch_bias(int n) const {
+    return n < N ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  __device__ __forceinline__ void fetch(int m, int n, Ctx& c) const {
+    c.a = float4{0.f, 0.f, 0.f, 0.f};
+    if (add != nullptr && m < M && n < N) {
+      const int cell = m / R, j = m - cell * R;
+      c.a = *reinterpret_cast<const float4*>(add + (size_t)addrow[j] * ldadd + n);
+    }
+  }
+  template <int PX = 16>
+  __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx& c) const {
+    if (m >= M || n >= N) return;
+    const int cell = m / R, j = m - cell * R;
+    float4 o;
+    o.x = v[0] + b.x + c.a.x; o.y = v[1] + b.y + c.a.y; o.z = v[2] + b.z + c.a.z; o.w = v[3] + b.w + c.a.w;
+    *reinterpret_cast<float4*>(out + ((size_t)cell * dst_per_cell + slot[j]) * ldo + n) = o;
+  }
+};
+
+// Values that came from global loads are passed through an empty asm statement before the store loop of the LDS drain: the
+// compiler's wait-count pass then settles them once (one s_waitcnt), instead of re-emitting s_waitcnt vmcnt(0) at their first use
+// in every exec-masked iteration -- where it would also wait for the store issued by the previous iteration.
+__device__ __forceinline__ void settle(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+template <class Ctx> __device__ __forceinline__ void settle_ctx(Ctx&) {}
+template <> __device__ __forceinline__ void settle_ctx<EpiResid::Ctx>(EpiResid::Ctx& c) { settle(c.zv); }
+template <> __device__ __forceinline__ void settle_ctx<EpiRowMap::Ctx>(EpiRowMap::Ctx& c) { settle(c.a); }
+
+// two-sweep driver shared by the kernels: lane owns rows m_i = mbase + 16 i and column groups n_j = nbase + 16 j
+template <class Epi, class = void> struct has_rowcol : std::false_type {};
+template <class Epi> struct has_rowcol<Epi, std::void_t<typename Epi::Row>> : std::true_type {};
+
+template <int TN, class Epi, int R = 4>
+__device__ __forceinline__ void run_epilogue(const Epi& epi, int mbase, int nbase, f32x4 (&acc)[R][TN]) {
+  float4 b4[TN];
+  typename Epi::Ctx ctx[R][TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) b4[j] = epi.fetch_bias(nbase + 16 * j);
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) epi.fetch(mbase + 16 * i, nbase + 16 * j, ctx[i][j]);
+  // one wait for everything that was loaded, before the first store (see settle())
+#pragma unroll
+  for (int j = 0; j < TN; ++j) settle(b4[j]);
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) settle_ctx(ctx[i][j]);
+  if constexpr (has_rowcol<Epi>::value) {
+    typename Epi::Row rows[R];
+    typename Epi::Col cols[TN];
+#pragma unroll
+    for (int i = 0; i < R; ++i) rows[i] = epi.row(mbase + 16 * i);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) cols[j] = epi.col(nbase + 16 * j);
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) epi.apply(mbase + 16 * i, nbase + 16 * j, acc[i][j], b4[j], ctx[i][j], rows[i], cols[j]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) epi.apply(mbase + 16 * i, nbase + 16 * j, acc[i][j], b4[j], ctx[i][j]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- kernel
+__device__ __forceinline__ int swz_f(int row) { return ((row >> 1) & 7) ^ ((((row + 12) & 15) < 8) ? 2 : 0); }
+
+template <int CNT> __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(CNT >= 0 && CNT <= 63, "vmcnt is a 6-bit field on gfx9");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
+}
+
+// gemm_duo.hip: two 256-thread workgroups per CU, W in fragment order straight to registers (abl: timing ablations, 0 = none)
+template <int BN, class Epi>
+void launch_duo(const GemmArgs& g, const Epi& epi, hipStream_t s, int abl);
+int duo_set_stamp_buffer(void* dev_ptr);
+
+}  // namespace ribca

@@ -76,6 +76,7 @@ void prof_drain() {
 struct BlockW {
   const float *ln1w, *ln1b, *qkvb, *projb, *ln2w, *ln2b, *fc1b, *fc2b;
   const uint16_t *qkvw, *projw, *fc1w, *fc2w;
+  const uint16_t* fc1wf;   // fc1 weight again, in MFMA fragment order (gemm_duo.hip): the GELU GEMMs run on the two-workgroups-per-CU kernel
 };
 
 struct ribca_vit {
@@ -120,6 +121,7 @@ void layout_block(Carver& c, BlockW& L, int D) {
   L.qkvw = c.take<uint16_t>((size_t)gemm_padded_n(3 * D) * 2 * Dp);
   L.projw = c.take<uint16_t>((size_t)gemm_padded_n(D) * 2 * Dp);
   L.fc1w = c.take<uint16_t>((size_t)gemm_padded_n(4 * D) * 2 * Dp);
+  L.fc1wf = c.take<uint16_t>((size_t)gemm_padded_n(4 * D) * 2 * Dp);
   L.fc2w = c.take<uint16_t>((size_t)gemm_padded_n(D) * 2 * H4);
 }
 
@@ -178,6 +180,7 @@ struct BlobReader {
     pack(L.projw, D, D, Dp); copy(L.projb, D);
     copy(L.ln2w, D); copy(L.ln2b, D);
     pack(L.fc1w, 4 * D, D, Dp); copy(L.fc1b, 4 * D);
+    launch_pack_wf(L.fc1w, 2 * Dp, gemm_padded_n(4 * D), Dp, const_cast<uint16_t*>(L.fc1wf), s);
     pack(L.fc2w, D, 4 * D, 4 * D); copy(L.fc2b, D);
   }
 };
@@ -232,7 +235,7 @@ void run_block(const BlockW& L, const BlockWs& w, int cells, const AttnGeom& a, 
   { ProfScope ps(P_LN, s); launch_layernorm_ps(w.z, D, L.ln2w, L.ln2b, w.xa, ld_x, Mc, D, s); }
   {
     ProfScope ps(P_FC1, s);
-    GemmArgs g{w.xa, ld_x, L.fc1w, ld_x, Mc, 4 * D, Dp, L.fc1b};
+    GemmArgs g{w.xa, ld_x, L.fc1w, ld_x, Mc, 4 * D, Dp, L.fc1b, L.fc1wf};
     launch_gemm_gelu(g, w.h, ld_h, s);
   }
   {

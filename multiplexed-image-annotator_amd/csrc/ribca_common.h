@@ -88,6 +88,17 @@ __device__ __forceinline__ void ps_store4_pair(uint16_t* row, int k, const float
     // neighbour lane inside a quad: one DPP move (quad_perm [1,0,3,2]) instead of a ds_bpermute round trip through the LDS unit
     recv.x = (uint32_t)__builtin_amdgcn_mov_dpp((int)send.x, 0xB1, 0xF, 0xF, true);
     recv.y = (uint32_t)__builtin_amdgcn_mov_dpp((int)send.y, 0xB1, 0xF, 0xF, true);
+  } else if constexpr (PX == 16) {
+    // partner = the same lane of the neighbouring 16-lane row: v_permlane16_swap_b32 (gfx950) exchanges the odd rows of its first
+    // operand with the even rows of its second, which is this hi/lo exchange in ONE VALU instruction per register -- no
+    // ds_bpermute round trip through the LDS unit (two per tile, each waited for, in the register epilogues)
+    const auto rx = __builtin_amdgcn_permlane16_swap(hi.x, lo.x, false, false);
+    const auto ry = __builtin_amdgcn_permlane16_swap(hi.y, lo.y, false, false);
+    const u32x4 o = {rx[0], ry[0], rx[1], ry[1]};      // even row: 8 x hi, odd row: 8 x lo
+    u32x4* dst = reinterpret_cast<u32x4*>(row + ps_off(k & ~7) + (odd ? 8 : 0));
+    if (nt) __builtin_nontemporal_store(o, dst);
+    else *dst = o;
+    return;
   } else {
     recv.x = __shfl_xor(send.x, PX, 64);
     recv.y = __shfl_xor(send.y, PX, 64);

@@ -17,7 +17,10 @@ struct GemmArgs {
   const uint16_t* W; int ldw;       // packed weight, Np rows
   int M, N, Kp;
   const float* bias;                // [N]
+  const uint16_t* WF = nullptr;     // the same weight in fragment order (gemm_duo.hip, launch_pack_wf); nullptr = made on demand
 };
+// W [Np][2*Kp] packed-split -> fragment order for the two-workgroups-per-CU kernel: block (jt, s) of 2 KB = [hi | lo] x 64 lanes x 16 B
+void launch_pack_wf(const uint16_t* W, int ldw, int Np, int Kp, uint16_t* WF, hipStream_t s);
 // z[m][n] += acc + bias                                   (attn.proj, mlp.fc2)
 void launch_gemm_resid(const GemmArgs& g, float* z, int ldz, hipStream_t s);
 // out_ps[m][n] = gelu(acc + bias), packed-split          (mlp.fc1)
