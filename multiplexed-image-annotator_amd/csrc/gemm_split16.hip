@@ -30,6 +30,8 @@
 //   chunks -- whole 256-512 byte row segments per instruction (what a CU can drain depends on the address shape of a store,
 //   tools/store_bench.hip).  It is not overlapped with the next tile's K loop; DESIGN.md section 6 lists the persistent /
 //   streaming / relay forms that were built for that and why they did not pay (output traffic, not the latency chain).
+//   gemm_duo.hip is the two-workgroups-per-CU form of this kernel (weights out of LDS, in fragment order): bit-identical, reached
+//   through variants 40-49 / RIBCA_GEMM_DUO=1, not faster end to end.
 #include <cstdlib>
 #include <type_traits>
 

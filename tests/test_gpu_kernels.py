@@ -127,6 +127,20 @@ def test_gemm_gelu(dev, m, n, k):
     assert err < 2e-5, err
 
 
+def test_gemm_duo_variant_bit_identical(dev):
+    """gemm_duo.hip (two workgroups per CU, weights in fragment order straight to registers; A/B variant 40 and the
+    RIBCA_GEMM_DUO=1 path of mlp.fc1) accumulates every output element in the production kernel's order: its residual, GELU and
+    QKV outputs must equal variant 0's bit for bit -- ragged M, every column-tile width, the 96-wide 2 x 2 wave layout included."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_gemm_variant", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                       "tools", "check_gemm_variant.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    shapes = [(1, 288, 288), (300, 288, 1152), (257, 144, 144), (130, 432, 144), (77, 576, 2304), (129, 384, 384), (64, 64, 64),
+              (1000, 2304, 576), (11100, 576, 576), (16500, 1536, 384)]
+    assert mod.compare([40], shapes=shapes, qkv_cases=((144, 3), (288, 130), (576, 31)), verbose=False) == 0
+
+
 @pytest.mark.parametrize("d,cells", [(144, 3), (288, 3), (384, 3), (576, 3), (288, 130), (384, 130), (576, 131), (288, 400)])
 def test_qkv_attention(dev, d, cells):
     from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
