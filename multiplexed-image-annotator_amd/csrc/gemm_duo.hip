@@ -145,6 +145,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
     }
   }
 
+  if (mode & 8) __builtin_amdgcn_s_setprio(3);
   // ---- A ring: wave w loads the 8-row groups w, w + NW, ... of every stage (1 KB per instruction) through a buffer descriptor
   // over the tile's rows: ONE per-lane offset register, everything that varies (group, K step) in the scalar offset, and rows beyond
   // M read as zeros by the descriptor's range check (their outputs are dropped by the epilogue guards).
@@ -280,6 +281,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
     return;
   }
   if (mode & 4) __builtin_amdgcn_s_setprio(3);
+  if (mode & 8) __builtin_amdgcn_s_setprio(0);     // bit 3: K loop at priority 3 (set below the prologue), epilogue back at 0
   const int mbase = m0 + wm * (16 * MT) + r16, nbase = n0 + wn * (16 * TN) + 4 * g;
 #pragma unroll
   for (int b = 0; b < NB; ++b) run_epilogue<TN, Epi, RB>(epi, mbase + 16 * RB * b, nbase, acc[b]);
