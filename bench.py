@@ -279,7 +279,7 @@ def main():
         spath = os.path.join(ROOT, "profiles", "r2", "sq_summary.json")
         if os.path.exists(spath):
             sq = json.load(open(spath))
-            gem = [v for k, v in sq.items() if k.startswith("gemm_ps_split_kernel")]
+            gem = [v for k, v in sq.items() if k.startswith("gemm_ps_split_kernel") or k.startswith("gemm_ps_duo_kernel")]
             cyc = sum(v["kernel_cycles"] for v in gem)
             if cyc > 0:
                 busy = round(sum(v["mfma_busy_frac"] * v["kernel_cycles"] for v in gem) / cyc, 4)
@@ -289,7 +289,7 @@ def main():
             d = model.D
             per_row = 4.0 * d * (1 + 3) + 4.0 * d * (1 + 2) + 4.0 * d * (1 + 4) + 4.0 * d * (4 + 2)      # qkv, proj, fc1, fc2
             alg_bytes += n_local * 101 * (model.depth - 1) * per_row + 12.0 * d * d * 4.0 * model.depth * ((n_local + args.chunk - 1) // args.chunk)
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_ps_split_kernel (qkv/proj/fc1/fc2, fp16x3)", "achieved": round(achieved, 2),
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_ps_split_kernel (qkv/proj/fc2) + gemm_ps_duo_kernel (fc1), fp16x3", "achieved": round(achieved, 2),
                            "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 5),
                            "traffic": traffic, "traffic_unit": f"bytes/launch (2*FETCH_SIZE + WRITE_SIZE, {traffic_src})",
                            "algorithmic_bytes_per_launch": round(alg_bytes / max(g_n, 1)),

@@ -566,12 +566,12 @@ static void launch_persist(const GemmArgs& g, const Epi& epi, hipStream_t s) {
 
 template <int BN, class Epi>
 static void launch_bn(const GemmArgs& g, const Epi& epi, hipStream_t s) {
-  // RIBCA_GEMM_DUO=1 (A/B): GELU GEMMs whose weight carries a fragment-order copy (GemmArgs::WF, set by the block runner for mlp.fc1)
-  // run on the two-workgroups-per-CU kernel: same bits, 5-10 % less time on those launches in isolation (tools/bench_gemm.py 0 40),
-  // nothing end to end (three segment streams already overlap one launch's epilogues with another's K loops: 7.80 vs 7.82 s per
-  // pass, profiles/r2/ab_duo_fc1.txt), so it is off by default.  With the residual / QKV epilogues the duo form is 5-25 % slower.
+  // Production: GELU GEMMs whose weight carries a fragment-order copy (GemmArgs::WF, set by the block runner for mlp.fc1) run on the
+  // two-workgroups-per-CU kernel: same bits, 4-12 % less time on those launches (tools/bench_gemm.py 0 40) and 1.4 % end to end
+  // (7.84 -> 7.73 s per pass, six interleaved rounds on one box: profiles/r2/duo_kernel/ab_end_to_end_fc1_on_duo_6rounds.txt).
+  // The residual and QKV epilogues stay here: there the duo form is 5-25 % slower.  RIBCA_GEMM_DUO=0: off.
   if constexpr (std::is_same<Epi, EpiGelu>::value) {
-    static const bool duo_on = getenv("RIBCA_GEMM_DUO") && atoi(getenv("RIBCA_GEMM_DUO")) != 0;
+    static const bool duo_on = !(getenv("RIBCA_GEMM_DUO") && atoi(getenv("RIBCA_GEMM_DUO")) == 0);
     if (g_variant == 0 && duo_on && g.WF != nullptr && g.M >= 4096) {
       launch_duo<BN, Epi>(g, epi, s, 0);
       return;

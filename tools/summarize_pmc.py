@@ -39,10 +39,10 @@ def counter_sums(sub, counter):
 
 fetch = counter_sums("fetch", "FETCH_SIZE")
 write = counter_sums("write", "WRITE_SIZE")
-gemm = [k for k in fetch if "gemm_ps_split_kernel" in k]
+gemm = [k for k in fetch if "gemm_ps_split_kernel" in k or "gemm_ps_duo_kernel" in k]
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 0 "
                  "--no-cpu-baseline --no-roofline --cells 8000 --size 1280 (chunk 1024)",
-       "kernel_family": "gemm_ps_split_kernel (all instantiations)",
+       "kernel_family": "gemm_ps_split_kernel + gemm_ps_duo_kernel (all instantiations)",
        "correction": "gfx950: FETCH_SIZE tallies 128-B requests at 64 B -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact; "
                      "unit KB = 1024 B",
        "note": "counts L2 misses served by the Infinity Cache as well as HBM; per-launch figure (M = 103424 rows for full chunks)"}
