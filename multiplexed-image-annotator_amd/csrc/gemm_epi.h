@@ -24,6 +24,15 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 struct EpiResid {
   float* z; int ldz; const float* bias; int M, N; int nt = 0;
   struct Ctx { float4 zv; };
+  // The residual tile z[m0 .. m0 + 255][n0 .. n0 + BN) was written one or two launches ago and has left the L2: the drain's z loads
+  // are HBM / Infinity-Cache misses, ~3 us of every tile's epilogue (profiles/r2/resid_epilogue_l2_resident_z_experiment.txt).  The
+  // loader waves therefore TOUCH it (one dword per 128-byte line, result discarded) right behind the last ring stage they issue,
+  // two K steps before the drain reads it.
+  static constexpr bool kTouch = true;
+  __device__ __forceinline__ bool touch_on() const { return (nt & 2) == 0; }      // nt bit 1: RIBCA_GEMM_TOUCH=0 (A/B)
+  __device__ __forceinline__ const float* touch_ptr(int m, int n) const {      // always a valid address: the touch is issued by every
+    return z + (size_t)(m < M ? m : M - 1) * ldz + (n < N ? n : N - 1);         // wave, whatever its rows (the caller counts vmcnt)
+  }
   __device__ __forceinline__ float4 fetch_bias(int n) const {
     return n < N ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
   }
@@ -36,12 +45,13 @@ struct EpiResid {
     f32x4 o;
     o[0] = c.zv.x + (v[0] + b.x); o[1] = c.zv.y + (v[1] + b.y); o[2] = c.zv.z + (v[2] + b.z); o[3] = c.zv.w + (v[3] + b.w);
     f32x4* dst = reinterpret_cast<f32x4*>(z + (size_t)m * ldz + n);
-    if (nt) __builtin_nontemporal_store(o, dst);
+    if (nt & 1) __builtin_nontemporal_store(o, dst);
     else *dst = o;
   }
 };
 
 struct EpiGelu {
+  static constexpr bool kTouch = false;
   uint16_t* out; int ldo; const float* bias; int M, N; int nt = 0;
   struct Ctx {};
   __device__ __forceinline__ float4 fetch_bias(int n) const {
@@ -58,6 +68,7 @@ struct EpiGelu {
 };
 
 struct EpiQKV {
+  static constexpr bool kTouch = false;
   uint16_t* q; uint16_t* k; uint16_t* vt; const float* bias; int D, hd, hdp /* stored dims per Q/K row = AttnGeom::hdq */, hdv; float scale; int M, N;
   int T, TP, H, KP;   // tokens per cell, padded token rows of Q/K, heads, padded keys per V^T row
   int nt = 0;
@@ -119,6 +130,7 @@ struct EpiQKV {
 // fp32 output with a per-cell row map (marker imputer): GEMM row m = cell * R + j is written to row
 // cell * dst_per_cell + slot[j] of `out`, plus bias and an optional table row add[addrow[j]] (positional embeddings).
 struct EpiRowMap {
+  static constexpr bool kTouch = false;
   float* out; int ldo; const float* bias; const float* add; int ldadd; const int* slot; const int* addrow; int R, dst_per_cell; int M, N;
   struct Ctx { float4 a; };
   __device__ __forceinline__ float4 fetch_bias(int n) const {

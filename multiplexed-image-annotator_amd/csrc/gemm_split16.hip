@@ -196,20 +196,46 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + ko),
                                          (__attribute__((address_space(3))) void*)(st + dst[i]), 16, 0, 0);
     };
+    // z touch (EpiResid, LDS epilogue): lane t of the 256 loader lanes owns row t of the tile and reads one dword of each of its
+    // BN / 32 lines, issued right BEHIND the last ring stage: vmcnt retires in order, so the two remaining stage waits simply
+    // leave these NT youngest operations in flight.  The results are never used; the destination registers are kept allocated
+    // until the drain's own waits have passed (empty asm at the end of this branch).
+    constexpr int NT = (Epi::kTouch && LEPI && STAG && (ABL == 0 || ABL == 4)) ? BN / 32 : 0;
+    unsigned int touched[NT > 0 ? NT : 1];
+    auto touch = [&]() {
+      if constexpr (NT > 0) {
+        const int trow = lw * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          // (switched off for A/B, the same instruction reads the start of z: an L2 hit that keeps the vmcnt arithmetic unchanged)
+          const float* p = epi.touch_on() ? epi.touch_ptr(m0 + trow, n0 + 32 * i) : epi.touch_ptr(0, 0);
+          asm volatile("global_load_dword %0, %1, off" : "=v"(touched[i]) : "v"(p) : "memory");
+        }
+      }
+    };
     if (!abl_no_loads(ABL)) {
       issue(0, 0);
       if (nk > 1) issue(1, 1);
     }
+    if (nk <= 2) touch();
     int cur = 0;
     for (int kk = 0; kk < nk; ++kk) {
-      if (kk + 1 < nk) wait_vmcnt<GPL>();
-      else wait_vmcnt<0>();
+      // stage kk has landed; one younger stage (and, behind the last stage, the touches) may stay in flight
+      const bool after_touch = NT > 0 && kk + 2 >= nk;
+      if (kk + 1 < nk) {
+        if (after_touch) wait_vmcnt<GPL + NT>();
+        else wait_vmcnt<GPL>();
+      } else {
+        if (after_touch) wait_vmcnt<NT>();
+        else wait_vmcnt<0>();
+      }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (!abl_no_loads(ABL) && kk + 2 < nk) {
         int nxt = cur + 2;
         nxt = nxt >= NST ? nxt - NST : nxt;
         issue(kk + 2, nxt);
+        if (kk + 3 == nk) touch();              // that was the last stage
       }
       if (STAG) __builtin_amdgcn_s_barrier();   // phase 2kk+1
       cur = cur + 1 == NST ? 0 : cur + 1;
@@ -224,6 +250,10 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
     if (ABL == 4 && g_stamps != nullptr && lane == 0) {      // per-wave end of the epilogue (stores accepted)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       g_stamps[(size_t)blockIdx.x * kStampStride + 6 + wave] = stamp_now();
+    }
+    if constexpr (NT > 0) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) asm volatile("" ::"v"(touched[i]));
     }
     return;
   }
@@ -618,7 +648,8 @@ static int nt_mask() {
   return m;
 }
 void launch_gemm_resid(const GemmArgs& g, float* z, int ldz, hipStream_t s) {
-  launch_any(g, EpiResid{z, ldz, g.bias, g.M, g.N, (nt_mask() >> 2) & 1}, s);
+  static const int no_touch = (getenv("RIBCA_GEMM_TOUCH") && atoi(getenv("RIBCA_GEMM_TOUCH")) == 0) ? 2 : 0;
+  launch_any(g, EpiResid{z, ldz, g.bias, g.M, g.N, ((nt_mask() >> 2) & 1) | no_touch}, s);
 }
 void launch_gemm_gelu(const GemmArgs& g, uint16_t* out, int ldo, hipStream_t s) {
   launch_any(g, EpiGelu{out, ldo, g.bias, g.M, g.N, nt_mask() & 1}, s);
