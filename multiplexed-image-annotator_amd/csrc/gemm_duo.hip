@@ -50,7 +50,12 @@ __device__ __forceinline__ void lds_read16(f16x8& dst, unsigned addr) {
 }
 template <int OFF>
 __device__ __forceinline__ void gload16(f16x8& dst, unsigned voff, const void* sbase) {
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+  // the base is wave-uniform by construction; readfirstlane states it (under SGPR pressure hipcc otherwise hands the "s" operand a
+  // VGPR pair, which the saddr form of the instruction does not take)
+  const unsigned long long b = (unsigned long long)(uintptr_t)sbase;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  const unsigned long long u = ((unsigned long long)hi << 32) | lo;
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(u), "n"(OFF) : "memory");
 }
 
 }  // namespace
@@ -111,6 +116,10 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
   // issue order inside a step: W (for step k + NWS - 1), then A (for step k + NST - 1); what may stay in flight at the top of step k
   constexpr int FLY = NST == 2 ? 0 : (NWS == 3 ? NA + NWL : NA);
   constexpr int PERIOD = NST == NWS ? NST : NST * NWS;
+  // z touch (EpiResid: the drain's z loads are HBM / Infinity-Cache misses, 13 of a tile's 17 us of epilogue here): every thread reads
+  // one dword of each 128-byte line of "its" row of the residual tile right behind the LAST operand batch; vmcnt retires in order,
+  // so the remaining waits leave these NT youngest operations in flight and nothing waits for them before the epilogue does.
+  constexpr int NT = (Epi::kTouch && !(ABL & 1)) ? BN / 32 : 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nblk = mtiles * ntiles;
   int bid = blockIdx.x;
@@ -201,12 +210,29 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
   const unsigned a_hi = lds_base + (unsigned)lds_off(wm * (16 * MT) + r16, 2 * g);     // + 2048 per m-tile, + STAGE per slot
   const unsigned a_lo = a_hi ^ 16u;
 
+  unsigned int touched[NT > 0 ? NT : 1];
+  auto touch = [&]() {
+    if constexpr (NT > 0) {
+      const int trow = tid < BM ? tid : BM - 1;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const float* p = epi.touch_on() ? epi.touch_ptr(m0 + trow, n0 + 32 * i) : epi.touch_ptr(0, 0);
+        asm volatile("global_load_dword %0, %1, off" : "=v"(touched[i]) : "v"(p) : "memory");
+      }
+    }
+  };
+  const int last_issue = nk - NST;            // the step whose issue is the final operand batch (< 0: all issued in the prologue)
   // K step kk on ring slot SA = kk % NST with W set SW = kk % NWS
   auto step = [&](auto sa_c, auto sw_c, int kk) {
     constexpr int SA = decltype(sa_c)::value, SW = decltype(sw_c)::value;
     // the operands of step kk have landed; younger ones (FLY operations: issued one step ago) may stay in flight
-    if (FLY > 0 && kk + 1 < nk) wait_vmcnt<FLY>();
-    else wait_vmcnt<0>();
+    if (NT > 0 && kk > last_issue) {            // the touches sit behind every operand batch
+      if (FLY > 0 && kk + 1 < nk) wait_vmcnt<FLY + NT>();
+      else wait_vmcnt<NT>();
+    } else {
+      if (FLY > 0 && kk + 1 < nk) wait_vmcnt<FLY>();
+      else wait_vmcnt<0>();
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(whi[SW][j]), "+v"(wlo[SW][j]));
     __builtin_amdgcn_s_barrier();             // stage kk landed for every wave; the slot of stage kk - 1 read by all
@@ -217,6 +243,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
       issue_w(kk + NWS - 1, whi[SN], wlo[SN]);
     }
     if (kk + NST - 1 < nk) issue_a(kk + NST - 1, (SA + NST - 1) % NST);
+    if (NT > 0 && kk == last_issue) touch();
     __builtin_amdgcn_sched_barrier(0);
     f16x8 ah[2], al[2];
     const unsigned a_hi_s = a_hi + (unsigned)(SA * STAGE), a_lo_s = a_lo + (unsigned)(SA * STAGE);   // (the 16-bit offset field cannot hold slot 2)
@@ -248,6 +275,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
     if (S < NWS - 1 && S < nk) issue_w(S, whi[S], wlo[S]);
     if (S < nk) issue_a(S, S);
   });
+  if (NT > 0 && last_issue < 0) touch();
   int kk = 0;
   for (; kk + PERIOD <= nk; kk += PERIOD)
     static_for<PERIOD>([&](auto p_c) {
@@ -285,6 +313,10 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
   const int mbase = m0 + wm * (16 * MT) + r16, nbase = n0 + wn * (16 * TN) + 4 * g;
 #pragma unroll
   for (int b = 0; b < NB; ++b) run_epilogue<TN, Epi, RB>(epi, mbase + 16 * RB * b, nbase, acc[b]);
+  if constexpr (NT > 0) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) asm volatile("" ::"v"(touched[i]));
+  }
   if ((ABL & 8) && g_duo_stamps != nullptr && lane == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long ts3 = __builtin_amdgcn_s_memrealtime();
