@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <map>
 #include <tuple>
+#include <type_traits>
 #include <utility>
 
 #include "gemm_epi.h"
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
   const int wm = wave / WN, wn = wave - wm * WN;
   const int r16 = lane & 15, g = lane >> 4;
   const int nk = Kp / BK;
-  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tc1 = 0, tc2 = 0;      // tc: shader-clock stamps around the K loop (in-kernel clock)
   if (ABL & 8) ts0 = __builtin_amdgcn_s_memrealtime();
   // mode bit 0: static wave priority by the CU's workgroup slot (TG_ID of HW_ID, bits 19:16); bit 1: the first round's odd-slot
   // workgroups start `delay` x 10 ns late; bit 2: epilogue at raised priority (A/B switches: none paid)
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
     for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(whi[SW][j]), "+v"(wlo[SW][j]));
     __builtin_amdgcn_s_barrier();             // stage kk landed for every wave; the slot of stage kk - 1 read by all
     asm volatile("" ::: "memory");
-    if ((ABL & 8) && kk == 0) ts1 = __builtin_amdgcn_s_memrealtime();
+    if ((ABL & 8) && kk == 0) { ts1 = __builtin_amdgcn_s_memrealtime(); tc1 = __builtin_amdgcn_s_memtime(); }
     if (kk + NWS - 1 < nk) {
       constexpr int SN = (SW + NWS - 1) % NWS;
       issue_w(kk + NWS - 1, whi[SN], wlo[SN]);
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
     if (kk + P < nk) step(std::integral_constant<int, P % NST>{}, std::integral_constant<int, P % NWS>{}, kk + P);
   });
 
-  if (ABL & 8) ts2 = __builtin_amdgcn_s_memrealtime();
+  if (ABL & 8) { ts2 = __builtin_amdgcn_s_memrealtime(); tc2 = __builtin_amdgcn_s_memtime(); }
   if (ABL & 1) {
 #pragma unroll
     for (int b = 0; b < NB; ++b)
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
       unsigned long long* o = g_duo_stamps + (size_t)blockIdx.x * 20;
       o[6 + wave] = ts2;
       if (wave == 0) {
-        o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts2;
+        o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts2; o[18] = tc1; o[19] = tc2;
         unsigned int xcc, hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
     unsigned long long* o = g_duo_stamps + (size_t)blockIdx.x * 20;
     o[6 + wave] = ts3;
     if (wave == 0) {
-      o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3;
+      o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3; o[18] = tc1; o[19] = tc2;
       unsigned int xcc, hwid;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));

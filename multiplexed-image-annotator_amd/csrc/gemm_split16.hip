@@ -259,7 +259,7 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
   }
 
   // -------------------------------------------------------------------- consumer
-  unsigned long long t0 = 0, t1 = 0, t2 = 0;
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, tc1 = 0, tc2 = 0;
   if (ABL == 4) t0 = stamp_now();
   const int wm = wave >> 1, wn = wave & 1;
   const int r16 = lane & 15, g = lane >> 4;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
     for (int kk = 0; kk < nk; ++kk) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (ABL == 4 && kk == 0) t1 = stamp_now();
+      if (ABL == 4 && kk == 0) { t1 = stamp_now(); tc1 = __builtin_amdgcn_s_memtime(); }
       if (ABL != 2) read_frags(smem + cur * STAGE);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
     }
     if (!late) __builtin_amdgcn_s_barrier();         // phase 2nk: partners finish their last MFMAs
   }
-  if (ABL == 4) t2 = stamp_now();
+  if (ABL == 4) { t2 = stamp_now(); tc2 = __builtin_amdgcn_s_memtime(); }
   if (abl_no_epi(ABL)) {   // timing ablation: no epilogue (accumulators kept alive so the MFMAs are not dead code)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
     const unsigned long long t3 = stamp_now();
     unsigned long long* o = g_stamps + (size_t)blockIdx.x * kStampStride;
     o[6] = t3;
-    o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3;
+    o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[18] = tc1; o[19] = tc2;
     unsigned int xcc, hwid;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));

@@ -41,7 +41,8 @@ for name, d, n, kp, kind in (("proj576", 576, 576, 576, 0), ("fc1_576", 576, 230
     base = t0.min()
     span = t3.max() - base
     cu = (t[:, 4].astype(np.int64) << 32) | (t[:, 5].astype(np.int64) & 0xFF00)      # XCC + (SE, SH, CU) bits of HW_ID
-    print(f"{name}: {nblk} workgroups on {len(np.unique(cu))} CUs, kernel span {span:.1f} us, nk={kp // 32}")
+    clk = (t[:, 19] - t[:, 18]) / np.maximum((t[:, 2] - t[:, 1]), 1) * 0.1      # shader cycles per 10 ns tick -> GHz
+    print(f"{name}: {nblk} workgroups on {len(np.unique(cu))} CUs, kernel span {span:.1f} us, nk={kp // 32}, in-kernel clock {np.median(clk):.2f} GHz (K loops)")
     for label, v in (("prologue (entry -> first stage landed)", t1 - t0), ("K loop", t2 - t1), ("epilogue (loop end -> last wave's stores accepted)", t3 - t2),
                      ("workgroup total", t3 - t0)):
         print(f"   {label:52s} median {np.median(v):7.2f}  p10 {np.percentile(v, 10):7.2f}  p90 {np.percentile(v, 90):7.2f} us")

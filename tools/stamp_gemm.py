@@ -44,7 +44,8 @@ for name, d, n, kp, kind in (("proj576", 576, 576, 576, 0), ("fc1_576", 576, 230
         sel = np.flatnonzero(cu == key)
         order = sel[np.argsort(t0[sel])]
         gaps += list((t0[order][1:] - t3[order][:-1]) * us)
-    print(f"{name}: {nblk} workgroups, kernel span {span:.1f} us, nk={kp // 32}")
+    clk = (t[:, 19] - t[:, 18]) / np.maximum((t2 - t1), 1) * 0.1      # shader cycles per 10 ns tick -> GHz
+    print(f"{name}: {nblk} workgroups, kernel span {span:.1f} us, nk={kp // 32}, in-kernel clock {np.median(clk):.2f} GHz (K loops)")
     for label, v in (("prologue  (entry -> first stage landed)", (t1 - t0) * us), ("K loop", (t2 - t1) * us),
                      ("epilogue  (loop end -> stores accepted)", (t3 - t2) * us), ("workgroup total", (t3 - t0) * us),
                      ("gap to next workgroup on the same CU", np.array(gaps))):
