@@ -252,13 +252,33 @@ def main():
 
     # ---- roofline of the dominant kernel (the bf16x3 GEMM family), one extra profiled pass -----------------------------
     if not args.no_roofline and rank == 0:
-        ops.prof_enable(True)
-        one_pass(streams=1)      # per-kernel durations: one stream, so a launch's events bracket that launch alone
-        torch.cuda.synchronize()
-        prof = ops.prof_read()
-        ops.prof_enable(False)
+        # per-kernel durations: one stream, so a launch's events bracket that launch alone; one model at a time, so that every
+        # model's GEMMs can be priced against the roofline that binds THEM (arithmetic intensity below / above the ridge)
         lo, hi = dist.shard_bounds(n_cells, rank, world) if sharded else (0, n_cells)
         n_local = hi - lo
+        prof, per_model = {}, []
+        GEMM_OPS = ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2")
+        for name, model in models.items():
+            ops.prof_enable(True)
+            one_pass(streams=1, models_sel=[name])
+            torch.cuda.synchronize()
+            pm = ops.prof_read()
+            ops.prof_enable(False)
+            for k, v in pm.items():
+                prof[k] = (prof.get(k, (0.0, 0))[0] + v[0], prof.get(k, (0, 0))[1] + v[1])
+            d = model.D
+            m_ms = sum(pm[k][0] for k in GEMM_OPS)
+            m_fl = n_local * ((model.depth - 1) * 24.0 * 101 * d * d + 6.0 * 101 * d * d + 18.0 * d * d)
+            m_by = n_local * 101 * (model.depth - 1) * 72.0 * d          # A in + output out + z read / written, 4 B per element
+            ai = m_fl / m_by
+            # ridge of the issued work: 3 MFMA passes per product against the 16-bit dense peak, HBM at 8 TB/s
+            ridge = PEAK_BF16_DENSE_TFLOPS * 1e12 / 3.0 / 8.0e12
+            tf, gbs = m_fl / (m_ms * 1e-3) / 1e12, m_by / (m_ms * 1e-3) / 1e9
+            bound = "mfma" if ai >= ridge else "hbm"
+            per_model.append({"model": name, "D": d, "gemm_ms": round(m_ms, 2), "algorithmic_tflops": round(tf, 1),
+                              "algorithmic_gb_per_s": round(gbs, 1), "flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1),
+                              "bound": bound,
+                              "frac_of_bound": round(3.0 * tf / PEAK_BF16_DENSE_TFLOPS if bound == "mfma" else gbs / 8000.0, 4)})
         gemm_flops = 0.0
         for name, model in models.items():
             d = model.D
@@ -298,7 +318,11 @@ def main():
                            "launches": int(g_n), "avg_launch_ms": round(g_ms / max(g_n, 1), 5),
                            "algorithmic_gflop_per_launch": round(gemm_flops / max(g_n, 1) / 1e9, 4), "mfma_passes_per_product": 3,
                            "issued_mfma_frac_of_peak": round(3 * achieved / PEAK_BF16_DENSE_TFLOPS, 4),
-                           "per_kernel_ms": {k: round(v[0], 3) for k, v in prof.items() if v[1]}}
+                           "per_kernel_ms": {k: round(v[0], 3) for k, v in prof.items() if v[1]},
+                           "per_model": per_model,
+                           "per_model_note": "GEMMs of one classifier: algorithmic FLOP per algorithmic byte against the ridge of the ISSUED "
+                                             "work (3 MFMA passes per product at 2.5 PF dense / 8 TB/s = 104 FLOP/B); frac_of_bound = issued "
+                                             "MFMA fraction of peak where MFMA-bound, algorithmic GB/s of 8 TB/s where HBM-bound"}
 
     # ---- the boundary itself: Annotator.preprocess -> predict -> export_annotations from host files ------------------------
     if not args.no_dropin and rank == 0 and world == 1 and not args.impute:
