@@ -176,14 +176,45 @@ int ribca_test_gemm(int32_t kind, const uint16_t* A, int32_t lda, const uint16_t
                     const float* bias, void* out, int32_t ldo, void* stream); /* kind 0: z += ..., 1: gelu -> PS */
 int ribca_test_qkv_attention(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t cells, int32_t D, int32_t Kp,
                              const float* bias, uint16_t* q, uint16_t* k, uint16_t* vt, uint16_t* out, int32_t ldo, void* stream);
+/* The classifiers' blocks run with LayerNorm FOLDED into the Linear behind it (timm Block.norm1 -> attn.qkv, norm2 -> mlp.fc1,
+ * reached from model.py:54-55): the residual stream is packed-split fp16 hi + lo, z_ps [M][ldz], which the qkv / fc1 GEMM reads as
+ * its operand; the weight is gamma o W, and the epilogue applies x = rstd * acc + (-mean * rstd) * csum[n] + bias2[n].  Hooks:
+ *   fold_weight:   w [N][K] fp32 + gamma, beta [K] + bias [N] -> packed weight [Np][2*Kp], csum [N], bias2 [N]
+ *   row_stats:     rowstat [M] float2 = (rstd, -mean * rstd) of every row of z_ps (eps 1e-6, biased variance over D)
+ *   gemm_resid_ps: z_ps += A W^T + bias in place; rowstat (optional) = statistics of the NEW rows through the epilogue's
+ *                  per-tile pairs (part: scratch of ribca_test_resid_tiles(N) * M float2)
+ *   gemm_fold:     kind 1: out_ps = gelu(folded x), as ribca_test_gemm kind 1
+ *   qkv_attention_fold: as ribca_test_qkv_attention with the folded qkv epilogue */
+int ribca_test_fold_weight(const float* w, int32_t N, int32_t K, const float* gamma, const float* beta, const float* bias, uint16_t* out,
+                           int32_t Np, int32_t Kp, float* csum, float* bias2, void* stream);
+int ribca_test_row_stats(const uint16_t* z_ps, int32_t ldz, int32_t M, int32_t D, float* rowstat, void* stream);
+int32_t ribca_test_resid_tiles(int32_t N);
+int ribca_test_gemm_resid_ps(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
+                             const float* bias, uint16_t* z_ps, int32_t ldz, float* part, float* rowstat, void* stream);
+int ribca_test_gemm_fold(int32_t kind, const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
+                         const float* bias2, const float* csum, const float* rowstat, void* out, int32_t ldo, void* stream);
+int ribca_test_qkv_attention_fold(const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t cells, int32_t D, int32_t Kp,
+                                  const float* bias2, const float* csum, const float* rowstat, uint16_t* q, uint16_t* k, uint16_t* vt,
+                                  uint16_t* out, int32_t ldo, void* stream);
+/* mlp.fc1 as the forward runs it for M >= 4096: the GELU epilogue on the two-workgroups-per-CU kernel (gemm_duo.hip), which reads the
+ * weight in MFMA fragment order from wf_scratch (Np * 2 * Kp uint16, filled here from W).  csum / rowstat NULL: plain epilogue
+ * (bit-identical to ribca_test_gemm kind 1), else the folded one (bit-identical to ribca_test_gemm_fold kind 1). */
+int ribca_test_gemm_duo_gelu(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
+                             const float* bias, const float* csum, const float* rowstat, uint16_t* wf_scratch, uint16_t* out, int32_t ldo,
+                             void* stream);
 int32_t ribca_gemm_padded_n(int32_t N);
-/* Measurement hook: 0 = production GEMM; 3 = without the half-step stagger; 4/5/7/9 = timing ablations (no loads / loads
- * only / no loads + stagger / no epilogue) whose RESULTS ARE WRONG by construction -- used by tools/bench_gemm.py only. */
+/* Measurement hooks of the DIAGNOSTIC library (libribca_hip_diag.so, built with -DRIBCA_DIAG; tools/ only).  In the product library
+ * every variant runs the production kernel.  0 = production GEMM; 3 = without the half-step stagger; 4/5/7/9/20-24 = timing
+ * ablations (no loads / loads only / no loads + stagger / no epilogue / fewer MFMA passes) whose RESULTS ARE WRONG by construction;
+ * 12 = production kernel + time stamps; 30 = persistent workgroups; 40-49 = the two-workgroups-per-CU kernel and its ablations. */
 int ribca_set_gemm_variant(int32_t v);
-/* Diagnostics for variant 12: device buffer of 20 x uint64 per workgroup receiving 100 MHz time stamps (entry, first stage
+/* Diagnostics for variants 12 / 48: device buffer of 20 x uint64 per workgroup receiving 100 MHz time stamps (entry, first stage
  * landed, K loop done, epilogue stores accepted), the XCC / HW id the workgroup ran on, and in [6..17] the time each of the 12
- * waves had its epilogue stores accepted.  NULL disables. */
-int ribca_set_gemm_stamps(void* dev_buffer);
+ * waves had its epilogue stores accepted.  capacity_blocks = workgroups the buffer has room for (workgroups beyond it do not
+ * stamp).  NULL disables. */
+int ribca_set_gemm_stamps(void* dev_buffer, int64_t capacity_blocks);
+/* 1 if this library carries the diagnostic kernel forms (-DRIBCA_DIAG), else 0 */
+int ribca_is_diag_build(void);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,8 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_uint32, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libribca_hip.so")
+# RIBCA_DIAG=1 selects the diagnostic library (same ABI + the A/B and timing-ablation kernel forms; `build --diag`): tools/ only
+LIB_PATH = os.path.join(HERE, "libribca_hip_diag.so" if os.environ.get("RIBCA_DIAG") == "1" else "libribca_hip.so")
 
 _lib = None
 
@@ -56,9 +57,22 @@ SIGNATURES = {
                                   c_void_p]),
     "ribca_test_qkv_attention": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_int32, c_void_p]),
+    "ribca_test_fold_weight": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p,
+                                         c_void_p, c_void_p]),
+    "ribca_test_row_stats": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "ribca_test_resid_tiles": (c_int32, [c_int32]),
+    "ribca_test_gemm_resid_ps": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
+                                           c_void_p, c_void_p, c_void_p]),
+    "ribca_test_gemm_fold": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_int32, c_void_p]),
+    "ribca_test_qkv_attention_fold": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "ribca_test_gemm_duo_gelu": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_int32, c_void_p]),
     "ribca_gemm_padded_n": (c_int32, [c_int32]),
     "ribca_set_gemm_variant": (c_int32, [c_int32]),
-    "ribca_set_gemm_stamps": (c_int32, [c_void_p]),
+    "ribca_set_gemm_stamps": (c_int32, [c_void_p, c_int64]),
+    "ribca_is_diag_build": (c_int32, []),
 }
 
 

@@ -13,6 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libribca_hip.so")
+LIB_DIAG = os.path.join(HERE, "libribca_hip_diag.so")
 SOURCES = ["gemm_split16.hip", "gemm_duo.hip", "attention.hip", "vit_misc.hip", "preprocess.hip", "preprocess_scaled.hip", "vote.hip", "colorize.hip", "knn.hip", "normalize.hip", "ribca_api.hip"]
 HEADERS = ["ribca_common.h", "ribca_kernels.h", "gemm_epi.h", os.path.join("..", "..", "include", "ribca_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
@@ -32,10 +33,14 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, diag: bool = False) -> str:
+    """diag=True builds libribca_hip_diag.so with -DRIBCA_DIAG: the product kernels plus the A/B / timing-ablation / stamp forms that
+    tools/ drive (select it at run time with RIBCA_DIAG=1).  The product library carries none of them."""
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build_diag" if diag else "build")
+    lib_path = LIB_DIAG if diag else LIB
+    flags = FLAGS + (["-DRIBCA_DIAG"] if diag else [])
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
 
@@ -43,7 +48,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         path = os.path.join(CSRC, src)
         if force or _stale(obj, [path] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", path, "-o", obj]
+            cmd = [hipcc] + flags + ["-c", path, "-o", obj]
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
@@ -55,15 +60,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         res = list(ex.map(compile_one, srcs))
     objs = [o for o, _ in res]
-    if force or any(ch for _, ch in res) or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or any(ch for _, ch in res) or _stale(lib_path, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
     if verbose:
-        print("built", LIB)
-    return LIB
+        print("built", lib_path)
+    return lib_path
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, diag="--diag" in sys.argv)

@@ -82,7 +82,11 @@ void launch_pack_wf(const uint16_t* W, int ldw, int Np, int Kp, uint16_t* WF, hi
 // Diagnostic stamps (ABL = 4, variant 44): same record as gemm_split16.hip's variant 12 -- per workgroup t0 entry, t1 first stage
 // landed, t2 K loop done, t3 stores accepted (wave 0), XCC id, HW id, then each wave's "stores accepted" -- into a buffer nothing reads.
 static __device__ unsigned long long* g_duo_stamps = nullptr;
-int duo_set_stamp_buffer(void* dev_ptr) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_duo_stamps), &dev_ptr, sizeof(dev_ptr)); }
+static __device__ unsigned int g_duo_stamp_cap = 0;      // workgroups the buffer has room for: larger grids do not stamp
+int duo_set_stamp_buffer(void* dev_ptr, unsigned int capacity_blocks) {
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_duo_stamp_cap), &capacity_blocks, sizeof(capacity_blocks)) != hipSuccess) return 1;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_duo_stamps), &dev_ptr, sizeof(dev_ptr));
+}
 
 // ABL bit mask (timing ablations, results wrong on purpose): 1 = no epilogue, 2 = no A loads, 4 = no W loads; 8 = stamps (results correct)
 // BM = rows of the tile: 256 with a 2-stage A ring (64 KB; operands of step k + 1 in flight during step k), or 192 with a 3-stage ring
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
       for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[b][i][j]));
-    if ((ABL & 8) && g_duo_stamps != nullptr && lane == 0) {
+    if ((ABL & 8) && g_duo_stamps != nullptr && blockIdx.x < g_duo_stamp_cap && lane == 0) {
       unsigned long long* o = g_duo_stamps + (size_t)blockIdx.x * 20;
       o[6 + wave] = ts2;
       if (wave == 0) {
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
 #pragma unroll
     for (int i = 0; i < NT; ++i) asm volatile("" ::"v"(touched[i]));
   }
-  if ((ABL & 8) && g_duo_stamps != nullptr && lane == 0) {
+  if ((ABL & 8) && g_duo_stamps != nullptr && blockIdx.x < g_duo_stamp_cap && lane == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long ts3 = __builtin_amdgcn_s_memrealtime();
     unsigned long long* o = g_duo_stamps + (size_t)blockIdx.x * 20;
@@ -336,6 +340,10 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
 // ---------------------------------------------------------------------------------------------- host side
 // Fragment-order copies made on demand for weights that were not created through ribca_vit_create (tests, tools): keyed by the
 // packed weight's device address.  Model weights carry their own copy (GemmArgs::WF).
+#ifndef RIBCA_DIAG
+static const uint16_t* wf_for(const GemmArgs& g, hipStream_t) { return g.WF; }     // product build: the caller owns the fragment-order copy
+#else
+// (diagnostic library only: single-threaded tools; the copy is remade on the caller's stream on every call)
 static const uint16_t* wf_for(const GemmArgs& g, hipStream_t s) {
   if (g.WF != nullptr) return g.WF;
   static std::map<std::tuple<const void*, int, int>, uint16_t*> cache;
@@ -353,9 +361,11 @@ static const uint16_t* wf_for(const GemmArgs& g, hipStream_t s) {
   cache[key] = wf;
   return wf;
 }
+#endif
 
+// false = not launched (no fragment-order weight): the caller runs the one-workgroup-per-CU kernel instead
 template <int BM, int NW, int WM, int NWS, int BN, class Epi>
-static void launch_duo_impl(const GemmArgs& g, const Epi& epi, hipStream_t s, int abl) {
+static bool launch_duo_impl(const GemmArgs& g, const Epi& epi, hipStream_t s, int abl) {
   static const int mode = getenv("RIBCA_DUO_MODE") ? atoi(getenv("RIBCA_DUO_MODE")) : 0;
   static const int delay_per_step = getenv("RIBCA_DUO_DELAY") ? atoi(getenv("RIBCA_DUO_DELAY")) : 40;   // 10 ns ticks per K step
   static const int lds_pad = getenv("RIBCA_DUO_SOLO") ? 1 : 0;      // diagnostics: one workgroup per CU (LDS padded past half)
@@ -365,7 +375,7 @@ static void launch_duo_impl(const GemmArgs& g, const Epi& epi, hipStream_t s, in
   const int ntiles = gemm_padded_n(g.N) / BN;
   const size_t lds = lds_pad ? (size_t)100 * 1024 : (size_t)NST * BM * ROWB;
   const uint16_t* wf = wf_for(g, s);
-  if (wf == nullptr) return;
+  if (wf == nullptr) return false;
   const dim3 grid(mtiles * ntiles), block(64 * NW);
   const int delay = delay_per_step * (g.Kp / BK);
   auto go = [&](auto abl_c) {
@@ -379,39 +389,53 @@ static void launch_duo_impl(const GemmArgs& g, const Epi& epi, hipStream_t s, in
     hipLaunchKernelGGL((gemm_ps_duo_kernel<BM, NW, WM, TN, NWS, Epi, ABL>), grid, block, lds, s, g.A, g.lda, wf, g.M, g.Kp, mtiles, ntiles, epi, mode, delay);
   };
   // the diagnostic forms (no epilogue / stamps) exist for the epilogues tools/bench_gemm.py and tools/stamp_duo.py drive
+#ifdef RIBCA_DIAG
   constexpr bool diag = std::is_same<Epi, EpiGelu>::value || std::is_same<Epi, EpiResid>::value;
+#else
+  constexpr bool diag = false;
+#endif
   if constexpr (diag) {
     switch (abl) {
-      case 1: go(std::integral_constant<int, 1>{}); return;
-      case 8: go(std::integral_constant<int, 8>{}); return;
-      case 9: go(std::integral_constant<int, 9>{}); return;
+      case 1: go(std::integral_constant<int, 1>{}); return true;
+      case 8: go(std::integral_constant<int, 8>{}); return true;
+      case 9: go(std::integral_constant<int, 9>{}); return true;
       default: break;
     }
   }
   go(std::integral_constant<int, 0>{});
+  return true;
 }
 
 template <int BN, class Epi>
-void launch_duo(const GemmArgs& g, const Epi& epi, hipStream_t s, int abl) {
+bool launch_duo(const GemmArgs& g, const Epi& epi, hipStream_t s, int abl) {
   // RIBCA_DUO_FORM (A/B): 0 = 192-row tiles, 3-stage ring, 4 waves as 1 x 4 (2 x 2 for 96-wide tiles), 3 W sets (production);
   // 1 = the same tile with 8 waves as 2 x 4 (4 x 2), 2 W sets; 2 = 256 rows, 2-stage ring, 4 waves
   static const int form = getenv("RIBCA_DUO_FORM") ? atoi(getenv("RIBCA_DUO_FORM")) : 0;
+  (void)form;
   if constexpr (BN % 64 == 0) {
-    if (form == 2) launch_duo_impl<256, 4, 1, 2, BN, Epi>(g, epi, s, abl);
-    else if (form == 1) launch_duo_impl<192, 8, 2, 2, BN, Epi>(g, epi, s, abl);
-    else launch_duo_impl<192, 4, 1, 3, BN, Epi>(g, epi, s, abl);
+#ifdef RIBCA_DIAG
+    if (form == 2) return launch_duo_impl<256, 4, 1, 2, BN, Epi>(g, epi, s, abl);
+    if (form == 1) return launch_duo_impl<192, 8, 2, 2, BN, Epi>(g, epi, s, abl);
+#endif
+    return launch_duo_impl<192, 4, 1, 3, BN, Epi>(g, epi, s, abl);
   } else {   // BN = 96
-    if (form == 2) launch_duo_impl<256, 4, 2, 2, BN, Epi>(g, epi, s, abl);
-    else if (form == 1) launch_duo_impl<192, 8, 4, 2, BN, Epi>(g, epi, s, abl);
-    else launch_duo_impl<192, 4, 2, 3, BN, Epi>(g, epi, s, abl);
+#ifdef RIBCA_DIAG
+    if (form == 2) return launch_duo_impl<256, 4, 2, 2, BN, Epi>(g, epi, s, abl);
+    if (form == 1) return launch_duo_impl<192, 8, 4, 2, BN, Epi>(g, epi, s, abl);
+#endif
+    return launch_duo_impl<192, 4, 2, 3, BN, Epi>(g, epi, s, abl);
   }
 }
 
-#define RIBCA_DUO_INST(BN, EPI) template void launch_duo<BN, EPI>(const GemmArgs&, const EPI&, hipStream_t, int);
-RIBCA_DUO_INST(128, EpiResid) RIBCA_DUO_INST(96, EpiResid) RIBCA_DUO_INST(64, EpiResid)
+#define RIBCA_DUO_INST(BN, EPI) template bool launch_duo<BN, EPI>(const GemmArgs&, const EPI&, hipStream_t, int);
 RIBCA_DUO_INST(128, EpiGelu) RIBCA_DUO_INST(96, EpiGelu) RIBCA_DUO_INST(64, EpiGelu)
+RIBCA_DUO_INST(128, EpiGeluLn) RIBCA_DUO_INST(96, EpiGeluLn) RIBCA_DUO_INST(64, EpiGeluLn)
+#ifdef RIBCA_DIAG
+RIBCA_DUO_INST(128, EpiResid) RIBCA_DUO_INST(96, EpiResid) RIBCA_DUO_INST(64, EpiResid)
 RIBCA_DUO_INST(128, EpiQKV) RIBCA_DUO_INST(96, EpiQKV) RIBCA_DUO_INST(64, EpiQKV)
+RIBCA_DUO_INST(128, EpiQKVLn) RIBCA_DUO_INST(96, EpiQKVLn) RIBCA_DUO_INST(64, EpiQKVLn)
 RIBCA_DUO_INST(128, EpiRowMap) RIBCA_DUO_INST(96, EpiRowMap) RIBCA_DUO_INST(64, EpiRowMap)
+#endif
 #undef RIBCA_DUO_INST
 
 }  // namespace ribca

@@ -21,14 +21,27 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 // (bias once per column group, the residual z tile) back to back, `apply` then computes and stores.  A single sweep
 // that loads, waits and stores per tile costs one L2/HBM round trip per tile (16 dependent round trips ~ 11 us per
 // 256 x 128 tile, as much as 14 K-steps of MFMAs).
+// Interface of an epilogue functor (the drivers below and the LDS drain of gemm_split16.hip call exactly these):
+//   fetch_bias(n) / fetch_csum(n)  per 4-column chunk: bias and (folded LayerNorm only) column sums of the weight
+//   fetch_row(m)                   per output row: (rstd, -mean * rstd) of the LayerNorm folded into this GEMM, else empty
+//   fetch(m, n, ctx)               per (row, chunk): residual / table values
+//   apply<PX>(m, n, acc, bias, csum, rowstat, ctx [, Row, Col])
+struct NoRow {};
+struct LnRow { float rstd, nm; };   // nm = -mean * rstd
+__device__ __forceinline__ void settle_row(NoRow&) {}
+__device__ __forceinline__ void settle_row(LnRow& r) { asm volatile("" : "+v"(r.rstd), "+v"(r.nm)); }
+
 struct EpiResid {
   float* z; int ldz; const float* bias; int M, N; int nt = 0;
   struct Ctx { float4 zv; };
+  typedef NoRow RowS;
+  __device__ __forceinline__ RowS fetch_row(int) const { return RowS{}; }
+  __device__ __forceinline__ float4 fetch_csum(int) const { return float4{0.f, 0.f, 0.f, 0.f}; }
   // The residual tile z[m0 .. m0 + 255][n0 .. n0 + BN) was written one or two launches ago and has left the L2: the drain's z loads
   // are HBM / Infinity-Cache misses, ~3 us of every tile's epilogue (profiles/r2/resid_epilogue_l2_resident_z_experiment.txt).  The
   // loader waves therefore TOUCH it (one dword per 128-byte line, result discarded) right behind the last ring stage they issue,
   // two K steps before the drain reads it.
-  static constexpr bool kTouch = true;
+  static constexpr bool kTouch = true, kFold = false;
   __device__ __forceinline__ bool touch_on() const { return (nt & 2) == 0; }      // nt bit 1: RIBCA_GEMM_TOUCH=0 (A/B)
   __device__ __forceinline__ const float* touch_ptr(int m, int n) const {      // always a valid address: the touch is issued by every
     return z + (size_t)(m < M ? m : M - 1) * ldz + (n < N ? n : N - 1);         // wave, whatever its rows (the caller counts vmcnt)
@@ -40,7 +53,7 @@ struct EpiResid {
     c.zv = (m < M && n < N) ? *reinterpret_cast<const float4*>(z + (size_t)m * ldz + n) : float4{0.f, 0.f, 0.f, 0.f};
   }
   template <int PX = 16>
-  __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx& c) const {
+  __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const float4&, const RowS&, const Ctx& c) const {
     if (m >= M || n >= N) return;
     f32x4 o;
     o[0] = c.zv.x + (v[0] + b.x); o[1] = c.zv.y + (v[1] + b.y); o[2] = c.zv.z + (v[2] + b.z); o[3] = c.zv.w + (v[3] + b.w);
@@ -50,29 +63,96 @@ struct EpiResid {
   }
 };
 
-struct EpiGelu {
-  static constexpr bool kTouch = false;
-  uint16_t* out; int ldo; const float* bias; int M, N; int nt = 0;
+// Residual update on a PACKED-SPLIT residual stream (the classifiers' blocks): z[m][n] += acc + bias with z stored as fp16 hi + lo
+// (22 bits), which is exactly the A operand the next qkv / fc1 GEMM reads -- no LayerNorm kernel, no second copy of the row.
+// The drain (lds_drain_resid_ps, gemm_split16.hip) also emits per (row, column tile) the mean and the centred sum of squares of the
+// NEW row segment; ln_finalize_kernel combines a row's tiles in tile order (Chan's update) into (rstd, -mean rstd).
+// Only the LDS-drain form of the kernel supports it (fetch / apply are never called).
+struct EpiResidPS {
+  static constexpr bool kTouch = true, kFold = false;
+  uint16_t* z; int ldz; const float* bias; int M, N; int nt = 0;
+  float2* part = nullptr;      // [column tiles][M] (mean, M2), or nullptr: no statistics wanted
   struct Ctx {};
+  typedef NoRow RowS;
+  __device__ __forceinline__ bool touch_on() const { return (nt & 2) == 0; }
+  __device__ __forceinline__ const float* touch_ptr(int m, int n) const {      // one dword of the 128-byte line holding columns n .. n + 31
+    return reinterpret_cast<const float*>(z + (size_t)(m < M ? m : M - 1) * ldz + 2 * (n < N ? n : N - 8));
+  }
+  __device__ __forceinline__ RowS fetch_row(int) const { return RowS{}; }
+  __device__ __forceinline__ float4 fetch_csum(int) const { return float4{0.f, 0.f, 0.f, 0.f}; }
   __device__ __forceinline__ float4 fetch_bias(int n) const {
     return n < N ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
   }
   __device__ __forceinline__ void fetch(int, int, Ctx&) const {}
   template <int PX = 16>
-  __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx&) const {
+  __device__ __forceinline__ void apply(int, int, const f32x4&, const float4&, const float4&, const RowS&, const Ctx&) const {}
+};
+
+// LayerNorm folded into the GEMM that follows it (timm Block.norm1 -> attn.qkv, norm2 -> mlp.fc1):
+//   LN(z) W^T + b = rstd (z (gamma o W)^T) - rstd mean c + b',   c[n] = sum_k (gamma o W)[n][k],  b' = b + W beta
+// The GEMM reads the residual stream z itself (packed-split), its weight is gamma o W (ribca_vit_create folds it), and the
+// epilogue applies the per-row (rstd, nm = -mean rstd) that the preceding residual epilogue produced:  x = rstd acc + (nm c + b').
+template <bool FOLD>
+__device__ __forceinline__ float4 ln_fold4(const f32x4& v, const float4& b, const float4& c, const std::conditional_t<FOLD, LnRow, NoRow>& r) {
+  if constexpr (FOLD) {
+    return float4{fmaf(r.rstd, v[0], fmaf(r.nm, c.x, b.x)), fmaf(r.rstd, v[1], fmaf(r.nm, c.y, b.y)), fmaf(r.rstd, v[2], fmaf(r.nm, c.z, b.z)),
+                  fmaf(r.rstd, v[3], fmaf(r.nm, c.w, b.w))};
+  } else {
+    return float4{v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w};
+  }
+}
+
+template <bool FOLD>
+struct EpiGeluT {
+  static constexpr bool kTouch = false, kFold = FOLD;
+  uint16_t* out; int ldo; const float* bias; int M, N; int nt = 0;
+  const float2* rowstat = nullptr; const float* csum = nullptr;     // FOLD only
+  struct Ctx {};
+  typedef std::conditional_t<FOLD, LnRow, NoRow> RowS;
+  __device__ __forceinline__ RowS fetch_row(int m) const {
+    if constexpr (FOLD) { const float2 r = this->rowstat[m < M ? m : M - 1]; return RowS{r.x, r.y}; }
+    else return RowS{};
+  }
+  __device__ __forceinline__ float4 fetch_csum(int n) const {
+    if constexpr (FOLD) return n < N ? *reinterpret_cast<const float4*>(this->csum + n) : float4{0.f, 0.f, 0.f, 0.f};
+    else return float4{0.f, 0.f, 0.f, 0.f};
+  }
+  __device__ __forceinline__ float4 fetch_bias(int n) const {      // bias == nullptr: already added (plain())
+    return (bias != nullptr && n < N) ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  // the same epilogue for a tile whose fold (and bias) has already been applied to the accumulators (gemm_split16.hip does it before
+  // parking the tile: the drain then needs neither row statistics nor column sums)
+  __device__ __forceinline__ EpiGeluT<false> plain() const { return EpiGeluT<false>{out, ldo, nullptr, M, N, nt}; }
+  __device__ __forceinline__ void fetch(int, int, Ctx&) const {}
+  template <int PX = 16>
+  __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const float4& c, const RowS& r, const Ctx&) const {
     if (m >= M || n >= N) return;
-    const f32x2v u0 = gelu_erf2(f32x2v{v[0] + b.x, v[1] + b.y}), u1 = gelu_erf2(f32x2v{v[2] + b.z, v[3] + b.w});
+    const float4 x = ln_fold4<FOLD>(v, b, c, r);
+    const f32x2v u0 = gelu_erf2(f32x2v{x.x, x.y}), u1 = gelu_erf2(f32x2v{x.z, x.w});
     float t[4] = {u0.x, u0.y, u1.x, u1.y};
     ps_store4_pair<PX>(out + (size_t)m * ldo, n, t, nt != 0);      // N % 8 == 0: the partner lane (n ^ 4, same m) passed the same guard
   }
 };
+typedef EpiGeluT<false> EpiGelu;
+typedef EpiGeluT<true> EpiGeluLn;
 
-struct EpiQKV {
-  static constexpr bool kTouch = false;
+template <bool FOLD>
+struct EpiQKVT {
+  static constexpr bool kTouch = false, kFold = FOLD;
+  typedef std::conditional_t<FOLD, LnRow, NoRow> RowS;
+  __device__ __forceinline__ RowS fetch_row(int m) const {
+    if constexpr (FOLD) { const float2 r = this->rowstat[m < M ? m : M - 1]; return RowS{r.x, r.y}; }
+    else return RowS{};
+  }
+  __device__ __forceinline__ float4 fetch_csum(int n) const {
+    if constexpr (FOLD) return n < N ? *reinterpret_cast<const float4*>(this->csum + n) : float4{0.f, 0.f, 0.f, 0.f};
+    else return float4{0.f, 0.f, 0.f, 0.f};
+  }
   uint16_t* q; uint16_t* k; uint16_t* vt; const float* bias; int D, hd, hdp /* stored dims per Q/K row = AttnGeom::hdq */, hdv; float scale; int M, N;
   int T, TP, H, KP;   // tokens per cell, padded token rows of Q/K, heads, padded keys per V^T row
   int nt = 0;
   unsigned magicT = 0;   // ceil(2^32 / T): m / T as one v_mul_hi + a fix-up (the epilogue does one such division per output row)
+  const float2* rowstat = nullptr; const float* csum = nullptr;     // FOLD only
   struct Ctx {};
   // row / column decompositions are computed once per accumulator row (4) and column group (TN), not once per tile
   struct Row { int cell, t, vpos; };
@@ -97,14 +177,19 @@ struct EpiQKV {
     c.d = f - c.head * hd;   // multiple of 4, d+3 < hd (hd % 4 == 0)
     return c;
   }
-  __device__ __forceinline__ float4 fetch_bias(int n) const {
-    return n < N ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+  __device__ __forceinline__ float4 fetch_bias(int n) const {      // bias == nullptr: already added (plain())
+    return (bias != nullptr && n < N) ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  __device__ __forceinline__ EpiQKVT<false> plain() const {
+    return EpiQKVT<false>{q, k, vt, nullptr, D, hd, hdp, hdv, scale, M, N, T, TP, H, KP, nt, magicT};
   }
   __device__ __forceinline__ void fetch(int, int, Ctx&) const {}
   template <int PX = 16>
-  __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx&, const Row& r, const Col& c) const {
+  __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const float4& cs, const RowS& rs, const Ctx&, const Row& r,
+                                        const Col& c) const {
     if (m >= M || n >= N) return;
-    float x[4] = {v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w};
+    const float4 xf = ln_fold4<FOLD>(v, b, cs, rs);
+    float x[4] = {xf.x, xf.y, xf.z, xf.w};
     const size_t ch = (size_t)r.cell * H + c.head;
     if (c.which < 2) {
       if (c.which == 0) {
@@ -126,13 +211,18 @@ struct EpiQKV {
     }
   }
 };
+typedef EpiQKVT<false> EpiQKV;
+typedef EpiQKVT<true> EpiQKVLn;
 
 // fp32 output with a per-cell row map (marker imputer): GEMM row m = cell * R + j is written to row
 // cell * dst_per_cell + slot[j] of `out`, plus bias and an optional table row add[addrow[j]] (positional embeddings).
 struct EpiRowMap {
-  static constexpr bool kTouch = false;
+  static constexpr bool kTouch = false, kFold = false;
   float* out; int ldo; const float* bias; const float* add; int ldadd; const int* slot; const int* addrow; int R, dst_per_cell; int M, N;
   struct Ctx { float4 a; };
+  typedef NoRow RowS;
+  __device__ __forceinline__ RowS fetch_row(int) const { return RowS{}; }
+  __device__ __forceinline__ float4 fetch_csum(int) const { return float4{0.f, 0.f, 0.f, 0.f}; }
   __device__ __forceinline__ float4 fetch_bias(int n) const {
     return n < N ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
   }
@@ -144,7 +234,7 @@ struct EpiRowMap {
     }
   }
   template <int PX = 16>
-  __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const Ctx& c) const {
+  __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const float4&, const RowS&, const Ctx& c) const {
     if (m >= M || n >= N) return;
     const int cell = m / R, j = m - cell * R;
     float4 o;
@@ -167,17 +257,25 @@ template <class Epi> struct has_rowcol<Epi, std::void_t<typename Epi::Row>> : st
 
 template <int TN, class Epi, int R = 4>
 __device__ __forceinline__ void run_epilogue(const Epi& epi, int mbase, int nbase, f32x4 (&acc)[R][TN]) {
-  float4 b4[TN];
+  float4 b4[TN], c4[TN];
   typename Epi::Ctx ctx[R][TN];
+  typename Epi::RowS rs[R];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) b4[j] = epi.fetch_bias(nbase + 16 * j);
+  for (int j = 0; j < TN; ++j) { b4[j] = epi.fetch_bias(nbase + 16 * j); c4[j] = epi.fetch_csum(nbase + 16 * j); }
+#pragma unroll
+  for (int i = 0; i < R; ++i) rs[i] = epi.fetch_row(mbase + 16 * i);
 #pragma unroll
   for (int i = 0; i < R; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) epi.fetch(mbase + 16 * i, nbase + 16 * j, ctx[i][j]);
   // one wait for everything that was loaded, before the first store (see settle())
 #pragma unroll
-  for (int j = 0; j < TN; ++j) settle(b4[j]);
+  for (int j = 0; j < TN; ++j) {
+    settle(b4[j]);
+    if constexpr (Epi::kFold) settle(c4[j]);
+  }
+#pragma unroll
+  for (int i = 0; i < R; ++i) settle_row(rs[i]);
 #pragma unroll
   for (int i = 0; i < R; ++i)
 #pragma unroll
@@ -192,12 +290,12 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, int mbase, int nbas
 #pragma unroll
     for (int i = 0; i < R; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) epi.apply(mbase + 16 * i, nbase + 16 * j, acc[i][j], b4[j], ctx[i][j], rows[i], cols[j]);
+      for (int j = 0; j < TN; ++j) epi.apply(mbase + 16 * i, nbase + 16 * j, acc[i][j], b4[j], c4[j], rs[i], ctx[i][j], rows[i], cols[j]);
   } else {
 #pragma unroll
     for (int i = 0; i < R; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) epi.apply(mbase + 16 * i, nbase + 16 * j, acc[i][j], b4[j], ctx[i][j]);
+      for (int j = 0; j < TN; ++j) epi.apply(mbase + 16 * i, nbase + 16 * j, acc[i][j], b4[j], c4[j], rs[i], ctx[i][j]);
   }
 }
 
@@ -211,7 +309,7 @@ template <int CNT> __device__ __forceinline__ void wait_vmcnt() {
 
 // gemm_duo.hip: two 256-thread workgroups per CU, W in fragment order straight to registers (abl: timing ablations, 0 = none)
 template <int BN, class Epi>
-void launch_duo(const GemmArgs& g, const Epi& epi, hipStream_t s, int abl);
-int duo_set_stamp_buffer(void* dev_ptr);
+bool launch_duo(const GemmArgs& g, const Epi& epi, hipStream_t s, int abl);
+int duo_set_stamp_buffer(void* dev_ptr, unsigned int capacity_blocks);
 
 }  // namespace ribca

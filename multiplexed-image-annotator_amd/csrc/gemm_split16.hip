@@ -45,6 +45,7 @@ namespace ribca {
 // entry, after the first stage has landed, after the K loop and after its epilogue, plus the XCC/CU it ran on, into a
 // buffer nothing else reads.
 __device__ unsigned long long* g_stamps = nullptr;
+__device__ unsigned int g_stamp_cap = 0;      // workgroups the buffer has room for: larger grids do not stamp
 constexpr int kStampStride = 20;   // per workgroup: t0..t3, xcc, hw id, then the epilogue end of each of the 12 waves
 __device__ __forceinline__ unsigned long long stamp_now() { return __builtin_amdgcn_s_memrealtime(); }
 
@@ -59,6 +60,12 @@ __device__ __forceinline__ unsigned long long stamp_now() { return __builtin_amd
 // neighbouring lane.  A V tile of the qkv product scatters 2-byte elements along V^T rows and keeps the register path.
 template <class Epi> __device__ __forceinline__ bool lepi_tile_uses_registers(const Epi&, int, int) { return false; }
 template <> __device__ __forceinline__ bool lepi_tile_uses_registers<EpiQKV>(const EpiQKV& e, int n0, int bn) { return n0 + bn > 2 * e.D; }
+
+
+template <class Epi> __device__ __forceinline__ auto lepi_plain(const Epi& e) {
+  if constexpr (Epi::kFold) return e.plain();
+  else return e;
+}
 
 template <int BN>
 __device__ __forceinline__ void lds_park(char* smem, const f32x4 (&acc)[4][BN / 32], int wm, int wn, int r16, int g) {
@@ -79,12 +86,18 @@ __device__ __forceinline__ void lds_drain(const Epi& epi, const char* smem, int 
   static_assert(768 % CPR == 0, "a thread keeps its column chunk across passes");
   const int c = tid % CPR, row0 = tid / CPR;
   const int n = n0 + 4 * c;
-  float4 b4 = epi.fetch_bias(n);
+  float4 b4 = epi.fetch_bias(n), c4 = epi.fetch_csum(n);
   typename Epi::Ctx ctx[NIT];
+  typename Epi::RowS rs[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int row = row0 + it * RSTEP;
-    if (NIT * RSTEP == 256 || row < 256) epi.fetch(m0 + row, n, ctx[it]);
+    if (NIT * RSTEP == 256 || row < 256) {
+      epi.fetch(m0 + row, n, ctx[it]);
+      rs[it] = epi.fetch_row(m0 + row);
+    } else {
+      rs[it] = typename Epi::RowS{};
+    }
   }
   // ALL of this thread's chunks leave LDS before the first store is issued.  The kernel contains LDS-DMA, so hipcc guards every
   // use of a ds_read result with s_waitcnt vmcnt(0) (an LDS-DMA could be pending for all it knows) -- interleaved with the stores
@@ -103,23 +116,162 @@ __device__ __forceinline__ void lds_drain(const Epi& epi, const char* smem, int 
 #pragma unroll
   for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(vals[it]));
   settle(b4);
+  if constexpr (Epi::kFold) settle(c4);
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) settle_ctx(ctx[it]);
+  for (int it = 0; it < NIT; ++it) { settle_ctx(ctx[it]); settle_row(rs[it]); }
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (has_rowcol<Epi>::value) {
     const typename Epi::Col col = epi.col(n);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int row = row0 + it * RSTEP;
-      if (NIT * RSTEP == 256 || row < 256) epi.template apply<1>(m0 + row, n, vals[it], b4, ctx[it], epi.row(m0 + row), col);
+      if (NIT * RSTEP == 256 || row < 256) epi.template apply<1>(m0 + row, n, vals[it], b4, c4, rs[it], ctx[it], epi.row(m0 + row), col);
     }
   } else {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int row = row0 + it * RSTEP;
-      if (NIT * RSTEP == 256 || row < 256) epi.template apply<1>(m0 + row, n, vals[it], b4, ctx[it]);
+      if (NIT * RSTEP == 256 || row < 256) epi.template apply<1>(m0 + row, n, vals[it], b4, c4, rs[it], ctx[it]);
     }
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------- residual drain, packed-split z
+// sum over the 32 lanes of a half wave, the same bits in every lane of the half: four DPP steps (quad, quad, 8, 16) and one bpermute
+__device__ __forceinline__ float dpp_add(float v, float o) { return v + o; }
+template <int CTRL> __device__ __forceinline__ float dpp_get(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v += dpp_get<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_get<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_get<0x141>(v);     // row_half_mirror: the other quad of the 8
+  v += dpp_get<0x140>(v);     // row_mirror: the other 8 of the 16
+  v += __shfl_xor(v, 16, 64);
+  return v;
+}
+// EpiResidPS: z (fp16 hi + lo) += tile + bias, row statistics of the new segment.  A wave owns whole rows: lanes 0-31 one row, lanes
+// 32-63 the next, lane c the 16-byte chunk c of the tile row (CPR = BN / 4 <= 32 chunks), so a row's sums are DPP reductions in a
+// fixed order.  A lane pair (even, odd chunk) shares one PS 8-group: the even lane loads / stores its 8 hi halves, the odd lane
+// the 8 lo halves, and one DPP exchange gives each lane hi and lo of its own four columns.
+template <int BN>
+__device__ __forceinline__ void lds_drain_resid_ps(const EpiResidPS& epi, const char* smem, int m0, int n0, int nt, int tid) {
+  constexpr int SROW = BN * 4 + 16, CPR = BN / 4, NIT = 11;     // 12 waves x 2 rows x 11 passes = 264 >= 256 rows
+  static_assert(CPR <= 32, "a tile row fits a half wave");
+  const int lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, half = lane >> 5;
+  const int n = n0 + 4 * c;
+  const bool col_ok = c < CPR && n < epi.N;
+  const bool odd = (c & 1) != 0;
+  float4 b4 = col_ok ? *reinterpret_cast<const float4*>(epi.bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+  const int gofs = 2 * (n & ~7) + (odd ? 8 : 0);
+  const int rbase = 2 * wave + half;
+  uint4 zraw[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int row = rbase + 24 * it;
+    const bool ok = col_ok && row < 256 && m0 + row < epi.M;
+    zraw[it] = ok ? *reinterpret_cast<const uint4*>(epi.z + (size_t)(m0 + row) * epi.ldz + gofs) : uint4{0u, 0u, 0u, 0u};
+  }
+  f32x4 vals[NIT];
+  const char* src = smem + rbase * SROW + c * 16;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int row = rbase + 24 * it;
+    vals[it] = (c < CPR && row < 256) ? *reinterpret_cast<const f32x4*>(src + it * 24 * SROW) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(vals[it]));
+  settle(b4);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(zraw[it].x), "+v"(zraw[it].y), "+v"(zraw[it].z), "+v"(zraw[it].w));
+  __builtin_amdgcn_sched_barrier(0);
+  float xs[NIT][4], s[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int row = rbase + 24 * it;
+    const bool ok = col_ok && row < 256 && m0 + row < epi.M;
+    // even lane holds hi[0..7] and needs lo[0..3] (the odd lane's x, y); odd lane holds lo[0..7] and needs hi[4..7] (the even lane's z, w)
+    const uint32_t sx = odd ? zraw[it].x : zraw[it].z, sy = odd ? zraw[it].y : zraw[it].w;
+    const uint32_t rx = (uint32_t)__builtin_amdgcn_mov_dpp((int)sx, 0xB1, 0xF, 0xF, true);
+    const uint32_t ry = (uint32_t)__builtin_amdgcn_mov_dpp((int)sy, 0xB1, 0xF, 0xF, true);
+    const uint32_t hx = odd ? rx : zraw[it].x, hy = odd ? ry : zraw[it].y;
+    const uint32_t lx = odd ? zraw[it].z : rx, ly = odd ? zraw[it].w : ry;
+    const f32x2 h01 = unpack_f16(hx), h23 = unpack_f16(hy), l01 = unpack_f16(lx), l23 = unpack_f16(ly);
+    const f32x4& v = vals[it];
+    float x[4] = {(h01[0] + l01[0]) + (v[0] + b4.x), (h01[1] + l01[1]) + (v[1] + b4.y), (h23[0] + l23[0]) + (v[2] + b4.z),
+                  (h23[1] + l23[1]) + (v[3] + b4.w)};
+    uint2 nh, nl;
+    split4(x, nh, nl);
+    const uint32_t tx = odd ? nh.x : nl.x, ty = odd ? nh.y : nl.y;
+    const uint32_t ux = (uint32_t)__builtin_amdgcn_mov_dpp((int)tx, 0xB1, 0xF, 0xF, true);
+    const uint32_t uy = (uint32_t)__builtin_amdgcn_mov_dpp((int)ty, 0xB1, 0xF, 0xF, true);
+    const u32x4 o = odd ? u32x4{ux, uy, nl.x, nl.y} : u32x4{nh.x, nh.y, ux, uy};
+    if (ok) *reinterpret_cast<u32x4*>(epi.z + (size_t)(m0 + row) * epi.ldz + gofs) = o;
+    // statistics of what was stored (hi + lo is exact in fp32)
+    const f32x2 a01 = unpack_f16(nh.x), a23 = unpack_f16(nh.y), c01 = unpack_f16(nl.x), c23 = unpack_f16(nl.y);
+    xs[it][0] = a01[0] + c01[0]; xs[it][1] = a01[1] + c01[1]; xs[it][2] = a23[0] + c23[0]; xs[it][3] = a23[1] + c23[1];
+    s[it] = ok ? (xs[it][0] + xs[it][1]) + (xs[it][2] + xs[it][3]) : 0.f;
+  }
+  if (epi.part == nullptr) return;
+  const int ncols = (epi.N - n0) < BN ? (epi.N - n0) : BN;
+  const float inv = 1.0f / (float)ncols;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) s[it] = half_wave_sum(s[it]) * inv;       // tile mean of the row
+  float q[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int row = rbase + 24 * it;
+    const bool ok = col_ok && row < 256 && m0 + row < epi.M;
+    const float d0 = xs[it][0] - s[it], d1 = xs[it][1] - s[it], d2 = xs[it][2] - s[it], d3 = xs[it][3] - s[it];
+    q[it] = ok ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) q[it] = half_wave_sum(q[it]);
+  if (c == 0) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = rbase + 24 * it;
+      if (row < 256 && m0 + row < epi.M) epi.part[(size_t)nt * epi.M + m0 + row] = float2{s[it], q[it]};
+    }
+  }
+}
+template <int BN, class Epi>
+__device__ __forceinline__ void lds_drain_any(const Epi& epi, const char* smem, int m0, int n0, int nt, int tid) {
+  if constexpr (std::is_same<Epi, EpiResidPS>::value) lds_drain_resid_ps<BN>(epi, smem, m0, n0, nt, tid);
+  else if constexpr (Epi::kFold) lds_drain<BN>(epi.plain(), smem, m0, n0, tid);      // the consumers folded before parking
+  else lds_drain<BN>(epi, smem, m0, n0, tid);
+}
+
+// ---------------------------------------------------------------------------------------------- folded LayerNorm, in registers
+// Epi::kFold: behind the ring the workgroup keeps (rstd, -mean rstd) of its 256 rows, the column sums and the folded bias of its BN
+// columns (2 KB + 8 BN bytes, written by the loader waves while the first ring stages are in flight).  After the K loop every
+// consumer lane turns its accumulators into  x = rstd acc + (nm c + b')  -- 4 rows and TN column groups per lane -- so that the
+// epilogue proper (park, drain, or the register path of the V tiles) is the plain one with nothing left to add.
+constexpr int kFoldRowBytes = 256 * 8;
+template <int BN> constexpr int fold_lds_bytes() { return kFoldRowBytes + 8 * BN; }
+template <int BN, int TN>
+__device__ __forceinline__ void fold_accumulators(f32x4 (&acc)[4][TN], const char* xs, int wm, int wn, int r16, int g) {
+  float2 rs[4];
+  float4 c4[TN], b4[TN];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rs[i] = *reinterpret_cast<const float2*>(xs + (wm * 64 + i * 16 + r16) * 8);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = wn * (BN / 2) + j * 16 + 4 * g;
+    c4[j] = *reinterpret_cast<const float4*>(xs + kFoldRowBytes + col * 4);
+    b4[j] = *reinterpret_cast<const float4*>(xs + kFoldRowBytes + 4 * BN + col * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      acc[i][j][0] = fmaf(rs[i].x, acc[i][j][0], fmaf(rs[i].y, c4[j].x, b4[j].x));
+      acc[i][j][1] = fmaf(rs[i].x, acc[i][j][1], fmaf(rs[i].y, c4[j].y, b4[j].y));
+      acc[i][j][2] = fmaf(rs[i].x, acc[i][j][2], fmaf(rs[i].y, c4[j].z, b4[j].z));
+      acc[i][j][3] = fmaf(rs[i].x, acc[i][j][3], fmaf(rs[i].y, c4[j].w, b4[j].w));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- loader/consumer split
@@ -213,6 +365,21 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
         }
       }
     };
+    // folded LayerNorm: this lane's row statistics and (loader waves 0 / 1) a chunk of the column sums / folded bias, requested
+    // in FRONT of the first ring stage -- vmcnt retires in order, so the wait for stage 0 covers them -- and copied behind the ring
+    unsigned long long fold_rs = 0;
+    u32x4 fold_cb = {0u, 0u, 0u, 0u};
+    if constexpr (Epi::kFold) {
+      int gm = m0 + lw * 64 + lane;
+      gm = gm < M ? gm : M - 1;
+      const float2* rp = epi.rowstat + gm;
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(fold_rs) : "v"(rp) : "memory");
+      if (lw < 2) {
+        const int n = n0 + 4 * lane;
+        const float* cp = (lw == 0 ? epi.csum : epi.bias) + ((lane < BN / 4 && n < epi.N) ? n : 0);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fold_cb) : "v"(cp) : "memory");
+      }
+    }
     if (!abl_no_loads(ABL)) {
       issue(0, 0);
       if (nk > 1) issue(1, 1);
@@ -229,6 +396,16 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
         if (after_touch) wait_vmcnt<NT>();
         else wait_vmcnt<0>();
       }
+      if constexpr (Epi::kFold) {
+        if (kk == 0) {      // consumers read this after the K loop, many barriers from here
+          char* xs = smem + NST * STAGE;
+          *reinterpret_cast<unsigned long long*>(xs + (lw * 64 + lane) * 8) = fold_rs;
+          if (lw < 2 && lane < BN / 4) {
+            const bool ok = n0 + 4 * lane < epi.N;
+            *reinterpret_cast<u32x4*>(xs + kFoldRowBytes + lw * (4 * BN) + lane * 16) = ok ? fold_cb : u32x4{0u, 0u, 0u, 0u};
+          }
+        }
+      }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (!abl_no_loads(ABL) && kk + 2 < nk) {
@@ -242,12 +419,12 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
     }
     if (STAG) __builtin_amdgcn_s_barrier();     // phase 2nk
     if constexpr (LEPI && STAG && !abl_no_epi(ABL)) {
-      if (!lepi_tile_uses_registers(epi, n0, BN)) {
+      if (!lepi_tile_uses_registers(lepi_plain(epi), n0, BN)) {
         __syncthreads();                          // consumers have parked the tile
-        lds_drain<BN>(epi, smem, m0, n0, tid);
+        lds_drain_any<BN>(epi, smem, m0, n0, nt, tid);
       }
     }
-    if (ABL == 4 && g_stamps != nullptr && lane == 0) {      // per-wave end of the epilogue (stores accepted)
+    if (ABL == 4 && g_stamps != nullptr && blockIdx.x < g_stamp_cap && lane == 0) {      // per-wave end of the epilogue (stores accepted)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       g_stamps[(size_t)blockIdx.x * kStampStride + 6 + wave] = stamp_now();
     }
@@ -347,21 +524,31 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
       for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
-  if constexpr (LEPI && STAG) {
+  if constexpr (Epi::kFold) {
+    static_assert(LEPI && STAG, "the folded epilogues exist in the production form only");
+    fold_accumulators<BN, TN>(acc, smem + NST * STAGE, wm, wn, r16, g);
+    const auto pe = epi.plain();
+    if (lepi_tile_uses_registers(pe, n0, BN)) run_epilogue<TN>(pe, m0 + wm * 64 + r16, n0 + wn * (BN / 2) + 4 * g, acc);
+    else {
+      lds_park<BN>(smem, acc, wm, wn, r16, g);
+      __syncthreads();
+      lds_drain<BN>(pe, smem, m0, n0, tid);
+    }
+  } else if constexpr (LEPI && STAG) {
     if (lepi_tile_uses_registers(epi, n0, BN)) run_epilogue<TN>(epi, m0 + wm * 64 + r16, n0 + wn * (BN / 2) + 4 * g, acc);
     else {
       lds_park<BN>(smem, acc, wm, wn, r16, g);
       __syncthreads();
-      lds_drain<BN>(epi, smem, m0, n0, tid);
+      lds_drain_any<BN>(epi, smem, m0, n0, nt, tid);
     }
   } else {
     run_epilogue<TN>(epi, m0 + wm * 64 + r16, n0 + wn * (BN / 2) + 4 * g, acc);
   }
-  if (ABL == 4 && g_stamps != nullptr && lane == 0 && tid != 0) {
+  if (ABL == 4 && g_stamps != nullptr && blockIdx.x < g_stamp_cap && lane == 0 && tid != 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     g_stamps[(size_t)blockIdx.x * kStampStride + 6 + wave] = stamp_now();
   }
-  if (ABL == 4 && g_stamps != nullptr && tid == 0) {
+  if (ABL == 4 && g_stamps != nullptr && blockIdx.x < g_stamp_cap && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // epilogue stores of this wave have been accepted
     const unsigned long long t3 = stamp_now();
     unsigned long long* o = g_stamps + (size_t)blockIdx.x * kStampStride;
@@ -374,6 +561,7 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
   }
 }
 
+#ifdef RIBCA_DIAG
 // ---------------------------------------------------------------------------------------------- persistent form
 // Same tile, ring, roles and stagger as gemm_ps_split_kernel, but ONE workgroup per CU walks a sequence of tiles (tile ids
 // blockIdx.x, blockIdx.x + gridDim.x, ...; the XCD-aware id -> (m, n) map is unchanged, so a workgroup's tiles stay on its XCD and
@@ -533,6 +721,8 @@ __global__ __launch_bounds__(768) void gemm_ps_persist_kernel(const uint16_t* __
   }
 }
 
+#endif  // RIBCA_DIAG
+
 // ---------------------------------------------------------------------------------------------- host side
 int gemm_pick_bn(int N) {
   if (N % 128 == 0) return 128;
@@ -547,8 +737,10 @@ int gemm_padded_n(int N) {
 
 static int g_variant = 0;   // 0 = production kernel; 3/4/5/7/9 = A/B and timing-ablation forms (tools/bench_gemm.py)
 void gemm_set_variant(int v) { g_variant = v; }
-int gemm_set_stamp_buffer(void* dev_ptr) {
-  (void)duo_set_stamp_buffer(dev_ptr);
+int gemm_set_stamp_buffer(void* dev_ptr, long long capacity_blocks) {
+  const unsigned int cap = dev_ptr == nullptr || capacity_blocks <= 0 ? 0u : (unsigned int)(capacity_blocks > 0xffffffffll ? 0xffffffffll : capacity_blocks);
+  if (duo_set_stamp_buffer(dev_ptr, cap) != 0) return 1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_cap), &cap, sizeof(cap)) != hipSuccess) return 1;
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dev_ptr, sizeof(dev_ptr));
 }
 
@@ -556,7 +748,7 @@ template <int BN, class Epi, int ABL = 0, bool STAG = false, bool LEPI = false>
 static void launch_split(const GemmArgs& g, const Epi& epi, hipStream_t s) {
   const int mtiles = (g.M + 255) / 256;
   const int ntiles = gemm_padded_n(g.N) / BN;
-  const size_t lds = (size_t)3 * (256 + BN) * ROWB;
+  const size_t lds = (size_t)3 * (256 + BN) * ROWB + (Epi::kFold ? fold_lds_bytes<BN>() : 0);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ps_split_kernel<BN, Epi, ABL, STAG, LEPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -571,6 +763,7 @@ static void launch_split(const GemmArgs& g, const Epi& epi, hipStream_t s) {
                      ntiles, epi, deph);
 }
 
+#ifdef RIBCA_DIAG
 static int persist_mode() {       // RIBCA_GEMM_PERSIST=1 (or variant 30): persistent workgroups with cross-tile prefetch
   static const int m = getenv("RIBCA_GEMM_PERSIST") ? atoi(getenv("RIBCA_GEMM_PERSIST")) : 0;
   return m;
@@ -593,43 +786,59 @@ static void launch_persist(const GemmArgs& g, const Epi& epi, hipStream_t s) {
   const int grid = mtiles * ntiles < n_cu ? mtiles * ntiles : n_cu;
   hipLaunchKernelGGL((gemm_ps_persist_kernel<BN, Epi>), dim3(grid), dim3(768), lds, s, g.A, g.lda, g.W, g.ldw, g.M, g.Kp, mtiles, ntiles, epi);
 }
+#endif
 
+// Product build: ONE kernel form per (tile width, epilogue) -- loader waves + half-step stagger + LDS epilogue -- plus the
+// two-workgroups-per-CU kernel for mlp.fc1.  The A/B and timing-ablation forms of DESIGN.md section 6 (no stagger, no loads, no
+// epilogue, fewer MFMA passes, stamps, persistent workgroups, duo variants 40-49) exist only in the diagnostic library
+// (-DRIBCA_DIAG: `python -m multiplexed_image_annotator_amd.build --diag` -> libribca_hip_diag.so, used by tools/).
 template <int BN, class Epi>
 static void launch_bn(const GemmArgs& g, const Epi& epi, hipStream_t s) {
-  // Production: GELU GEMMs whose weight carries a fragment-order copy (GemmArgs::WF, set by the block runner for mlp.fc1) run on the
-  // two-workgroups-per-CU kernel: same bits, 4-12 % less time on those launches (tools/bench_gemm.py 0 40) and 1.4 % end to end
-  // (7.84 -> 7.73 s per pass, six interleaved rounds on one box: profiles/r2/duo_kernel/ab_end_to_end_fc1_on_duo_6rounds.txt).
-  // The residual and QKV epilogues stay here: there the duo form is 5-25 % slower.  RIBCA_GEMM_DUO=0: off.
-  if constexpr (std::is_same<Epi, EpiGelu>::value) {
+  // GELU GEMMs whose weight carries a fragment-order copy (GemmArgs::WF, set by the block runner for mlp.fc1) run on the
+  // two-workgroups-per-CU kernel: same bits, 4-12 % less time on those launches and 1.4 % end to end
+  // (profiles/r2/duo_kernel/ab_end_to_end_fc1_on_duo_6rounds.txt).  The residual and QKV epilogues stay here: there the duo form is
+  // 5-25 % slower.  RIBCA_GEMM_DUO=0: off.
+  if constexpr (std::is_same<Epi, EpiGelu>::value || std::is_same<Epi, EpiGeluLn>::value) {
     static const bool duo_on = !(getenv("RIBCA_GEMM_DUO") && atoi(getenv("RIBCA_GEMM_DUO")) == 0);
-    if (g_variant == 0 && duo_on && g.WF != nullptr && g.M >= 4096) {
-      launch_duo<BN, Epi>(g, epi, s, 0);
-      return;
+    if (g_variant == 0 && duo_on && g.WF != nullptr && g.M >= 4096 && launch_duo<BN, Epi>(g, epi, s, 0)) return;
+  }
+#ifdef RIBCA_DIAG
+  if constexpr (!std::is_same<Epi, EpiResidPS>::value) {
+    if (g_variant >= 40 && g_variant <= 49) {   // two workgroups per CU (gemm_duo.hip); 41-47 = its timing ablations (bit mask), 48 = stamps
+      if (launch_duo<BN, Epi>(g, epi, s, g_variant - 40)) return;   // 41 = no epilogue, 48 = stamps, 49 = both
     }
   }
-  if (g_variant >= 40 && g_variant <= 49) {   // two workgroups per CU (gemm_duo.hip); 41-47 = its timing ablations (bit mask), 48 = stamps
-    launch_duo<BN, Epi>(g, epi, s, g_variant - 40);   // 41 = no epilogue, 48 = stamps, 49 = both
-    return;
+  if constexpr (std::is_same<Epi, EpiResidPS>::value || Epi::kFold) {      // these epilogues exist in the LDS-drain forms only
+    switch (g_variant) {
+      case 21: launch_split<BN, Epi, 6, true, true>(g, epi, s); return;
+      case 22: launch_split<BN, Epi, 7, true, true>(g, epi, s); return;
+      case 12: launch_split<BN, Epi, 4, true, true>(g, epi, s); return;
+      case 9: launch_split<BN, Epi, 3, true, true>(g, epi, s); return;
+      default: break;
+    }
+  } else {
+    if ((g_variant == 30 || (g_variant == 0 && persist_mode())) && (g.M + 255) / 256 * (gemm_padded_n(g.N) / BN) >= 512) {
+      launch_persist<BN, Epi>(g, epi, s);
+      return;
+    }
+    switch (g_variant) {
+      case 3: launch_split<BN, Epi, 0, false>(g, epi, s); return;   // no stagger (A/B reference)
+      case 4: launch_split<BN, Epi, 1, false>(g, epi, s); return;   // ablation: no loads
+      case 5: launch_split<BN, Epi, 2, false>(g, epi, s); return;   // ablation: loads only
+      case 7: launch_split<BN, Epi, 1, true>(g, epi, s); return;    // ablation: no loads, staggered
+      case 9: launch_split<BN, Epi, 3, true>(g, epi, s); return;    // ablation: no epilogue
+      case 20: launch_split<BN, Epi, 5, true>(g, epi, s); return;   // ablation: no loads, no epilogue (the K-loop structure alone)
+      case 21: launch_split<BN, Epi, 6, true, true>(g, epi, s); return;   // ablation: 2 MFMAs per operand pair
+      case 22: launch_split<BN, Epi, 7, true, true>(g, epi, s); return;   // ablation: 1 MFMA per operand pair
+      case 23: launch_split<BN, Epi, 8, true>(g, epi, s); return;   // ablation: 2 MFMAs, no epilogue
+      case 24: launch_split<BN, Epi, 9, true>(g, epi, s); return;   // ablation: 1 MFMA, no epilogue
+      case 12: launch_split<BN, Epi, 4, true, true>(g, epi, s); return;   // production kernel + diagnostic time stamps
+      case 14: launch_split<BN, Epi, 0, true>(g, epi, s); return;   // A/B: epilogue straight from the accumulator registers
+      default: break;
+    }
   }
-  if ((g_variant == 30 || (g_variant == 0 && persist_mode())) && (g.M + 255) / 256 * (gemm_padded_n(g.N) / BN) >= 512) {
-    launch_persist<BN, Epi>(g, epi, s);
-    return;
-  }
-  switch (g_variant) {
-    case 3: launch_split<BN, Epi, 0, false>(g, epi, s); break;   // no stagger (A/B reference)
-    case 4: launch_split<BN, Epi, 1, false>(g, epi, s); break;   // ablation: no loads
-    case 5: launch_split<BN, Epi, 2, false>(g, epi, s); break;   // ablation: loads only
-    case 7: launch_split<BN, Epi, 1, true>(g, epi, s); break;    // ablation: no loads, staggered
-    case 9: launch_split<BN, Epi, 3, true>(g, epi, s); break;    // ablation: no epilogue
-    case 20: launch_split<BN, Epi, 5, true>(g, epi, s); break;   // ablation: no loads, no epilogue (the K-loop structure alone)
-    case 21: launch_split<BN, Epi, 6, true, true>(g, epi, s); break;   // ablation: 2 MFMAs per operand pair
-    case 22: launch_split<BN, Epi, 7, true, true>(g, epi, s); break;   // ablation: 1 MFMA per operand pair
-    case 23: launch_split<BN, Epi, 8, true>(g, epi, s); break;   // ablation: 2 MFMAs, no epilogue
-    case 24: launch_split<BN, Epi, 9, true>(g, epi, s); break;   // ablation: 1 MFMA, no epilogue
-    case 12: launch_split<BN, Epi, 4, true, true>(g, epi, s); break;   // production kernel + diagnostic time stamps
-    case 14: launch_split<BN, Epi, 0, true>(g, epi, s); break;   // A/B: epilogue straight from the accumulator registers
-    default: launch_split<BN, Epi, 0, true, true>(g, epi, s); break;   // production: loader waves + half-step stagger + LDS epilogue
-  }
+#endif
+  launch_split<BN, Epi, 0, true, true>(g, epi, s);   // production: loader waves + half-step stagger + LDS epilogue
 }
 
 template <class Epi>
@@ -654,6 +863,20 @@ void launch_gemm_resid(const GemmArgs& g, float* z, int ldz, hipStream_t s) {
 void launch_gemm_gelu(const GemmArgs& g, uint16_t* out, int ldo, hipStream_t s) {
   launch_any(g, EpiGelu{out, ldo, g.bias, g.M, g.N, nt_mask() & 1}, s);
 }
+void launch_gemm_resid_ps(const GemmArgs& g, uint16_t* z, int ldz, float2* part, hipStream_t s) {
+  static const int no_touch = (getenv("RIBCA_GEMM_TOUCH") && atoi(getenv("RIBCA_GEMM_TOUCH")) == 0) ? 2 : 0;
+  launch_any(g, EpiResidPS{z, ldz, g.bias, g.M, g.N, no_touch, part}, s);
+}
+void launch_gemm_gelu_ln(const GemmArgs& g, const float2* rowstat, const float* csum, uint16_t* out, int ldo, hipStream_t s) {
+  launch_any(g, EpiGeluLn{out, ldo, g.bias, g.M, g.N, nt_mask() & 1, rowstat, csum}, s);
+}
+void launch_gemm_qkv_ln(const GemmArgs& g, const float2* rowstat, const float* csum, uint16_t* q, uint16_t* k, uint16_t* vt, const AttnGeom& a,
+                        float scale, hipStream_t s) {
+  launch_any(g, EpiQKVLn{q, k, vt, g.bias, a.D, a.hd, a.hdq, a.hdv, scale, g.M, g.N, a.T, a.TP, a.H, a.KP, (nt_mask() >> 1) & 1,
+                         (unsigned)((0x100000000ull + (unsigned long long)a.T - 1) / (unsigned long long)a.T), rowstat, csum}, s);
+}
+int gemm_resid_tiles(int N) { return gemm_padded_n(N) / gemm_pick_bn(N); }
+int gemm_resid_bn(int N) { return gemm_pick_bn(N); }
 void launch_gemm_qkv(const GemmArgs& g, uint16_t* q, uint16_t* k, uint16_t* vt, const AttnGeom& a, float scale, hipStream_t s) {
   launch_any(g, EpiQKV{q, k, vt, g.bias, a.D, a.hd, a.hdq /* Q/K row pitch: compact */, a.hdv, scale, g.M, g.N, a.T, a.TP, a.H, a.KP, (nt_mask() >> 1) & 1,
                        (unsigned)((0x100000000ull + (unsigned long long)a.T - 1) / (unsigned long long)a.T)}, s);

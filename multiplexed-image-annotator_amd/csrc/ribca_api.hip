@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -77,10 +78,14 @@ struct BlockW {
   const float *ln1w, *ln1b, *qkvb, *projb, *ln2w, *ln2b, *fc1b, *fc2b;
   const uint16_t *qkvw, *projw, *fc1w, *fc2w;
   const uint16_t* fc1wf;   // fc1 weight again, in MFMA fragment order (gemm_duo.hip): the GELU GEMMs run on the two-workgroups-per-CU kernel
+  // LayerNorm folded into qkv / fc1 (classifiers): qkvw / fc1w then hold gamma o W, and per output column the sum of the packed row
+  // and the bias with beta folded in (vit_misc.hip pack_weight_fold_kernel)
+  const float *qkvc = nullptr, *qkvb2 = nullptr, *fc1c = nullptr, *fc1b2 = nullptr;
 };
 
 struct ribca_vit {
   int D, C, K, depth, hd, hdp, hdv, Dp, H4;
+  bool fold = true;        // LayerNorm folded into the qkv / fc1 GEMMs, residual stream packed-split (RIBCA_LN_FOLD=0 at create: round-2 path)
   char* arena = nullptr;
   size_t arena_bytes = 0;
   const float *cls, *pos, *pe_b, *norm_w, *norm_b, *head_w, *head_b;
@@ -112,8 +117,12 @@ struct Carver {
   }
 };
 
-void layout_block(Carver& c, BlockW& L, int D) {
+void layout_block(Carver& c, BlockW& L, int D, bool fold = false) {
   const int Dp = round_up(D, 32), H4 = 4 * D;
+  if (fold) {
+    L.qkvc = c.take<float>(3 * D); L.qkvb2 = c.take<float>(3 * D);
+    L.fc1c = c.take<float>(4 * D); L.fc1b2 = c.take<float>(4 * D);
+  }
   L.ln1w = c.take<float>(D); L.ln1b = c.take<float>(D);
   L.qkvb = c.take<float>(3 * D); L.projb = c.take<float>(D);
   L.ln2w = c.take<float>(D); L.ln2b = c.take<float>(D);
@@ -134,7 +143,7 @@ size_t layout(ribca_vit* m, char* base) {
   m->pe_b = c.take<float>(D);
   m->pe_w = c.take<float>((size_t)D * 16 * m->C);
   m->layers.resize(m->depth);
-  for (auto& L : m->layers) layout_block(c, L, D);
+  for (auto& L : m->layers) layout_block(c, L, D, m->fold);
   m->norm_w = c.take<float>(D); m->norm_b = c.take<float>(D);
   m->head_w = c.take<float>((size_t)m->K * D); m->head_b = c.take<float>(m->K);
   return c.off;
@@ -173,13 +182,23 @@ struct BlobReader {
     launch_pack_weight(p, N, K, const_cast<uint16_t*>(dst), gemm_padded_n(N), Kp, s);
     p += (size_t)N * K;
   }
-  void block(const BlockW& L, int D) {
+  // weight [N][K] and its bias [N] follow each other in the blob; gamma / beta were copied to the arena just before (same stream)
+  void pack_fold(const uint16_t* dst, int N, int K, int Kp, const float* gamma, const float* beta, const float* csum, const float* bias2) {
+    launch_pack_weight_fold(p, N, K, gamma, beta, p + (size_t)N * K, const_cast<uint16_t*>(dst), gemm_padded_n(N), Kp, const_cast<float*>(csum),
+                            const_cast<float*>(bias2), s);
+    p += (size_t)N * K;
+  }
+  void block(const BlockW& L, int D, bool fold = false) {
     const int Dp = round_up(D, 32);
     copy(L.ln1w, D); copy(L.ln1b, D);
-    pack(L.qkvw, 3 * D, D, Dp); copy(L.qkvb, 3 * D);
+    if (fold) pack_fold(L.qkvw, 3 * D, D, Dp, L.ln1w, L.ln1b, L.qkvc, L.qkvb2);
+    else pack(L.qkvw, 3 * D, D, Dp);
+    copy(L.qkvb, 3 * D);
     pack(L.projw, D, D, Dp); copy(L.projb, D);
     copy(L.ln2w, D); copy(L.ln2b, D);
-    pack(L.fc1w, 4 * D, D, Dp); copy(L.fc1b, 4 * D);
+    if (fold) pack_fold(L.fc1w, 4 * D, D, Dp, L.ln2w, L.ln2b, L.fc1c, L.fc1b2);
+    else pack(L.fc1w, 4 * D, D, Dp);
+    copy(L.fc1b, 4 * D);
     launch_pack_wf(L.fc1w, 2 * Dp, gemm_padded_n(4 * D), Dp, const_cast<uint16_t*>(L.fc1wf), s);
     pack(L.fc2w, D, 4 * D, 4 * D); copy(L.fc2b, D);
   }
@@ -190,12 +209,22 @@ int64_t block_params(int64_t d) { return 2 * d + 3 * d * d + 3 * d + d * d + d +
 struct BlockWs {
   float* z; uint16_t* xa; uint16_t* q; uint16_t* k; uint16_t* vt; uint16_t* h;
   size_t qk_bytes, vt_bytes, xa_bytes;
+  // folded-LayerNorm blocks: residual stream packed-split [rows][2 * Dp], per-tile row statistics of the last residual GEMM and
+  // the (rstd, -mean rstd) pairs the next qkv / fc1 epilogue reads
+  uint16_t* zps = nullptr; float2* part = nullptr; float2* rs = nullptr;
 };
-BlockWs carve_blocks(Carver& c, int cells, const AttnGeom& a) {
+BlockWs carve_blocks(Carver& c, int cells, const AttnGeom& a, bool fold = false) {
   BlockWs w;
   const size_t Mc = (size_t)cells * a.T;
   const int Dp = round_up(a.D, 32);
-  w.z = c.take<float>(Mc * a.D);
+  if (fold) {
+    w.z = nullptr;
+    w.zps = c.take<uint16_t>(Mc * 2 * Dp);
+    w.part = c.take<float2>(Mc * gemm_resid_tiles(a.D));
+    w.rs = c.take<float2>(Mc);
+  } else {
+    w.z = c.take<float>(Mc * a.D);
+  }
   w.xa_bytes = Mc * 2 * Dp * sizeof(uint16_t);
   w.xa = c.take<uint16_t>(Mc * 2 * Dp);
   const size_t qk = (size_t)cells * a.H * a.TP * 2 * a.hdq;
@@ -211,6 +240,7 @@ BlockWs carve_blocks(Carver& c, int cells, const AttnGeom& a) {
 // pads (tokens >= T, head dims >= hd, feature columns >= D) are never written by any kernel: zero them once per call
 int zero_pads(const BlockWs& w, hipStream_t s) {
   HIP_TRY(hipMemsetAsync(w.xa, 0, w.xa_bytes, s));
+  if (w.zps) HIP_TRY(hipMemsetAsync(w.zps, 0, w.xa_bytes, s));     // same shape as xa: the K pad of the next GEMM must read as zeros
   HIP_TRY(hipMemsetAsync(w.q, 0, w.qk_bytes, s));
   HIP_TRY(hipMemsetAsync(w.k, 0, w.qk_bytes, s));
   HIP_TRY(hipMemsetAsync(w.vt, 0, w.vt_bytes, s));
@@ -277,6 +307,67 @@ void run_last_block_cls(const BlockW& L, const BlockWs& w, int cells, const Attn
   }
 }
 
+// ---- the classifiers' blocks with LayerNorm folded into the GEMM behind it (gemm_epi.h).  Five launches + two finalisers per block
+// instead of seven + no LayerNorm pass over the rows: qkv and fc1 read the packed-split residual stream itself, the residual GEMMs
+// (proj, fc2) update it in place and leave the row statistics of the NEW rows behind.
+// Precondition: w.rs holds the statistics of z for norm1 (row_stats after the embedding, or the previous block's fc2).
+void resid_ps_and_stats(const GemmArgs& g, const BlockWs& w, int ldz_rows, int D, bool want_stats, hipStream_t s) {
+  launch_gemm_resid_ps(g, w.zps, ldz_rows, want_stats ? w.part : nullptr, s);
+  if (want_stats) launch_ln_finalize(w.part, gemm_resid_tiles(D), g.M, gemm_resid_bn(D), D, w.rs, s);
+}
+void run_block_fold(const BlockW& L, const BlockWs& w, int cells, const AttnGeom& a, hipStream_t s) {
+  const int D = a.D, Dp = round_up(D, 32), ld_x = 2 * Dp, ld_h = 2 * 4 * D, Mc = cells * a.T;
+  const float scale = 1.0f / sqrtf((float)a.hd);
+  {
+    ProfScope ps(P_QKV, s);
+    GemmArgs g{w.zps, ld_x, L.qkvw, ld_x, Mc, 3 * D, Dp, L.qkvb2};
+    launch_gemm_qkv_ln(g, w.rs, L.qkvc, w.q, w.k, w.vt, a, scale, s);
+  }
+  { ProfScope ps(P_ATTN, s); launch_attention(w.q, w.k, w.vt, w.xa, ld_x, cells, a, s); }
+  {
+    ProfScope ps(P_PROJ, s);
+    GemmArgs g{w.xa, ld_x, L.projw, ld_x, Mc, D, Dp, L.projb};
+    resid_ps_and_stats(g, w, ld_x, D, true, s);
+  }
+  {
+    ProfScope ps(P_FC1, s);
+    GemmArgs g{w.zps, ld_x, L.fc1w, ld_x, Mc, 4 * D, Dp, L.fc1b2, L.fc1wf};
+    launch_gemm_gelu_ln(g, w.rs, L.fc1c, w.h, ld_h, s);
+  }
+  {
+    ProfScope ps(P_FC2, s);
+    GemmArgs g{w.h, ld_h, L.fc2w, ld_h, Mc, D, 4 * D, L.fc2b};
+    resid_ps_and_stats(g, w, ld_x, D, true, s);
+  }
+}
+// last block, CLS rows only behind the attention (see run_last_block_cls): GEMM row m = cell, addressed with a row stride of T rows;
+// the statistics of norm2 are indexed by GEMM row too.  Nothing reads statistics after the last fc2 (the head normalises itself).
+void run_last_block_cls_fold(const BlockW& L, const BlockWs& w, int cells, const AttnGeom& a, hipStream_t s) {
+  const int D = a.D, Dp = round_up(D, 32), ld_x = 2 * Dp, ld_h = 2 * 4 * D, Mc = cells * a.T;
+  const float scale = 1.0f / sqrtf((float)a.hd);
+  {
+    ProfScope ps(P_QKV, s);
+    GemmArgs g{w.zps, ld_x, L.qkvw, ld_x, Mc, 3 * D, Dp, L.qkvb2};
+    launch_gemm_qkv_ln(g, w.rs, L.qkvc, w.q, w.k, w.vt, a, scale, s);
+  }
+  { ProfScope ps(P_ATTN, s); launch_attention(w.q, w.k, w.vt, w.xa, ld_x, cells, a, s, 1); }
+  {
+    ProfScope ps(P_PROJ, s);
+    GemmArgs g{w.xa, a.T * ld_x, L.projw, ld_x, cells, D, Dp, L.projb};
+    resid_ps_and_stats(g, w, a.T * ld_x, D, true, s);
+  }
+  {
+    ProfScope ps(P_FC1, s);
+    GemmArgs g{w.zps, a.T * ld_x, L.fc1w, ld_x, cells, 4 * D, Dp, L.fc1b2};
+    launch_gemm_gelu_ln(g, w.rs, L.fc1c, w.h, ld_h, s);
+  }
+  {
+    ProfScope ps(P_FC2, s);
+    GemmArgs g{w.h, ld_h, L.fc2w, ld_h, cells, D, 4 * D, L.fc2b};
+    resid_ps_and_stats(g, w, a.T * ld_x, D, false, s);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -285,7 +376,7 @@ int ribca_version(void) { return 100; }
 const char* ribca_last_error(void) { return g_err.c_str(); }
 int32_t ribca_gemm_padded_n(int32_t N) { return gemm_padded_n(N); }
 int ribca_set_gemm_variant(int32_t v) { gemm_set_variant(v); return 0; }
-int ribca_set_gemm_stamps(void* dev_buffer) { return gemm_set_stamp_buffer(dev_buffer); }
+int ribca_set_gemm_stamps(void* dev_buffer, int64_t capacity_blocks) { return gemm_set_stamp_buffer(dev_buffer, capacity_blocks); }
 
 int64_t ribca_vit_blob_len(int32_t D, int32_t C, int32_t K, int32_t depth) {
   const int64_t d = D;
@@ -308,6 +399,7 @@ int ribca_vit_create(const float* blob, int64_t blob_len, int32_t D, int32_t C, 
   m->hdv = round_up(m->hd, 16);
   m->Dp = round_up(D, 32);
   m->H4 = 4 * D;  // multiple of 32 because D % 8 == 0
+  m->fold = !(getenv("RIBCA_LN_FOLD") && atoi(getenv("RIBCA_LN_FOLD")) == 0);
   m->arena_bytes = layout(m, nullptr);
   hipError_t e = hipMalloc((void**)&m->arena, m->arena_bytes);
   if (e != hipSuccess) { delete m; return hip_fail(e, "hipMalloc(weights)"); }
@@ -317,7 +409,7 @@ int ribca_vit_create(const float* blob, int64_t blob_len, int32_t D, int32_t C, 
   r.copy(m->pos, (size_t)kTokens * D);
   r.copy(m->pe_w, (size_t)D * 16 * C);
   r.copy(m->pe_b, D);
-  for (auto& L : m->layers) r.block(L, D);
+  for (auto& L : m->layers) r.block(L, D, m->fold);
   r.copy(m->norm_w, D); r.copy(m->norm_b, D);
   r.copy(m->head_w, (size_t)K * D); r.copy(m->head_b, K);
   e = r.err != hipSuccess ? r.err : hipGetLastError();
@@ -340,7 +432,7 @@ double ribca_vit_flops_per_cell(const ribca_vit_t* m) {
 int64_t ribca_vit_workspace_bytes(const ribca_vit_t* m, int32_t chunk_cells) {
   if (!m || chunk_cells <= 0) return 0;
   Carver c(nullptr);
-  carve_blocks(c, chunk_cells, make_attn_geom(m->D, kHeads, kTokens));
+  carve_blocks(c, chunk_cells, make_attn_geom(m->D, kHeads, kTokens), m->fold);
   return (int64_t)c.off;
 }
 
@@ -353,7 +445,7 @@ int ribca_vit_forward(const ribca_vit_t* m, const float* patches, int32_t c_img,
   if (((uintptr_t)workspace & 255) != 0) return fail("ribca_vit_forward: workspace must be 256-byte aligned");
   const AttnGeom geom = make_attn_geom(m->D, kHeads, kTokens);
   Carver c((char*)workspace);
-  const BlockWs w = carve_blocks(c, chunk_cells, geom);
+  const BlockWs w = carve_blocks(c, chunk_cells, geom, m->fold);
   if ((int64_t)c.off > workspace_bytes) return fail("ribca_vit_forward: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const int D = m->D;
@@ -363,6 +455,25 @@ int ribca_vit_forward(const ribca_vit_t* m, const float* patches, int32_t c_img,
   }
   for (int c0 = 0; c0 < n_cells; c0 += chunk_cells) {
     const int bc = n_cells - c0 < chunk_cells ? n_cells - c0 : chunk_cells;
+    if (m->fold) {
+      const int ld_z = 2 * m->Dp;
+      {
+        ProfScope ps(P_EMBED, s);
+        launch_embed_ps(patches + (size_t)c0 * c_img * 1600, c_img, src_chan, m->C, m->pe_w, m->pe_b, m->pos, w.zps, ld_z, D, bc, s);
+      }
+      {
+        ProfScope ps(P_OTHER, s);
+        launch_cls_rows_ps(w.zps, ld_z, m->cls, m->pos, D, bc, kTokens, s);
+      }
+      { ProfScope ps(P_LN, s); launch_row_stats_ps(w.zps, ld_z, bc * kTokens, D, w.rs, s); }
+      for (size_t li = 0; li + 1 < m->layers.size(); ++li) run_block_fold(m->layers[li], w, bc, geom, s);
+      run_last_block_cls_fold(m->layers.back(), w, bc, geom, s);
+      {
+        ProfScope ps(P_HEAD, s);
+        launch_head_softmax_ps(w.zps, ld_z, m->norm_w, m->norm_b, m->head_w, m->head_b, probs + (size_t)c0 * m->K, D, m->K, bc, s);
+      }
+      continue;
+    }
     {
       ProfScope ps(P_EMBED, s);
       launch_embed_f32(patches + (size_t)c0 * c_img * 1600, c_img, src_chan, m->C, m->pe_w, m->pe_b, m->pos, w.z, D, D, bc, s);
@@ -699,6 +810,68 @@ int ribca_test_gemm(int32_t kind, const uint16_t* A, int32_t lda, const uint16_t
   else return fail("ribca_test_gemm: kind must be 0 or 1");
   HIP_TRY(hipGetLastError());
   return 0;
+}
+int ribca_test_fold_weight(const float* w, int32_t N, int32_t K, const float* gamma, const float* beta, const float* bias, uint16_t* out,
+                           int32_t Np, int32_t Kp, float* csum, float* bias2, void* stream) {
+  if (Np != gemm_padded_n(N)) return fail("ribca_test_fold_weight: Np must be ribca_gemm_padded_n(N)");
+  launch_pack_weight_fold(w, N, K, gamma, beta, bias, out, Np, Kp, csum, bias2, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int ribca_test_row_stats(const uint16_t* z_ps, int32_t ldz, int32_t M, int32_t D, float* rowstat, void* stream) {
+  launch_row_stats_ps(z_ps, ldz, M, D, reinterpret_cast<float2*>(rowstat), (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int32_t ribca_test_resid_tiles(int32_t N) { return gemm_resid_tiles(N); }
+int ribca_test_gemm_resid_ps(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
+                             const float* bias, uint16_t* z_ps, int32_t ldz, float* part, float* rowstat, void* stream) {
+  if (N % 8 != 0) return fail("ribca_test_gemm_resid_ps: N must be a multiple of 8");
+  if ((rowstat != nullptr) != (part != nullptr)) return fail("ribca_test_gemm_resid_ps: part and rowstat go together");
+  GemmArgs g{A, lda, W, ldw, M, N, Kp, bias};
+  launch_gemm_resid_ps(g, z_ps, ldz, reinterpret_cast<float2*>(part), (hipStream_t)stream);
+  if (rowstat) launch_ln_finalize(reinterpret_cast<const float2*>(part), gemm_resid_tiles(N), M, gemm_resid_bn(N), N, reinterpret_cast<float2*>(rowstat),
+                                  (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int ribca_test_gemm_fold(int32_t kind, const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
+                         const float* bias2, const float* csum, const float* rowstat, void* out, int32_t ldo, void* stream) {
+  if (kind != 1) return fail("ribca_test_gemm_fold: kind must be 1");
+  GemmArgs g{z_ps, lda, W, ldw, M, N, Kp, bias2};
+  launch_gemm_gelu_ln(g, reinterpret_cast<const float2*>(rowstat), csum, (uint16_t*)out, ldo, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int ribca_test_qkv_attention_fold(const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t cells, int32_t D, int32_t Kp,
+                                  const float* bias2, const float* csum, const float* rowstat, uint16_t* q, uint16_t* k, uint16_t* vt,
+                                  uint16_t* out, int32_t ldo, void* stream) {
+  const AttnGeom a = make_attn_geom(D, kHeads, kTokens);
+  GemmArgs g{z_ps, lda, W, ldw, cells * kTokens, 3 * D, Kp, bias2};
+  launch_gemm_qkv_ln(g, reinterpret_cast<const float2*>(rowstat), csum, q, k, vt, a, 1.0f / sqrtf((float)a.hd), (hipStream_t)stream);
+  launch_attention(q, k, vt, out, ldo, cells, a, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int ribca_test_gemm_duo_gelu(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
+                             const float* bias, const float* csum, const float* rowstat, uint16_t* wf_scratch, uint16_t* out, int32_t ldo,
+                             void* stream) {
+  if (M < 4096) return fail("ribca_test_gemm_duo_gelu: the forward uses this kernel for M >= 4096 only");
+  if (!wf_scratch) return fail("ribca_test_gemm_duo_gelu: wf_scratch is NULL");
+  if ((csum != nullptr) != (rowstat != nullptr)) return fail("ribca_test_gemm_duo_gelu: csum and rowstat go together");
+  launch_pack_wf(W, ldw, gemm_padded_n(N), Kp, wf_scratch, (hipStream_t)stream);
+  GemmArgs g{A, lda, W, ldw, M, N, Kp, bias, wf_scratch};
+  if (csum) launch_gemm_gelu_ln(g, reinterpret_cast<const float2*>(rowstat), csum, out, ldo, (hipStream_t)stream);
+  else launch_gemm_gelu(g, out, ldo, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int ribca_is_diag_build(void) {
+#ifdef RIBCA_DIAG
+  return 1;
+#else
+  return 0;
+#endif
 }
 int ribca_test_qkv_attention(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t cells, int32_t D, int32_t Kp,
                              const float* bias, uint16_t* q, uint16_t* k, uint16_t* vt, uint16_t* out, int32_t ldo, void* stream) {

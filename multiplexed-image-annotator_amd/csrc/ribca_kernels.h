@@ -9,7 +9,7 @@ namespace ribca {
 // ----- GEMM (gemm_split16.hip): C = A * W^T with A [M][2*Kp] and W [Np][2*Kp] in packed-split fp16 ---------------
 int gemm_pick_bn(int N);            // column-tile width used for an N-wide weight (64 / 96 / 128)
 int gemm_padded_n(int N);
-int gemm_set_stamp_buffer(void* dev_ptr);   // diagnostics (variant 12): 6 x uint64 per workgroup
+int gemm_set_stamp_buffer(void* dev_ptr, long long capacity_blocks);   // diagnostics (variant 12): 20 x uint64 per workgroup; larger grids do not stamp
 void gemm_set_variant(int v);      // 0 = production; 3/4/5/7/9 = A/B and timing-ablation forms of the same kernel           // N rounded up to that tile width (rows the packed weight must have)
 
 struct GemmArgs {
@@ -25,6 +25,14 @@ void launch_pack_wf(const uint16_t* W, int ldw, int Np, int Kp, uint16_t* WF, hi
 void launch_gemm_resid(const GemmArgs& g, float* z, int ldz, hipStream_t s);
 // out_ps[m][n] = gelu(acc + bias), packed-split          (mlp.fc1)
 void launch_gemm_gelu(const GemmArgs& g, uint16_t* out, int ldo, hipStream_t s);
+// ---- classifier blocks: LayerNorm folded into qkv / fc1, residual stream packed-split (gemm_epi.h: EpiResidPS, EpiGeluLn, EpiQKVLn)
+// z_ps[m][n] += acc + bias on the packed-split residual stream; part [gemm_resid_tiles(N)][M] receives (mean, centred sum of
+// squares) of every (row, column tile) of the NEW z, or nullptr
+void launch_gemm_resid_ps(const GemmArgs& g, uint16_t* z, int ldz, float2* part, hipStream_t s);
+int gemm_resid_tiles(int N);        // column tiles of an N-wide residual GEMM (= rows of `part`)
+int gemm_resid_bn(int N);           // their width
+// the same as launch_gemm_gelu / launch_gemm_qkv with x = rowstat[m].x * acc + (rowstat[m].y * csum[n] + bias[n])
+void launch_gemm_gelu_ln(const GemmArgs& g, const float2* rowstat, const float* csum, uint16_t* out, int ldo, hipStream_t s);
 // geometry of one attention problem: D = H*hd features, T tokens per cell; Q/K rows padded to TP = 16*NT tokens and STORED with
 // hdq = round8(hd) dims (compact: whole PS groups only); the MFMA K dimension is hdp = round32(hd), the groups beyond hdq are
 // zero registers, never memory.  V^T rows = hdv head dims x KP keys (KP = 32*ceil(NT/2)); rows >= hd are never read.
@@ -36,6 +44,8 @@ bool attention_supported(const AttnGeom& a);
 // qkv: scatter into per-head attention operands (Q pre-scaled by hd^-0.5, V transposed + key-permuted)
 void launch_gemm_qkv(const GemmArgs& g, uint16_t* q, uint16_t* k, uint16_t* vt, const AttnGeom& a, float scale, hipStream_t s);
 // fp32 output through a per-cell row map (imputer embeddings / predictions), see EpiRowMap
+void launch_gemm_qkv_ln(const GemmArgs& g, const float2* rowstat, const float* csum, uint16_t* q, uint16_t* k, uint16_t* vt, const AttnGeom& a,
+                        float scale, hipStream_t s);
 void launch_gemm_rowmap(const GemmArgs& g, float* out, int ldo, const float* add, int ldadd, const int* slot, const int* addrow, int R,
                         int dst_per_cell, hipStream_t s);
 
@@ -61,6 +71,19 @@ void launch_fill_rows(float* z, int ldz, const float* a, const float* table, int
 void launch_head_softmax(const float* z, int ldz, const float* gamma, const float* beta, const float* hw, const float* hb,
                          float* probs, int D, int K, int cells, hipStream_t s);
 void launch_pack_weight(const float* w, int N, int K, uint16_t* out, int Np, int Kp, hipStream_t s);
+// packed-split residual stream of the classifiers
+void launch_embed_ps(const float* patches, int c_img, const int* src_chan, int C, const float* w, const float* bias, const float* pos,
+                     uint16_t* z, int ldz, int D, int cells, hipStream_t s);
+void launch_cls_rows_ps(uint16_t* z, int ldz, const float* cls, const float* pos, int D, int cells, int tokens_per_cell, hipStream_t s);
+void launch_head_softmax_ps(const uint16_t* z, int ldz, const float* gamma, const float* beta, const float* hw, const float* hb,
+                            float* probs, int D, int K, int cells, hipStream_t s);
+// rowstat[m] = (rstd, -mean * rstd) of row m of a packed-split z (LayerNorm eps 1e-6)
+void launch_row_stats_ps(const uint16_t* z, int ldz, int M, int D, float2* rowstat, hipStream_t s);
+// the same from the residual epilogue's per-tile pairs: part [T][M], tiles bn wide over N columns
+void launch_ln_finalize(const float2* part, int T, int M, int bn, int N, float2* rowstat, hipStream_t s);
+// gamma o W packed-split + csum[n] + bias2[n] = bias[n] + W[n] . beta   (LayerNorm folded into the Linear)
+void launch_pack_weight_fold(const float* w, int N, int K, const float* gamma, const float* beta, const float* bias, uint16_t* out, int Np,
+                             int Kp, float* csum, float* bias2, hipStream_t s);
 
 // ----- pre-processing (preprocess.hip) -----------------------------------------------------------------------
 void launch_mask_max(const int32_t* mask, long long n, int32_t* out_max, hipStream_t s);

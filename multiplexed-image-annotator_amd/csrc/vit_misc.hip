@@ -63,9 +63,11 @@ void launch_layernorm_ps(const float* z, int ldz, const float* gamma, const floa
 // cancellation of O(1) terms, and LayerNorm rescales that row to unit variance, so a 2^-16-relative product error
 // (split 16-bit operands) is amplified ~50x there.  fp32 FMA keeps this stage at the reference's own precision.
 // Classic 64x64 LDS-tiled SGEMM, one input channel (16 taps) per K step, im2col done on the fly from the fp32 patches.
+// PS = true: z is the packed-split residual stream of the classifiers (uint16 [rows][ldz], fp16 hi + lo), else fp32.
+template <bool PS>
 __global__ __launch_bounds__(256) void embed_f32_kernel(const float* __restrict__ patches, int c_img, const int* __restrict__ src_chan,
                                                         int C, const float* __restrict__ w /*[D][C*16]*/, const float* __restrict__ bias,
-                                                        const float* __restrict__ pos, float* __restrict__ z, int ldz, int D, int M) {
+                                                        const float* __restrict__ pos, void* __restrict__ zv, int ldz, int D, int M) {
   __shared__ float As[16][64 + 4];  // [k][row]
   __shared__ float Ws[16][64 + 4];  // [k][col]
   const int tid = threadIdx.x;
@@ -118,7 +120,13 @@ __global__ __launch_bounds__(256) void embed_f32_kernel(const float* __restrict_
     const float4 pe = *reinterpret_cast<const float4*>(pos + (size_t)(1 + tt) * D + n);
     float4 o;
     o.x = acc[i][0] + bv.x + pe.x; o.y = acc[i][1] + bv.y + pe.y; o.z = acc[i][2] + bv.z + pe.z; o.w = acc[i][3] + bv.w + pe.w;
-    *reinterpret_cast<float4*>(z + ((size_t)cl * kTokens + 1 + tt) * ldz + n) = o;
+    const size_t zrow = ((size_t)cl * kTokens + 1 + tt) * ldz;
+    if constexpr (PS) {
+      const float v4[4] = {o.x, o.y, o.z, o.w};
+      ps_store4(static_cast<uint16_t*>(zv) + zrow, n, v4);
+    } else {
+      *reinterpret_cast<float4*>(static_cast<float*>(zv) + zrow + n) = o;
+    }
   }
 }
 
@@ -126,8 +134,100 @@ void launch_embed_f32(const float* patches, int c_img, const int* src_chan, int 
                       float* z, int ldz, int D, int cells, hipStream_t s) {
   const int M = cells * 100;
   if (M <= 0) return;
-  hipLaunchKernelGGL(embed_f32_kernel, dim3((M + 63) / 64, (D + 63) / 64), dim3(256), 0, s, patches, c_img, src_chan, C, w, bias, pos, z,
-                     ldz, D, M);
+  hipLaunchKernelGGL(embed_f32_kernel<false>, dim3((M + 63) / 64, (D + 63) / 64), dim3(256), 0, s, patches, c_img, src_chan, C, w, bias, pos,
+                     (void*)z, ldz, D, M);
+}
+void launch_embed_ps(const float* patches, int c_img, const int* src_chan, int C, const float* w, const float* bias, const float* pos,
+                     uint16_t* z, int ldz, int D, int cells, hipStream_t s) {
+  const int M = cells * 100;
+  if (M <= 0) return;
+  hipLaunchKernelGGL(embed_f32_kernel<true>, dim3((M + 63) / 64, (D + 63) / 64), dim3(256), 0, s, patches, c_img, src_chan, C, w, bias, pos,
+                     (void*)z, ldz, D, M);
+}
+
+// packed-split residual stream: CLS rows (model.py:49-51), one thread per 4 columns
+__global__ void cls_rows_ps_kernel(uint16_t* __restrict__ z, int ldz, const float* __restrict__ cls, const float* __restrict__ pos, int D,
+                                   int cells, int T) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int dq = D >> 2;
+  if (idx >= cells * dq) return;
+  const int cell = idx / dq, d = 4 * (idx - cell * dq);
+  const float4 a = *reinterpret_cast<const float4*>(cls + d), b = *reinterpret_cast<const float4*>(pos + d);
+  const float v4[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+  ps_store4(z + (size_t)cell * T * ldz, d, v4);
+}
+void launch_cls_rows_ps(uint16_t* z, int ldz, const float* cls, const float* pos, int D, int cells, int tokens_per_cell, hipStream_t s) {
+  if (cells <= 0) return;
+  hipLaunchKernelGGL(cls_rows_ps_kernel, dim3((cells * (D >> 2) + 255) / 256), dim3(256), 0, s, z, ldz, cls, pos, D, cells, tokens_per_cell);
+}
+
+// Row statistics of a packed-split residual stream, as the folded-LayerNorm GEMM epilogues read them: rowstat[m] = (rstd, -mean rstd),
+// two-pass mean / biased variance over hi + lo (exact in fp32), eps 1e-6.  One wave per row, D <= 1024.  Used once per forward chunk,
+// behind the patch embedding; every later LayerNorm's statistics come out of the residual GEMM epilogues (gemm_split16.hip).
+__global__ __launch_bounds__(256) void row_stats_ps_kernel(const uint16_t* __restrict__ z, int ldz, int M, int D, float2* __restrict__ rowstat) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int ng = D >> 3;
+  const uint16_t* zr = z + (size_t)row * ldz;
+  float x[2][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int g = lane + 64 * i;
+    if (g < ng) {
+      const uint4 hi = *reinterpret_cast<const uint4*>(zr + 16 * g), lo = *reinterpret_cast<const uint4*>(zr + 16 * g + 8);
+      const uint32_t hw[4] = {hi.x, hi.y, hi.z, hi.w}, lw[4] = {lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x2 h = unpack_f16(hw[j]), l = unpack_f16(lw[j]);
+        x[i][2 * j] = h[0] + l[0]; x[i][2 * j + 1] = h[1] + l[1];
+      }
+      sum += ((x[i][0] + x[i][1]) + (x[i][2] + x[i][3])) + ((x[i][4] + x[i][5]) + (x[i][6] + x[i][7]));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[i][j] = 0.f;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (lane + 64 * i < ng) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = x[i][j] - mean; sq += d * d; }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + kLnEps);
+  if (lane == 0) rowstat[row] = float2{rstd, -mean * rstd};
+}
+void launch_row_stats_ps(const uint16_t* z, int ldz, int M, int D, float2* rowstat, hipStream_t s) {
+  if (M <= 0) return;
+  hipLaunchKernelGGL(row_stats_ps_kernel, dim3((M + 3) / 4), dim3(256), 0, s, z, ldz, M, D, rowstat);
+}
+
+// rowstat[m] = (rstd, -mean rstd) from the per-column-tile (mean, centred sum of squares) pairs the residual epilogue wrote:
+// tiles are combined in tile order with Chan's update, so the result does not depend on which workgroup finished first.
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restrict__ part, int T, int M, int bn, int N, float2* __restrict__ rowstat) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  float2 p = part[m];
+  float mean = p.x, m2 = p.y, cnt = (float)(N < bn ? N : bn);
+  for (int t = 1; t < T; ++t) {
+    const int rem = N - t * bn;
+    const float nb = (float)(rem < bn ? rem : bn);
+    p = part[(size_t)t * M + m];
+    const float delta = p.x - mean, tot = cnt + nb;
+    mean += delta * (nb / tot);
+    m2 += p.y + delta * delta * (cnt * nb / tot);
+    cnt = tot;
+  }
+  const float rstd = 1.0f / sqrtf(m2 / (float)N + kLnEps);
+  rowstat[m] = float2{rstd, -mean * rstd};
+}
+void launch_ln_finalize(const float2* part, int T, int M, int bn, int N, float2* rowstat, hipStream_t s) {
+  if (M <= 0) return;
+  hipLaunchKernelGGL(ln_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, s, part, T, M, bn, N, rowstat);
 }
 
 // z[cell*T + 0][:] = cls_token + pos_embed[0]   (model.py:49-51; markerImputer.py:197-199)
@@ -233,20 +333,26 @@ void launch_fill_rows(float* z, int ldz, const float* a, const float* table, int
 }
 
 // final LayerNorm of the CLS row -> Linear(D, K) -> softmax(dim=1), all fp32.  One wave per cell, K <= 16.
-__global__ __launch_bounds__(256) void head_softmax_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ gamma,
+template <bool PS>
+__global__ __launch_bounds__(256) void head_softmax_kernel(const void* __restrict__ zv, int ldz, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ hw,
                                                            const float* __restrict__ hb, float* __restrict__ probs, int D, int K,
                                                            int cells) {
   const int lane = threadIdx.x & 63;
   const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (cell >= cells) return;
-  const float* zr = z + (size_t)cell * kTokens * ldz;
   float x[12];
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
     const int d = lane + 64 * i;
-    x[i] = d < D ? zr[d] : 0.f;
+    if constexpr (PS) {
+      const uint16_t* zr = static_cast<const uint16_t*>(zv) + (size_t)cell * kTokens * ldz;
+      x[i] = d < D ? f16_to_f32(zr[ps_off(d)]) + f16_to_f32(zr[ps_off(d) + 8]) : 0.f;
+    } else {
+      const float* zr = static_cast<const float*>(zv) + (size_t)cell * kTokens * ldz;
+      x[i] = d < D ? zr[d] : 0.f;
+    }
     sum += x[i];
   }
   const float mean = wave_sum(sum) / (float)D;
@@ -284,7 +390,12 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(const float* __restri
 void launch_head_softmax(const float* z, int ldz, const float* gamma, const float* beta, const float* hw, const float* hb, float* probs,
                          int D, int K, int cells, hipStream_t s) {
   if (cells <= 0) return;
-  hipLaunchKernelGGL(head_softmax_kernel, dim3((cells + 3) / 4), dim3(256), 0, s, z, ldz, gamma, beta, hw, hb, probs, D, K, cells);
+  hipLaunchKernelGGL(head_softmax_kernel<false>, dim3((cells + 3) / 4), dim3(256), 0, s, (const void*)z, ldz, gamma, beta, hw, hb, probs, D, K, cells);
+}
+void launch_head_softmax_ps(const uint16_t* z, int ldz, const float* gamma, const float* beta, const float* hw, const float* hb, float* probs,
+                            int D, int K, int cells, hipStream_t s) {
+  if (cells <= 0) return;
+  hipLaunchKernelGGL(head_softmax_kernel<true>, dim3((cells + 3) / 4), dim3(256), 0, s, (const void*)z, ldz, gamma, beta, hw, hb, probs, D, K, cells);
 }
 
 // fp32 nn.Linear weight [N][K] -> packed-split fp16 [Np][2*Kp], zero padded.  One thread per 4 consecutive k.
@@ -304,6 +415,48 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int N, int K, ui
 void launch_pack_weight(const float* w, int N, int K, uint16_t* out, int Np, int Kp, hipStream_t s) {
   const long long total = (long long)Np * (Kp >> 2);
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, N, K, out, Np, Kp);
+}
+
+
+// LayerNorm folded into the Linear that follows it (gemm_epi.h, EpiGeluT / EpiQKVT with FOLD): packs gamma o W as the packed-split
+// weight and emits, per output row n, csum[n] = sum_k (hi + lo of the PACKED element) -- what the MFMAs will actually multiply the
+// row mean with -- and bias2[n] = bias[n] + sum_k beta[k] W[n][k]; both sums in fp64.  One wave per output row.
+__global__ __launch_bounds__(256) void pack_weight_fold_kernel(const float* __restrict__ w, int N, int K, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const float* __restrict__ bias,
+                                                               uint16_t* __restrict__ out, int Np, int Kp, float* __restrict__ csum,
+                                                               float* __restrict__ bias2) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= Np) return;
+  double cq = 0.0, bb = 0.0;
+  for (int q = lane; q < (Kp >> 2); q += 64) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = 4 * q + i;
+        if (k < K) {
+          const float wv = w[(size_t)n * K + k];
+          v[i] = gamma[k] * wv;
+          bb += (double)beta[k] * (double)wv;
+        }
+      }
+    }
+    uint2 hi, lo;
+    split4(v, hi, lo);
+    uint16_t* p = out + (size_t)n * (2 * Kp) + ps_off(4 * q);
+    *reinterpret_cast<uint2*>(p) = hi;
+    *reinterpret_cast<uint2*>(p + 8) = lo;
+    const f32x2 h01 = unpack_f16(hi.x), h23 = unpack_f16(hi.y), l01 = unpack_f16(lo.x), l23 = unpack_f16(lo.y);
+    cq += ((double)h01[0] + (double)l01[0]) + ((double)h01[1] + (double)l01[1]) + ((double)h23[0] + (double)l23[0]) + ((double)h23[1] + (double)l23[1]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { cq += __shfl_xor(cq, o, 64); bb += __shfl_xor(bb, o, 64); }
+  if (lane == 0 && n < N) { csum[n] = (float)cq; bias2[n] = (float)((double)bias[n] + bb); }
+}
+void launch_pack_weight_fold(const float* w, int N, int K, const float* gamma, const float* beta, const float* bias, uint16_t* out, int Np,
+                             int Kp, float* csum, float* bias2, hipStream_t s) {
+  hipLaunchKernelGGL(pack_weight_fold_kernel, dim3((Np + 3) / 4), dim3(256), 0, s, w, N, K, gamma, beta, bias, out, Np, Kp, csum, bias2);
 }
 
 }  // namespace ribca

@@ -127,18 +127,199 @@ def test_gemm_gelu(dev, m, n, k):
     assert err < 2e-5, err
 
 
-def test_gemm_duo_variant_bit_identical(dev):
-    """gemm_duo.hip (two workgroups per CU, weights in fragment order straight to registers; A/B variant 40 and the
-    RIBCA_GEMM_DUO=1 path of mlp.fc1) accumulates every output element in the production kernel's order: its residual, GELU and
-    QKV outputs must equal variant 0's bit for bit -- ragged M, every column-tile width, the 96-wide 2 x 2 wave layout included."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("check_gemm_variant", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                                                       "tools", "check_gemm_variant.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    shapes = [(1, 288, 288), (300, 288, 1152), (257, 144, 144), (130, 432, 144), (77, 576, 2304), (129, 384, 384), (64, 64, 64),
-              (1000, 2304, 576), (11100, 576, 576), (16500, 1536, 384)]
-    assert mod.compare([40], shapes=shapes, qkv_cases=((144, 3), (288, 130), (576, 31)), verbose=False) == 0
+def _ln_case(m, d, seed, dev, mean=0.5, std=3.0, row_scale=False):
+    """rows of a packed-split residual stream with a chosen mean / spread, their exact (fp64) decode, LayerNorm parameters"""
+    z = rnd((m, d), seed, dev, std) + mean
+    if row_scale:      # spread the row scales over three decades (background tokens of a real patch sit at |z| ~ 0.02)
+        z = z * torch.logspace(-2, 1, m, device=dev, dtype=torch.float32)[:, None]
+    dp = (d + 31) // 32 * 32
+    z_ps = ps_encode(z, dp)
+    zq = ps_decode(z_ps, d)
+    g = rnd((d,), seed + 1, dev, 0.1) + 1.0
+    b = rnd((d,), seed + 2, dev, 0.1)
+    return z_ps, zq, g, b, dp
+
+
+def _row_stats(z_ps, dp, m, d, dev):
+    from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
+    rs = torch.zeros((m, 2), dtype=torch.float32, device=dev)
+    check(lib().ribca_test_row_stats(ptr(z_ps), 2 * dp, m, d, ptr(rs), stream_ptr()), "row_stats")
+    return rs
+
+
+def _fold(w, g, b, bias, kp, dev):
+    from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
+    n, k = w.shape
+    npad = lib().ribca_gemm_padded_n(n)
+    w_ps = torch.zeros((npad, 2 * kp), dtype=torch.int16, device=dev)
+    csum = torch.zeros(n, dtype=torch.float32, device=dev)
+    bias2 = torch.zeros(n, dtype=torch.float32, device=dev)
+    check(lib().ribca_test_fold_weight(ptr(w), n, k, ptr(g), ptr(b), ptr(bias), ptr(w_ps), npad, kp, ptr(csum), ptr(bias2), stream_ptr()), "fold")
+    return w_ps, csum, bias2
+
+
+@pytest.mark.parametrize("n,k", [(432, 144), (1152, 288), (1536, 384), (2304, 576)])
+def test_fold_weight(dev, n, k):
+    """gamma o W packed, csum = row sums of the PACKED values (what the MFMAs multiply the row mean with), bias2 = b + W beta"""
+    kp = (k + 31) // 32 * 32
+    w = rnd((n, k), 40, dev, 1.0 / np.sqrt(k))
+    g = rnd((k,), 41, dev, 0.1) + 1.0
+    b = rnd((k,), 42, dev, 0.1)
+    bias = rnd((n,), 43, dev, 0.1)
+    w_ps, csum, bias2 = _fold(w, g, b, bias, kp, dev)
+    wq = ps_decode(w_ps, kp)
+    ref = (g * w).double()                                           # the kernel rounds gamma * w to fp32 once, then splits
+    assert torch.all((wq[:n, :k] - ref).abs() <= ref.abs() * 2.0 ** -23 + 2.0 ** -25)
+    assert torch.all(wq[n:] == 0) and torch.all(wq[:, k:] == 0)
+    # fp64 sums rounded once to fp32
+    assert torch.all((csum.double() - wq[:n].sum(1)).abs() <= wq[:n].sum(1).abs() * 2.0 ** -23 + 1e-12)
+    ref_b = bias.double() + w.double() @ b.double()
+    assert torch.all((bias2.double() - ref_b).abs() <= ref_b.abs() * 2.0 ** -23 + 1e-9)
+
+
+@pytest.mark.parametrize("d", [144, 288, 384, 576, 768])
+@pytest.mark.parametrize("mean,std", [(0.5, 3.0), (30.0, 1.0), (-300.0, 2.0)])
+def test_row_stats(dev, d, mean, std):
+    m = 203
+    z_ps, zq, _, _, dp = _ln_case(m, d, 44, dev, mean, std, row_scale=(mean == 0.5))
+    rs = _row_stats(z_ps, dp, m, d, dev).double()
+    mu = zq.mean(1)
+    rstd = 1.0 / torch.sqrt(zq.var(1, unbiased=False) + 1e-6)
+    # two-pass fp32 statistics of exactly representable inputs: the mean carries 2^-24 |mu| (relative to the spread: x |mu| / sigma),
+    # the centred squares then see that error twice
+    amp = 1.0 + (mu.abs() * rstd)
+    assert torch.all((rs[:, 0] - rstd).abs() <= rstd * 4e-7 * amp), ((rs[:, 0] - rstd).abs() / rstd).max()
+    assert torch.all((rs[:, 1] + mu * rstd).abs() <= 4e-7 * amp * (1.0 + (mu * rstd).abs())), (rs[:, 1] + mu * rstd).abs().max()
+
+
+RESID_PS_SHAPES = [(1, 288, 288), (300, 288, 1152), (257, 144, 144), (130, 144, 576), (77, 576, 2304), (129, 384, 384), (515, 768, 768),
+                   (11100, 576, 576), (22100, 288, 288), (16500, 384, 1536), (40000, 144, 144)]
+
+
+@pytest.mark.parametrize("m,n,k", RESID_PS_SHAPES)
+@pytest.mark.parametrize("mean", [0.3, 40.0])
+def test_gemm_resid_ps(dev, m, n, k, mean):
+    """proj / fc2 of the classifiers: z (packed-split) += A W^T + b in place, plus (rstd, -mean rstd) of the NEW rows out of the
+    epilogue's per-tile pairs (2 ... 6 column tiles), also for rows whose mean dwarfs their spread"""
+    from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
+    kp = (k + 31) // 32 * 32
+    a = rnd((m, k), 5, dev)
+    w = rnd((n, k), 6, dev, 1.0 / np.sqrt(k))
+    bias = rnd((n,), 7, dev, 0.1)
+    npd = (n + 31) // 32 * 32
+    z0 = rnd((m, n), 8, dev) + mean
+    a_ps = ps_encode(a, kp)
+    w_ps = ps_encode(w, kp, lib().ribca_gemm_padded_n(n))
+    z_ps = ps_encode(z0, npd)
+    z0q = ps_decode(z_ps, n)
+    aq, wq = ps_decode(a_ps, k), ps_decode(w_ps, k)[:n]
+    tiles = lib().ribca_test_resid_tiles(n)
+    part = torch.zeros((tiles, m, 2), dtype=torch.float32, device=dev)
+    rs = torch.zeros((m, 2), dtype=torch.float32, device=dev)
+    check(lib().ribca_test_gemm_resid_ps(ptr(a_ps), 2 * kp, ptr(w_ps), 2 * kp, m, n, kp, ptr(bias), ptr(z_ps), 2 * npd, ptr(part), ptr(rs),
+                                         stream_ptr()), "resid_ps")
+    ref = z0q + aq @ wq.t() + bias.double()
+    got = ps_decode(z_ps, n)
+    err = ((got - ref).abs() / (1.0 + ref.abs())).max().item()
+    note_err(f"gemm_resid_ps {m}x{n}x{k} mean {mean}", err)
+    # as test_gemm_residual, plus the re-split of the new row (2^-23 relative)
+    assert err < 2e-5, err
+    assert torch.all(ps_decode(z_ps, npd)[:, n:] == 0)
+    # the statistics describe the rows that were STORED
+    mu = got.mean(1)
+    rstd = 1.0 / torch.sqrt(got.var(1, unbiased=False) + 1e-6)
+    amp = 1.0 + mu.abs() * rstd
+    e1 = ((rs[:, 0].double() - rstd).abs() / (rstd * amp)).max().item()
+    e2 = ((rs[:, 1].double() + mu * rstd).abs() / (amp * (1.0 + (mu * rstd).abs()))).max().item()
+    note_err(f"resid_ps stats {m}x{n}x{k} mean {mean}", max(e1, e2))
+    assert e1 < 1e-6 and e2 < 1e-6, (e1, e2)
+
+
+@pytest.mark.parametrize("m,d", [(150, 288), (101, 144), (260, 576), (7001, 288), (5000, 576), (20000, 288), (12000, 384), (9000, 144)])
+@pytest.mark.parametrize("mean,std", [(0.5, 3.0), (30.0, 1.0)])
+def test_gemm_fold_gelu(dev, m, d, mean, std):
+    """norm2 -> mlp.fc1 folded: gelu(LN(z) W^T + b) from the packed-split z, the folded weight and the row statistics; the
+    two-workgroups-per-CU kernel the forward uses for M >= 4096 must give the same bits as the one-workgroup kernel"""
+    from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
+    n = 4 * d
+    z_ps, zq, g, b, dp = _ln_case(m, d, 50, dev, mean, std, row_scale=(mean == 0.5))
+    w = rnd((n, d), 53, dev, 2.0 / np.sqrt(d))
+    bias = rnd((n,), 54, dev, 0.1)
+    w_ps, csum, bias2 = _fold(w, g, b, bias, dp, dev)
+    rs = _row_stats(z_ps, dp, m, d, dev)
+    out = torch.zeros((m, 2 * n), dtype=torch.int16, device=dev)
+    check(lib().ribca_test_gemm_fold(1, ptr(z_ps), 2 * dp, ptr(w_ps), 2 * dp, m, n, dp, ptr(bias2), ptr(csum), ptr(rs), ptr(out), 2 * n,
+                                     stream_ptr()), "gemm_fold")
+    ln = torch.nn.functional.layer_norm(zq, (d,), g.double(), b.double(), 1e-6)
+    ref = torch.nn.functional.gelu(ln @ w.double().t() + bias.double())
+    err = (ps_decode(out, n) - ref).abs().max().item()
+    note_err(f"gemm_fold_gelu {m}x{n}x{d} mean {mean}", err)
+    # test_gemm_gelu's bound (2e-5) times the amplification of the cancellation rstd (acc - mean c): products carry 2^-24 relative
+    # to |z| ~ |mean|, the LayerNorm output lives on the scale sigma
+    assert err < 2e-5 * (1.0 + abs(mean) / std), err
+    if m >= 4096:
+        wf = torch.zeros_like(w_ps)
+        out2 = torch.zeros_like(out)
+        check(lib().ribca_test_gemm_duo_gelu(ptr(z_ps), 2 * dp, ptr(w_ps), 2 * dp, m, n, dp, ptr(bias2), ptr(csum), ptr(rs), ptr(wf), ptr(out2),
+                                             2 * n, stream_ptr()), "duo fold")
+        assert torch.equal(out, out2)
+
+
+def test_gemm_duo_bit_identical(dev):
+    """gemm_duo.hip (two workgroups per CU, weights in fragment order straight to registers; the forward's mlp.fc1 kernel for
+    M >= 4096) accumulates every output element in the one-workgroup kernel's order: GELU outputs must be equal bit for bit,
+    ragged M and every column-tile width included.  (The residual / QKV forms of that kernel are diagnostic-library variants:
+    tools/check_gemm_variant.py under RIBCA_DIAG=1.)"""
+    from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
+    for m, n, k in [(4096, 576, 144), (5000, 1152, 288), (7001, 1536, 384), (11100, 2304, 576), (4100, 64, 64), (6000, 192, 96)]:
+        kp = (k + 31) // 32 * 32
+        a = rnd((m, k), 9, dev)
+        w = rnd((n, k), 10, dev, 2.0 / np.sqrt(k))
+        bias = rnd((n,), 11, dev, 0.1)
+        a_ps = ps_encode(a, kp)
+        w_ps = ps_encode(w, kp, lib().ribca_gemm_padded_n(n))
+        o1 = torch.zeros((m, 2 * n), dtype=torch.int16, device=dev)
+        o2 = torch.zeros_like(o1)
+        wf = torch.zeros_like(w_ps)
+        check(lib().ribca_test_gemm(1, ptr(a_ps), 2 * kp, ptr(w_ps), 2 * kp, m, n, kp, ptr(bias), ptr(o1), 2 * n, stream_ptr()), "gemm")
+        check(lib().ribca_test_gemm_duo_gelu(ptr(a_ps), 2 * kp, ptr(w_ps), 2 * kp, m, n, kp, ptr(bias), None, None, ptr(wf), ptr(o2), 2 * n,
+                                             stream_ptr()), "duo")
+        assert torch.equal(o1, o2), (m, n, k)
+
+
+@pytest.mark.parametrize("d,cells", [(144, 3), (288, 3), (384, 3), (576, 3), (288, 130), (384, 70), (576, 131)])
+@pytest.mark.parametrize("mean,std", [(0.5, 1.0), (30.0, 1.0)])
+def test_qkv_attention_fold(dev, d, cells, mean, std):
+    """norm1 -> attn.qkv folded + attention: against LayerNorm + qkv + softmax attention in fp64"""
+    from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
+    heads, ntok = 12, 101
+    hd = d // heads
+    hdp, hdv = (hd + 7) // 8 * 8, (hd + 15) // 16 * 16
+    m = cells * ntok
+    z_ps, zq, g, b, dp = _ln_case(m, d, 60, dev, mean, std)
+    w = rnd((3 * d, d), 63, dev, 1.0 / np.sqrt(d))
+    bias = rnd((3 * d,), 64, dev, 0.1)
+    w_ps, csum, bias2 = _fold(w, g, b, bias, dp, dev)
+    rs = _row_stats(z_ps, dp, m, d, dev)
+    q = torch.zeros((cells, heads, 112, 2 * hdp), dtype=torch.int16, device=dev)
+    k = torch.zeros_like(q)
+    vt = torch.zeros((cells, heads, hdv, 256), dtype=torch.int16, device=dev)
+    out = torch.zeros((m, 2 * dp), dtype=torch.int16, device=dev)
+    check(lib().ribca_test_qkv_attention_fold(ptr(z_ps), 2 * dp, ptr(w_ps), 2 * dp, cells, d, dp, ptr(bias2), ptr(csum), ptr(rs), ptr(q), ptr(k),
+                                              ptr(vt), ptr(out), 2 * dp, stream_ptr()), "qkv fold")
+    ln = torch.nn.functional.layer_norm(zq, (d,), g.double(), b.double(), 1e-6)
+    qkv = (ln @ w.double().t() + bias.double()).reshape(cells, ntok, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    qq, kk, vv = qkv[0], qkv[1], qkv[2]
+    qd = ps_decode(q.reshape(-1, 2 * hdp), hdp).reshape(cells, heads, 112, hdp)
+    kd = ps_decode(k.reshape(-1, 2 * hdp), hdp).reshape(cells, heads, 112, hdp)
+    amp = 1.0 + abs(mean) / std
+    assert torch.all((qd[:, :, :ntok, :hd] - qq * hd ** -0.5).abs() <= (qq.abs() + 1.0) * 1e-5 * amp)
+    assert torch.all((kd[:, :, :ntok, :hd] - kk).abs() <= (kk.abs() + 1.0) * 1e-5 * amp)
+    att = torch.softmax(qq @ kk.transpose(-1, -2) * hd ** -0.5, dim=-1) @ vv
+    ref = att.permute(0, 2, 1, 3).reshape(m, d)
+    err = (ps_decode(out, d) - ref).abs().max().item()
+    note_err(f"qkv_attention_fold d={d} cells={cells} mean {mean}", err)
+    assert err < 4e-5 * amp, err
 
 
 @pytest.mark.parametrize("d,cells", [(144, 3), (288, 3), (384, 3), (576, 3), (288, 130), (384, 130), (576, 131), (288, 400)])
@@ -209,6 +390,48 @@ def test_vit_forward_vs_oracle(dev, name):
     assert torch.equal(got.argmax(1), ref.argmax(1))
     got2 = model.predict_proba(x.to(dev), list(range(c)), chunk_cells=64).cpu()
     assert torch.equal(got, got2)     # chunking does not change results
+
+
+def _large_mean_state_dict(name, c0=125.0, c1=30.0):
+    """adversarial statistics for the folded LayerNorm: a shared offset on every residual row (pos_embed + c0, and + c1 from every
+    attn.proj / mlp.fc2 bias so that it keeps pace with the growing spread): |row mean| / row std >= 30 at the input of every block"""
+    sd = synth.make_vit_state_dict(name, synth.SEED_BASE + 7)
+    sd["pos_embed"] = sd["pos_embed"] + c0
+    for i in range(12):
+        sd[f"blocks.{i}.attn.proj.bias"] = sd[f"blocks.{i}.attn.proj.bias"] + c1
+        sd[f"blocks.{i}.mlp.fc2.bias"] = sd[f"blocks.{i}.mlp.fc2.bias"] + c1
+    return sd
+
+
+@pytest.mark.parametrize("name", ["nerve", "immune_base", "immune_full"])
+def test_vit_forward_large_row_mean(dev, name):
+    """the LayerNorm fold computes rstd (z (gamma o W)^T - mean c), whose cancellation grows with |mean| / std of
+    the residual rows.  Weights with a large shared offset put every row at |mean| / std = 30 ... 65 (checked below on the fp64
+    oracle); the fp32 reference itself then sits 4e-5 ... 2.4e-4 from the fp64 forward (x - mean in fp32 loses log2(|mean| / std)
+    bits).  Bound: the end-to-end tolerance of the golden / config tests (E2E_TOL = 2e-4 in test_gpu_e2e.py) against the fp64
+    forward, or 3x the fp32 reference's own distance from it where that is larger; always inside the north-star 1e-3; labels identical."""
+    from oracle import ref_vit
+    ops = _ops()
+    d, c, k = synth.VIT_CONFIGS[name]
+    sd = _large_mean_state_dict(name)
+    n = 24
+    u = synth.uniform(synth.stream_key(5, "vitx/" + name), n * c * 1600).reshape(n, c, 40, 40).to(torch.float32)
+    x = torch.where(u * 2 - 1 > 0.1, u * 2 - 1, torch.full_like(u, -1.0))
+    sd64 = {key: v.double() for key, v in sd.items()}
+    with torch.no_grad():
+        z = torch.cat((sd64["cls_token"].expand(n, -1, -1), ref_vit.patch_embed(sd64, x.double())), dim=1) + sd64["pos_embed"]
+        for i in range(12):
+            ratio = z.mean(-1).abs() / z.std(-1, unbiased=False)
+            assert ratio.min().item() >= 30.0, (i, ratio.min().item())
+            z = ref_vit.block(sd64, i, z)
+        p64 = torch.softmax(ref_vit.logits(sd64, x.double()), dim=1)
+    p32 = ref_vit.predict_proba(sd, x, 8)
+    got = ops.VitModel(sd, dev).predict_proba(x.to(dev), list(range(c)), chunk_cells=16).cpu()
+    err = (got.double() - p64).abs().max().item()
+    err32 = (p32.double() - p64).abs().max().item()
+    note_err(f"vit_forward large row mean {name} (fp32 reference vs fp64: {err32:.2e})", err)
+    assert err < max(2e-4, 3.0 * err32) and err < 1e-3, (err, err32)
+    assert torch.equal(got.argmax(1), p64.argmax(1))
 
 
 def test_vit_golden_logits(dev, golden_dir):

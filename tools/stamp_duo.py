@@ -4,6 +4,7 @@ a workgroup's epilogue / prologue runs beside a co-resident workgroup's K loop."
 import os
 import sys
 
+os.environ.setdefault("RIBCA_DIAG", "1")      # the stamp / ablation kernel forms live in libribca_hip_diag.so (build --diag)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
@@ -25,15 +26,18 @@ for name, d, n, kp, kind in (("proj576", 576, 576, 576, 0), ("fc1_576", 576, 230
     out = torch.zeros((M, n if kind == 0 else 2 * n), dtype=torch.float32 if kind == 0 else torch.int16, device=dev)
     ldo = n if kind == 0 else 2 * n
     bn = 128 if n % 128 == 0 else (96 if n % 96 == 0 else 64)
-    nblk = ((M + 255) // 256) * (npad // bn)
+    # the default duo form (RIBCA_DUO_FORM 0 / 1) launches 192-row tiles, form 2 256-row tiles; the library also refuses to stamp
+    # workgroups beyond the capacity it is told
+    bm = 256 if os.environ.get("RIBCA_DUO_FORM") == "2" or not (40 <= variant <= 49) else 192
+    nblk = ((M + bm - 1) // bm) * (npad // bn)
     stamps = torch.zeros((nblk, 20), dtype=torch.int64, device=dev)
-    lib().ribca_set_gemm_stamps(ptr(stamps))
+    lib().ribca_set_gemm_stamps(ptr(stamps), nblk)
     lib().ribca_set_gemm_variant(variant)
     for _ in range(2):
         check(lib().ribca_test_gemm(kind, ptr(a), 2 * kp, ptr(w), 2 * kp, M, n, kp, ptr(bias), ptr(out), ldo, stream_ptr()), "gemm")
     torch.cuda.synchronize()
     lib().ribca_set_gemm_variant(0)
-    lib().ribca_set_gemm_stamps(None)
+    lib().ribca_set_gemm_stamps(None, 0)
     t = stamps.cpu().numpy().astype(np.float64)
     us = 0.01
     t0, t1, t2 = t[:, 0] * us, t[:, 1] * us, t[:, 2] * us

@@ -5,6 +5,8 @@ and the gap between consecutive workgroups on the same CU."""
 import os
 import sys
 
+os.environ.setdefault("RIBCA_DIAG", "1")      # the stamp / ablation kernel forms live in libribca_hip_diag.so (build --diag)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
@@ -27,13 +29,13 @@ for name, d, n, kp, kind in (("proj576", 576, 576, 576, 0), ("fc1_576", 576, 230
     bn = 128 if n % 128 == 0 else (96 if n % 96 == 0 else 64)
     nblk = ((M + 255) // 256) * (npad // bn)
     stamps = torch.zeros((nblk, 20), dtype=torch.int64, device=dev)
-    lib().ribca_set_gemm_stamps(ptr(stamps))
+    lib().ribca_set_gemm_stamps(ptr(stamps), nblk)
     lib().ribca_set_gemm_variant(12)
     for _ in range(2):
         check(lib().ribca_test_gemm(kind, ptr(a), 2 * kp, ptr(w), 2 * kp, M, n, kp, ptr(bias), ptr(out), ldo, stream_ptr()), "gemm")
     torch.cuda.synchronize()
     lib().ribca_set_gemm_variant(0)
-    lib().ribca_set_gemm_stamps(None)
+    lib().ribca_set_gemm_stamps(None, 0)
     t = stamps.cpu().numpy().astype(np.float64)
     t0, t1, t2, t3 = t[:, 0], t[:, 1], t[:, 2], t[:, 3]
     us = 0.01  # 100 MHz ticks -> microseconds
