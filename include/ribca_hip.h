@@ -178,19 +178,23 @@ int ribca_test_qkv_attention(const uint16_t* A, int32_t lda, const uint16_t* W, 
                              const float* bias, uint16_t* q, uint16_t* k, uint16_t* vt, uint16_t* out, int32_t ldo, void* stream);
 /* The classifiers' blocks run with LayerNorm FOLDED into the Linear behind it (timm Block.norm1 -> attn.qkv, norm2 -> mlp.fc1,
  * reached from model.py:54-55): the residual stream is packed-split fp16 hi + lo, z_ps [M][ldz], which the qkv / fc1 GEMM reads as
- * its operand; the weight is gamma o W, and the epilogue applies x = rstd * acc + (-mean * rstd) * csum[n] + bias2[n].  Hooks:
+ * its operand; the weight is gamma o W, and the epilogue applies x = rstd * acc + (-mean * rstd) * csum[n] + bias2[n] with the
+ * (rstd, mean) pair of the row in `rowstat`.  Hooks:
  *   fold_weight:   w [N][K] fp32 + gamma, beta [K] + bias [N] -> packed weight [Np][2*Kp], csum [N], bias2 [N]
- *   row_stats:     rowstat [M] float2 = (rstd, -mean * rstd) of every row of z_ps (eps 1e-6, biased variance over D)
- *   gemm_resid_ps: z_ps += A W^T + bias in place; rowstat (optional) = statistics of the NEW rows through the epilogue's
- *                  per-tile pairs (part: scratch of ribca_test_resid_tiles(N) * M float2)
+ *   row_stats:     rowstat [M] float2 = (rstd, mean) of every row of z_ps (eps 1e-6, biased variance over D); recentre != 0: the
+ *                  rows are first rewritten as z - mean (every reader of the stream is a LayerNorm, so a per-row constant is
+ *                  unobservable) and the statistics are those of the rewritten rows
+ *   gemm_resid_ps: z_ps = (z_ps - prev[m].mean) + A W^T + bias in place (prev: rowstat of the stored rows, or NULL); rowstat
+ *                  (optional) = statistics of the NEW rows through the epilogue's per-tile pairs (part: scratch of
+ *                  ribca_test_resid_tiles(N) * M float2)
  *   gemm_fold:     kind 1: out_ps = gelu(folded x), as ribca_test_gemm kind 1
  *   qkv_attention_fold: as ribca_test_qkv_attention with the folded qkv epilogue */
 int ribca_test_fold_weight(const float* w, int32_t N, int32_t K, const float* gamma, const float* beta, const float* bias, uint16_t* out,
                            int32_t Np, int32_t Kp, float* csum, float* bias2, void* stream);
-int ribca_test_row_stats(const uint16_t* z_ps, int32_t ldz, int32_t M, int32_t D, float* rowstat, void* stream);
+int ribca_test_row_stats(uint16_t* z_ps, int32_t ldz, int32_t M, int32_t D, float* rowstat, int32_t recentre, void* stream);
 int32_t ribca_test_resid_tiles(int32_t N);
 int ribca_test_gemm_resid_ps(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
-                             const float* bias, uint16_t* z_ps, int32_t ldz, float* part, float* rowstat, void* stream);
+                             const float* bias, uint16_t* z_ps, int32_t ldz, float* part, float* rowstat, const float* prev, void* stream);
 int ribca_test_gemm_fold(int32_t kind, const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
                          const float* bias2, const float* csum, const float* rowstat, void* out, int32_t ldo, void* stream);
 int ribca_test_qkv_attention_fold(const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t cells, int32_t D, int32_t Kp,

@@ -59,10 +59,10 @@ SIGNATURES = {
                                            c_void_p, c_void_p, c_int32, c_void_p]),
     "ribca_test_fold_weight": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p,
                                          c_void_p, c_void_p]),
-    "ribca_test_row_stats": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "ribca_test_row_stats": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     "ribca_test_resid_tiles": (c_int32, [c_int32]),
     "ribca_test_gemm_resid_ps": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
-                                           c_void_p, c_void_p, c_void_p]),
+                                           c_void_p, c_void_p, c_void_p, c_void_p]),
     "ribca_test_gemm_fold": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_int32, c_void_p]),
     "ribca_test_qkv_attention_fold": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,

@@ -27,7 +27,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 //   fetch(m, n, ctx)               per (row, chunk): residual / table values
 //   apply<PX>(m, n, acc, bias, csum, rowstat, ctx [, Row, Col])
 struct NoRow {};
-struct LnRow { float rstd, nm; };   // nm = -mean * rstd
+struct LnRow { float rstd, nm; };   // nm = -mean * rstd  (memory holds (rstd, mean) per row: the residual epilogue wants the mean itself)
 __device__ __forceinline__ void settle_row(NoRow&) {}
 __device__ __forceinline__ void settle_row(LnRow& r) { asm volatile("" : "+v"(r.rstd), "+v"(r.nm)); }
 
@@ -67,11 +67,17 @@ struct EpiResid {
 // (22 bits), which is exactly the A operand the next qkv / fc1 GEMM reads -- no LayerNorm kernel, no second copy of the row.
 // The drain (lds_drain_resid_ps, gemm_split16.hip) also emits per (row, column tile) the mean and the centred sum of squares of the
 // NEW row segment; ln_finalize_kernel combines a row's tiles in tile order (Chan's update) into (rstd, -mean rstd).
+// Re-centring: every reader of the residual stream of a pre-LN block is a LayerNorm (norm1, norm2, the final norm), so a constant
+// added to a whole row is unobservable.  The epilogue therefore subtracts the mean the STORED row had before this update
+// (prev[m * prev_stride].y, the statistics the previous LayerNorm used): stored rows keep |mean| <= one update's common mode,
+// whatever offset the weights put on the stream, and the fold's cancellation rstd (acc - mean c) stays benign
+// (tests/test_gpu_kernels.py::test_vit_forward_large_row_mean).
 // Only the LDS-drain form of the kernel supports it (fetch / apply are never called).
 struct EpiResidPS {
   static constexpr bool kTouch = true, kFold = false;
   uint16_t* z; int ldz; const float* bias; int M, N; int nt = 0;
   float2* part = nullptr;      // [column tiles][M] (mean, M2), or nullptr: no statistics wanted
+  const float2* prev = nullptr; int prev_stride = 1;     // (rstd, mean) of the stored rows, or nullptr: no re-centring
   struct Ctx {};
   typedef NoRow RowS;
   __device__ __forceinline__ bool touch_on() const { return (nt & 2) == 0; }
@@ -110,7 +116,7 @@ struct EpiGeluT {
   struct Ctx {};
   typedef std::conditional_t<FOLD, LnRow, NoRow> RowS;
   __device__ __forceinline__ RowS fetch_row(int m) const {
-    if constexpr (FOLD) { const float2 r = this->rowstat[m < M ? m : M - 1]; return RowS{r.x, r.y}; }
+    if constexpr (FOLD) { const float2 r = this->rowstat[m < M ? m : M - 1]; return RowS{r.x, -r.y * r.x}; }
     else return RowS{};
   }
   __device__ __forceinline__ float4 fetch_csum(int n) const {
@@ -141,7 +147,7 @@ struct EpiQKVT {
   static constexpr bool kTouch = false, kFold = FOLD;
   typedef std::conditional_t<FOLD, LnRow, NoRow> RowS;
   __device__ __forceinline__ RowS fetch_row(int m) const {
-    if constexpr (FOLD) { const float2 r = this->rowstat[m < M ? m : M - 1]; return RowS{r.x, r.y}; }
+    if constexpr (FOLD) { const float2 r = this->rowstat[m < M ? m : M - 1]; return RowS{r.x, -r.y * r.x}; }
     else return RowS{};
   }
   __device__ __forceinline__ float4 fetch_csum(int n) const {

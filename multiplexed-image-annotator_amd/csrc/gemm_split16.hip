@@ -168,11 +168,13 @@ __device__ __forceinline__ void lds_drain_resid_ps(const EpiResidPS& epi, const 
   const int gofs = 2 * (n & ~7) + (odd ? 8 : 0);
   const int rbase = 2 * wave + half;
   uint4 zraw[NIT];
+  float pmean[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int row = rbase + 24 * it;
     const bool ok = col_ok && row < 256 && m0 + row < epi.M;
     zraw[it] = ok ? *reinterpret_cast<const uint4*>(epi.z + (size_t)(m0 + row) * epi.ldz + gofs) : uint4{0u, 0u, 0u, 0u};
+    pmean[it] = (ok && epi.prev != nullptr) ? epi.prev[(size_t)(m0 + row) * epi.prev_stride].y : 0.f;
   }
   f32x4 vals[NIT];
   const char* src = smem + rbase * SROW + c * 16;
@@ -185,7 +187,7 @@ __device__ __forceinline__ void lds_drain_resid_ps(const EpiResidPS& epi, const 
   for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(vals[it]));
   settle(b4);
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(zraw[it].x), "+v"(zraw[it].y), "+v"(zraw[it].z), "+v"(zraw[it].w));
+  for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(zraw[it].x), "+v"(zraw[it].y), "+v"(zraw[it].z), "+v"(zraw[it].w), "+v"(pmean[it]));
   __builtin_amdgcn_sched_barrier(0);
   float xs[NIT][4], s[NIT];
 #pragma unroll
@@ -200,8 +202,9 @@ __device__ __forceinline__ void lds_drain_resid_ps(const EpiResidPS& epi, const 
     const uint32_t lx = odd ? zraw[it].z : rx, ly = odd ? zraw[it].w : ry;
     const f32x2 h01 = unpack_f16(hx), h23 = unpack_f16(hy), l01 = unpack_f16(lx), l23 = unpack_f16(ly);
     const f32x4& v = vals[it];
-    float x[4] = {(h01[0] + l01[0]) + (v[0] + b4.x), (h01[1] + l01[1]) + (v[1] + b4.y), (h23[0] + l23[0]) + (v[2] + b4.z),
-                  (h23[1] + l23[1]) + (v[3] + b4.w)};
+    const float pm = pmean[it];
+    float x[4] = {((h01[0] + l01[0]) - pm) + (v[0] + b4.x), ((h01[1] + l01[1]) - pm) + (v[1] + b4.y), ((h23[0] + l23[0]) - pm) + (v[2] + b4.z),
+                  ((h23[1] + l23[1]) - pm) + (v[3] + b4.w)};
     uint2 nh, nl;
     split4(x, nh, nl);
     const uint32_t tx = odd ? nh.x : nl.x, ty = odd ? nh.y : nl.y;
@@ -398,8 +401,10 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
       }
       if constexpr (Epi::kFold) {
         if (kk == 0) {      // consumers read this after the K loop, many barriers from here
+          asm volatile("" : "+v"(fold_rs), "+v"(fold_cb));      // (the values exist from here on: the wait above covered their loads)
           char* xs = smem + NST * STAGE;
-          *reinterpret_cast<unsigned long long*>(xs + (lw * 64 + lane) * 8) = fold_rs;
+          const float2 sm = __builtin_bit_cast(float2, fold_rs);      // memory: (rstd, mean); the fold wants (rstd, -mean rstd)
+          *reinterpret_cast<float2*>(xs + (lw * 64 + lane) * 8) = float2{sm.x, -sm.y * sm.x};
           if (lw < 2 && lane < BN / 4) {
             const bool ok = n0 + 4 * lane < epi.N;
             *reinterpret_cast<u32x4*>(xs + kFoldRowBytes + lw * (4 * BN) + lane * 16) = ok ? fold_cb : u32x4{0u, 0u, 0u, 0u};
@@ -863,9 +868,9 @@ void launch_gemm_resid(const GemmArgs& g, float* z, int ldz, hipStream_t s) {
 void launch_gemm_gelu(const GemmArgs& g, uint16_t* out, int ldo, hipStream_t s) {
   launch_any(g, EpiGelu{out, ldo, g.bias, g.M, g.N, nt_mask() & 1}, s);
 }
-void launch_gemm_resid_ps(const GemmArgs& g, uint16_t* z, int ldz, float2* part, hipStream_t s) {
+void launch_gemm_resid_ps(const GemmArgs& g, uint16_t* z, int ldz, float2* part, const float2* prev, int prev_stride, hipStream_t s) {
   static const int no_touch = (getenv("RIBCA_GEMM_TOUCH") && atoi(getenv("RIBCA_GEMM_TOUCH")) == 0) ? 2 : 0;
-  launch_any(g, EpiResidPS{z, ldz, g.bias, g.M, g.N, no_touch, part}, s);
+  launch_any(g, EpiResidPS{z, ldz, g.bias, g.M, g.N, no_touch, part, prev, prev_stride}, s);
 }
 void launch_gemm_gelu_ln(const GemmArgs& g, const float2* rowstat, const float* csum, uint16_t* out, int ldo, hipStream_t s) {
   launch_any(g, EpiGeluLn{out, ldo, g.bias, g.M, g.N, nt_mask() & 1, rowstat, csum}, s);

@@ -311,8 +311,9 @@ void run_last_block_cls(const BlockW& L, const BlockWs& w, int cells, const Attn
 // instead of seven + no LayerNorm pass over the rows: qkv and fc1 read the packed-split residual stream itself, the residual GEMMs
 // (proj, fc2) update it in place and leave the row statistics of the NEW rows behind.
 // Precondition: w.rs holds the statistics of z for norm1 (row_stats after the embedding, or the previous block's fc2).
-void resid_ps_and_stats(const GemmArgs& g, const BlockWs& w, int ldz_rows, int D, bool want_stats, hipStream_t s) {
-  launch_gemm_resid_ps(g, w.zps, ldz_rows, want_stats ? w.part : nullptr, s);
+// prev_stride: w.rs[m * prev_stride] = (rstd, mean) of the stored row that GEMM row m updates (re-centring, EpiResidPS)
+void resid_ps_and_stats(const GemmArgs& g, const BlockWs& w, int ldz_rows, int D, bool want_stats, int prev_stride, hipStream_t s) {
+  launch_gemm_resid_ps(g, w.zps, ldz_rows, want_stats ? w.part : nullptr, w.rs, prev_stride, s);
   if (want_stats) launch_ln_finalize(w.part, gemm_resid_tiles(D), g.M, gemm_resid_bn(D), D, w.rs, s);
 }
 void run_block_fold(const BlockW& L, const BlockWs& w, int cells, const AttnGeom& a, hipStream_t s) {
@@ -327,7 +328,7 @@ void run_block_fold(const BlockW& L, const BlockWs& w, int cells, const AttnGeom
   {
     ProfScope ps(P_PROJ, s);
     GemmArgs g{w.xa, ld_x, L.projw, ld_x, Mc, D, Dp, L.projb};
-    resid_ps_and_stats(g, w, ld_x, D, true, s);
+    resid_ps_and_stats(g, w, ld_x, D, true, 1, s);
   }
   {
     ProfScope ps(P_FC1, s);
@@ -337,7 +338,7 @@ void run_block_fold(const BlockW& L, const BlockWs& w, int cells, const AttnGeom
   {
     ProfScope ps(P_FC2, s);
     GemmArgs g{w.h, ld_h, L.fc2w, ld_h, Mc, D, 4 * D, L.fc2b};
-    resid_ps_and_stats(g, w, ld_x, D, true, s);
+    resid_ps_and_stats(g, w, ld_x, D, true, 1, s);
   }
 }
 // last block, CLS rows only behind the attention (see run_last_block_cls): GEMM row m = cell, addressed with a row stride of T rows;
@@ -354,7 +355,7 @@ void run_last_block_cls_fold(const BlockW& L, const BlockWs& w, int cells, const
   {
     ProfScope ps(P_PROJ, s);
     GemmArgs g{w.xa, a.T * ld_x, L.projw, ld_x, cells, D, Dp, L.projb};
-    resid_ps_and_stats(g, w, a.T * ld_x, D, true, s);
+    resid_ps_and_stats(g, w, a.T * ld_x, D, true, a.T, s);      // the stored CLS rows still carry norm1's (all-rows) statistics
   }
   {
     ProfScope ps(P_FC1, s);
@@ -364,7 +365,7 @@ void run_last_block_cls_fold(const BlockW& L, const BlockWs& w, int cells, const
   {
     ProfScope ps(P_FC2, s);
     GemmArgs g{w.h, ld_h, L.fc2w, ld_h, cells, D, 4 * D, L.fc2b};
-    resid_ps_and_stats(g, w, a.T * ld_x, D, false, s);
+    resid_ps_and_stats(g, w, a.T * ld_x, D, false, 1, s);
   }
 }
 
@@ -465,7 +466,7 @@ int ribca_vit_forward(const ribca_vit_t* m, const float* patches, int32_t c_img,
         ProfScope ps(P_OTHER, s);
         launch_cls_rows_ps(w.zps, ld_z, m->cls, m->pos, D, bc, kTokens, s);
       }
-      { ProfScope ps(P_LN, s); launch_row_stats_ps(w.zps, ld_z, bc * kTokens, D, w.rs, s); }
+      { ProfScope ps(P_LN, s); launch_row_stats_ps(w.zps, ld_z, bc * kTokens, D, w.rs, true, s); }
       for (size_t li = 0; li + 1 < m->layers.size(); ++li) run_block_fold(m->layers[li], w, bc, geom, s);
       run_last_block_cls_fold(m->layers.back(), w, bc, geom, s);
       {
@@ -818,18 +819,18 @@ int ribca_test_fold_weight(const float* w, int32_t N, int32_t K, const float* ga
   HIP_TRY(hipGetLastError());
   return 0;
 }
-int ribca_test_row_stats(const uint16_t* z_ps, int32_t ldz, int32_t M, int32_t D, float* rowstat, void* stream) {
-  launch_row_stats_ps(z_ps, ldz, M, D, reinterpret_cast<float2*>(rowstat), (hipStream_t)stream);
+int ribca_test_row_stats(uint16_t* z_ps, int32_t ldz, int32_t M, int32_t D, float* rowstat, int32_t recentre, void* stream) {
+  launch_row_stats_ps(z_ps, ldz, M, D, reinterpret_cast<float2*>(rowstat), recentre != 0, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 int32_t ribca_test_resid_tiles(int32_t N) { return gemm_resid_tiles(N); }
 int ribca_test_gemm_resid_ps(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
-                             const float* bias, uint16_t* z_ps, int32_t ldz, float* part, float* rowstat, void* stream) {
+                             const float* bias, uint16_t* z_ps, int32_t ldz, float* part, float* rowstat, const float* prev, void* stream) {
   if (N % 8 != 0) return fail("ribca_test_gemm_resid_ps: N must be a multiple of 8");
   if ((rowstat != nullptr) != (part != nullptr)) return fail("ribca_test_gemm_resid_ps: part and rowstat go together");
   GemmArgs g{A, lda, W, ldw, M, N, Kp, bias};
-  launch_gemm_resid_ps(g, z_ps, ldz, reinterpret_cast<float2*>(part), (hipStream_t)stream);
+  launch_gemm_resid_ps(g, z_ps, ldz, reinterpret_cast<float2*>(part), reinterpret_cast<const float2*>(prev), 1, (hipStream_t)stream);
   if (rowstat) launch_ln_finalize(reinterpret_cast<const float2*>(part), gemm_resid_tiles(N), M, gemm_resid_bn(N), N, reinterpret_cast<float2*>(rowstat),
                                   (hipStream_t)stream);
   HIP_TRY(hipGetLastError());

@@ -26,12 +26,13 @@ void launch_gemm_resid(const GemmArgs& g, float* z, int ldz, hipStream_t s);
 // out_ps[m][n] = gelu(acc + bias), packed-split          (mlp.fc1)
 void launch_gemm_gelu(const GemmArgs& g, uint16_t* out, int ldo, hipStream_t s);
 // ---- classifier blocks: LayerNorm folded into qkv / fc1, residual stream packed-split (gemm_epi.h: EpiResidPS, EpiGeluLn, EpiQKVLn)
-// z_ps[m][n] += acc + bias on the packed-split residual stream; part [gemm_resid_tiles(N)][M] receives (mean, centred sum of
-// squares) of every (row, column tile) of the NEW z, or nullptr
-void launch_gemm_resid_ps(const GemmArgs& g, uint16_t* z, int ldz, float2* part, hipStream_t s);
+// z_ps[m][n] = (z_ps[m][n] - prev[m * prev_stride].y) + acc + bias on the packed-split residual stream (prev = (rstd, mean) of the
+// stored rows: re-centring, see EpiResidPS; nullptr = none); part [gemm_resid_tiles(N)][M] receives (mean, centred sum of squares)
+// of every (row, column tile) of the NEW z, or nullptr
+void launch_gemm_resid_ps(const GemmArgs& g, uint16_t* z, int ldz, float2* part, const float2* prev, int prev_stride, hipStream_t s);
 int gemm_resid_tiles(int N);        // column tiles of an N-wide residual GEMM (= rows of `part`)
 int gemm_resid_bn(int N);           // their width
-// the same as launch_gemm_gelu / launch_gemm_qkv with x = rowstat[m].x * acc + (rowstat[m].y * csum[n] + bias[n])
+// the same as launch_gemm_gelu / launch_gemm_qkv with rowstat[m] = (rstd, mean):  x = rstd * acc + (-mean * rstd * csum[n] + bias[n])
 void launch_gemm_gelu_ln(const GemmArgs& g, const float2* rowstat, const float* csum, uint16_t* out, int ldo, hipStream_t s);
 // geometry of one attention problem: D = H*hd features, T tokens per cell; Q/K rows padded to TP = 16*NT tokens and STORED with
 // hdq = round8(hd) dims (compact: whole PS groups only); the MFMA K dimension is hdp = round32(hd), the groups beyond hdq are
@@ -77,8 +78,9 @@ void launch_embed_ps(const float* patches, int c_img, const int* src_chan, int C
 void launch_cls_rows_ps(uint16_t* z, int ldz, const float* cls, const float* pos, int D, int cells, int tokens_per_cell, hipStream_t s);
 void launch_head_softmax_ps(const uint16_t* z, int ldz, const float* gamma, const float* beta, const float* hw, const float* hb,
                             float* probs, int D, int K, int cells, hipStream_t s);
-// rowstat[m] = (rstd, -mean * rstd) of row m of a packed-split z (LayerNorm eps 1e-6)
-void launch_row_stats_ps(const uint16_t* z, int ldz, int M, int D, float2* rowstat, hipStream_t s);
+// rowstat[m] = (rstd, mean) of row m of a packed-split z (LayerNorm eps 1e-6, biased variance); recentre: the row is first rewritten
+// as z - mean (every reader is a LayerNorm: unobservable) and the statistics describe the rewritten row
+void launch_row_stats_ps(uint16_t* z, int ldz, int M, int D, float2* rowstat, bool recentre, hipStream_t s);
 // the same from the residual epilogue's per-tile pairs: part [T][M], tiles bn wide over N columns
 void launch_ln_finalize(const float2* part, int T, int M, int bn, int N, float2* rowstat, hipStream_t s);
 // gamma o W packed-split + csum[n] + bias2[n] = bias[n] + W[n] . beta   (LayerNorm folded into the Linear)

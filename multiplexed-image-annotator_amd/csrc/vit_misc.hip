@@ -161,35 +161,65 @@ void launch_cls_rows_ps(uint16_t* z, int ldz, const float* cls, const float* pos
   hipLaunchKernelGGL(cls_rows_ps_kernel, dim3((cells * (D >> 2) + 255) / 256), dim3(256), 0, s, z, ldz, cls, pos, D, cells, tokens_per_cell);
 }
 
-// Row statistics of a packed-split residual stream, as the folded-LayerNorm GEMM epilogues read them: rowstat[m] = (rstd, -mean rstd),
+// Row statistics of a packed-split residual stream, as the folded-LayerNorm GEMM epilogues read them: rowstat[m] = (rstd, mean),
 // two-pass mean / biased variance over hi + lo (exact in fp32), eps 1e-6.  One wave per row, D <= 1024.  Used once per forward chunk,
 // behind the patch embedding; every later LayerNorm's statistics come out of the residual GEMM epilogues (gemm_split16.hip).
-__global__ __launch_bounds__(256) void row_stats_ps_kernel(const uint16_t* __restrict__ z, int ldz, int M, int D, float2* __restrict__ rowstat) {
+// RECENTRE: the row is rewritten as z - mean first (see EpiResidPS: a per-row constant is unobservable) and the statistics are those
+// of the rewritten row.
+template <bool RECENTRE>
+__global__ __launch_bounds__(256) void row_stats_ps_kernel(uint16_t* __restrict__ z, int ldz, int M, int D, float2* __restrict__ rowstat) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int ng = D >> 3;
-  const uint16_t* zr = z + (size_t)row * ldz;
+  uint16_t* zr = z + (size_t)row * ldz;
   float x[2][8];
-  float sum = 0.f;
+  auto load_sum = [&]() {
+    float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int g = lane + 64 * i;
-    if (g < ng) {
-      const uint4 hi = *reinterpret_cast<const uint4*>(zr + 16 * g), lo = *reinterpret_cast<const uint4*>(zr + 16 * g + 8);
-      const uint32_t hw[4] = {hi.x, hi.y, hi.z, hi.w}, lw[4] = {lo.x, lo.y, lo.z, lo.w};
+    for (int i = 0; i < 2; ++i) {
+      const int g = lane + 64 * i;
+      if (g < ng) {
+        const uint4 hi = *reinterpret_cast<const uint4*>(zr + 16 * g), lo = *reinterpret_cast<const uint4*>(zr + 16 * g + 8);
+        const uint32_t hw[4] = {hi.x, hi.y, hi.z, hi.w}, lw[4] = {lo.x, lo.y, lo.z, lo.w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x2 h = unpack_f16(hw[j]), l = unpack_f16(lw[j]);
-        x[i][2 * j] = h[0] + l[0]; x[i][2 * j + 1] = h[1] + l[1];
+        for (int j = 0; j < 4; ++j) {
+          const f32x2 h = unpack_f16(hw[j]), l = unpack_f16(lw[j]);
+          x[i][2 * j] = h[0] + l[0]; x[i][2 * j + 1] = h[1] + l[1];
+        }
+        sum += ((x[i][0] + x[i][1]) + (x[i][2] + x[i][3])) + ((x[i][4] + x[i][5]) + (x[i][6] + x[i][7]));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[i][j] = 0.f;
       }
-      sum += ((x[i][0] + x[i][1]) + (x[i][2] + x[i][3])) + ((x[i][4] + x[i][5]) + (x[i][6] + x[i][7]));
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) x[i][j] = 0.f;
     }
+    return sum;
+  };
+  float mean = wave_sum(load_sum()) / (float)D;
+  if constexpr (RECENTRE) {
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int g = lane + 64 * i;
+      if (g < ng) {
+        float a[4] = {x[i][0] - mean, x[i][1] - mean, x[i][2] - mean, x[i][3] - mean};
+        float b[4] = {x[i][4] - mean, x[i][5] - mean, x[i][6] - mean, x[i][7] - mean};
+        uint2 ah, al, bh, bl;
+        split4(a, ah, al);
+        split4(b, bh, bl);
+        *reinterpret_cast<uint4*>(zr + 16 * g) = uint4{ah.x, ah.y, bh.x, bh.y};
+        *reinterpret_cast<uint4*>(zr + 16 * g + 8) = uint4{al.x, al.y, bl.x, bl.y};
+        const uint32_t hw[4] = {ah.x, ah.y, bh.x, bh.y}, lw[4] = {al.x, al.y, bl.x, bl.y};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x2 h = unpack_f16(hw[j]), l = unpack_f16(lw[j]);
+          x[i][2 * j] = h[0] + l[0]; x[i][2 * j + 1] = h[1] + l[1];
+        }
+        sum += ((x[i][0] + x[i][1]) + (x[i][2] + x[i][3])) + ((x[i][4] + x[i][5]) + (x[i][6] + x[i][7]));
+      }
+    }
+    mean = wave_sum(sum) / (float)D;
   }
-  const float mean = wave_sum(sum) / (float)D;
   float sq = 0.f;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -199,14 +229,15 @@ __global__ __launch_bounds__(256) void row_stats_ps_kernel(const uint16_t* __res
     }
   }
   const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + kLnEps);
-  if (lane == 0) rowstat[row] = float2{rstd, -mean * rstd};
+  if (lane == 0) rowstat[row] = float2{rstd, mean};
 }
-void launch_row_stats_ps(const uint16_t* z, int ldz, int M, int D, float2* rowstat, hipStream_t s) {
+void launch_row_stats_ps(uint16_t* z, int ldz, int M, int D, float2* rowstat, bool recentre, hipStream_t s) {
   if (M <= 0) return;
-  hipLaunchKernelGGL(row_stats_ps_kernel, dim3((M + 3) / 4), dim3(256), 0, s, z, ldz, M, D, rowstat);
+  if (recentre) hipLaunchKernelGGL(row_stats_ps_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, s, z, ldz, M, D, rowstat);
+  else hipLaunchKernelGGL(row_stats_ps_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, s, z, ldz, M, D, rowstat);
 }
 
-// rowstat[m] = (rstd, -mean rstd) from the per-column-tile (mean, centred sum of squares) pairs the residual epilogue wrote:
+// rowstat[m] = (rstd, mean) from the per-column-tile (mean, centred sum of squares) pairs the residual epilogue wrote:
 // tiles are combined in tile order with Chan's update, so the result does not depend on which workgroup finished first.
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restrict__ part, int T, int M, int bn, int N, float2* __restrict__ rowstat) {
   const int m = blockIdx.x * 256 + threadIdx.x;
@@ -223,7 +254,7 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restri
     cnt = tot;
   }
   const float rstd = 1.0f / sqrtf(m2 / (float)N + kLnEps);
-  rowstat[m] = float2{rstd, -mean * rstd};
+  rowstat[m] = float2{rstd, mean};
 }
 void launch_ln_finalize(const float2* part, int T, int M, int bn, int N, float2* rowstat, hipStream_t s) {
   if (M <= 0) return;

@@ -140,11 +140,22 @@ def _ln_case(m, d, seed, dev, mean=0.5, std=3.0, row_scale=False):
     return z_ps, zq, g, b, dp
 
 
-def _row_stats(z_ps, dp, m, d, dev):
+def _row_stats(z_ps, dp, m, d, dev, recentre=False):
+    """(rstd, mean) per row of a packed-split buffer; recentre rewrites the rows as z - mean first"""
     from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
     rs = torch.zeros((m, 2), dtype=torch.float32, device=dev)
-    check(lib().ribca_test_row_stats(ptr(z_ps), 2 * dp, m, d, ptr(rs), stream_ptr()), "row_stats")
+    check(lib().ribca_test_row_stats(ptr(z_ps), 2 * dp, m, d, ptr(rs), 1 if recentre else 0, stream_ptr()), "row_stats")
     return rs
+
+
+def _stats_err(rs, rows):
+    """relative error of (rstd, mean) against the fp64 statistics of `rows`; the mean is measured on the scale of the row's spread"""
+    mu = rows.mean(1)
+    rstd = 1.0 / torch.sqrt(rows.var(1, unbiased=False) + 1e-6)
+    amp = 1.0 + mu.abs() * rstd
+    e1 = ((rs[:, 0].double() - rstd).abs() / (rstd * amp)).max().item()
+    e2 = ((rs[:, 1].double() - mu).abs() * rstd / amp).max().item()
+    return e1, e2
 
 
 def _fold(w, g, b, bias, kp, dev):
@@ -182,14 +193,25 @@ def test_fold_weight(dev, n, k):
 def test_row_stats(dev, d, mean, std):
     m = 203
     z_ps, zq, _, _, dp = _ln_case(m, d, 44, dev, mean, std, row_scale=(mean == 0.5))
-    rs = _row_stats(z_ps, dp, m, d, dev).double()
-    mu = zq.mean(1)
-    rstd = 1.0 / torch.sqrt(zq.var(1, unbiased=False) + 1e-6)
+    rs = _row_stats(z_ps, dp, m, d, dev)
     # two-pass fp32 statistics of exactly representable inputs: the mean carries 2^-24 |mu| (relative to the spread: x |mu| / sigma),
     # the centred squares then see that error twice
-    amp = 1.0 + (mu.abs() * rstd)
-    assert torch.all((rs[:, 0] - rstd).abs() <= rstd * 4e-7 * amp), ((rs[:, 0] - rstd).abs() / rstd).max()
-    assert torch.all((rs[:, 1] + mu * rstd).abs() <= 4e-7 * amp * (1.0 + (mu * rstd).abs())), (rs[:, 1] + mu * rstd).abs().max()
+    e1, e2 = _stats_err(rs, zq)
+    note_err(f"row_stats d={d} mean {mean}", max(e1, e2))
+    assert e1 < 4e-7 and e2 < 4e-7, (e1, e2)
+    assert torch.equal(ps_decode(z_ps, d), zq)                      # untouched
+    # re-centred: the rows are rewritten as z - mean (|stored mean| << spread) and the statistics are those of what is stored
+    rs2 = _row_stats(z_ps, dp, m, d, dev, recentre=True)
+    z2 = ps_decode(z_ps, d)
+    e1, e2 = _stats_err(rs2, z2)
+    assert e1 < 4e-7 and e2 < 4e-7, (e1, e2)
+    sig = zq.std(1, unbiased=False)
+    assert torch.all(z2.mean(1).abs() <= 1e-6 * sig + 2.0 ** -21 * zq.mean(1).abs())      # the fp32 mean itself: a few ulps of |mean|
+    # the same LayerNorm input: fp32 z - mean of nearby numbers is (nearly) exact, the re-split costs 2^-23 of the CENTRED value
+    ln1 = torch.nn.functional.layer_norm(zq, (d,), None, None, 1e-6)
+    ln2 = torch.nn.functional.layer_norm(z2, (d,), None, None, 1e-6)
+    assert (ln1 - ln2).abs().max().item() < 5e-6
+    assert torch.all(ps_decode(z_ps, dp)[:, d:] == 0)
 
 
 RESID_PS_SHAPES = [(1, 288, 288), (300, 288, 1152), (257, 144, 144), (130, 144, 576), (77, 576, 2304), (129, 384, 384), (515, 768, 768),
@@ -197,8 +219,8 @@ RESID_PS_SHAPES = [(1, 288, 288), (300, 288, 1152), (257, 144, 144), (130, 144, 
 
 
 @pytest.mark.parametrize("m,n,k", RESID_PS_SHAPES)
-@pytest.mark.parametrize("mean", [0.3, 40.0])
-def test_gemm_resid_ps(dev, m, n, k, mean):
+@pytest.mark.parametrize("mean,recentre", [(0.3, False), (40.0, False), (40.0, True)])
+def test_gemm_resid_ps(dev, m, n, k, mean, recentre):
     """proj / fc2 of the classifiers: z (packed-split) += A W^T + b in place, plus (rstd, -mean rstd) of the NEW rows out of the
     epilogue's per-tile pairs (2 ... 6 column tiles), also for rows whose mean dwarfs their spread"""
     from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
@@ -216,21 +238,24 @@ def test_gemm_resid_ps(dev, m, n, k, mean):
     tiles = lib().ribca_test_resid_tiles(n)
     part = torch.zeros((tiles, m, 2), dtype=torch.float32, device=dev)
     rs = torch.zeros((m, 2), dtype=torch.float32, device=dev)
+    # the forward hands the epilogue the (rstd, mean) the stored rows had: it subtracts that mean (re-centring)
+    prev = _row_stats(z_ps, npd, m, n, dev) if recentre else None
     check(lib().ribca_test_gemm_resid_ps(ptr(a_ps), 2 * kp, ptr(w_ps), 2 * kp, m, n, kp, ptr(bias), ptr(z_ps), 2 * npd, ptr(part), ptr(rs),
-                                         stream_ptr()), "resid_ps")
+                                         ptr(prev) if recentre else None, stream_ptr()), "resid_ps")
     ref = z0q + aq @ wq.t() + bias.double()
+    if recentre:
+        ref = ref - prev[:, 1:2].double()
     got = ps_decode(z_ps, n)
     err = ((got - ref).abs() / (1.0 + ref.abs())).max().item()
-    note_err(f"gemm_resid_ps {m}x{n}x{k} mean {mean}", err)
-    # as test_gemm_residual, plus the re-split of the new row (2^-23 relative)
+    note_err(f"gemm_resid_ps {m}x{n}x{k} mean {mean} recentre {recentre}", err)
+    # as test_gemm_residual, plus the re-split of the new row (2^-23 relative); re-centred rows: z - mean is one more fp32 rounding
+    # at |z| <= 45 (2^-24 x 45 = 2.7e-6 absolute)
     assert err < 2e-5, err
     assert torch.all(ps_decode(z_ps, npd)[:, n:] == 0)
+    if recentre:
+        assert got.mean(1).abs().max().item() < 1.0        # the offset is gone: what is left is the mean of the update itself
     # the statistics describe the rows that were STORED
-    mu = got.mean(1)
-    rstd = 1.0 / torch.sqrt(got.var(1, unbiased=False) + 1e-6)
-    amp = 1.0 + mu.abs() * rstd
-    e1 = ((rs[:, 0].double() - rstd).abs() / (rstd * amp)).max().item()
-    e2 = ((rs[:, 1].double() + mu * rstd).abs() / (amp * (1.0 + (mu * rstd).abs()))).max().item()
+    e1, e2 = _stats_err(rs, got)
     note_err(f"resid_ps stats {m}x{n}x{k} mean {mean}", max(e1, e2))
     assert e1 < 1e-6 and e2 < 1e-6, (e1, e2)
 
