@@ -138,104 +138,119 @@ __device__ __forceinline__ void lds_drain(const Epi& epi, const char* smem, int 
 
 
 // ---------------------------------------------------------------------------------------------- residual drain, packed-split z
-// sum over the 32 lanes of a half wave, the same bits in every lane of the half: four DPP steps (quad, quad, 8, 16) and one bpermute
-__device__ __forceinline__ float dpp_add(float v, float o) { return v + o; }
 template <int CTRL> __device__ __forceinline__ float dpp_get(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
-__device__ __forceinline__ float half_wave_sum(float v) {
+// sum over the 16 lanes of a DPP row, the same bits in every lane of the row, fixed order: four VALU steps, no LDS round trip
+__device__ __forceinline__ float row16_sum(float v) {
   v += dpp_get<0xB1>(v);      // quad_perm [1,0,3,2]
   v += dpp_get<0x4E>(v);      // quad_perm [2,3,0,1]
   v += dpp_get<0x141>(v);     // row_half_mirror: the other quad of the 8
   v += dpp_get<0x140>(v);     // row_mirror: the other 8 of the 16
-  v += __shfl_xor(v, 16, 64);
   return v;
 }
-// EpiResidPS: z (fp16 hi + lo) += tile + bias, row statistics of the new segment.  A wave owns whole rows: lanes 0-31 one row, lanes
-// 32-63 the next, lane c the 16-byte chunk c of the tile row (CPR = BN / 4 <= 32 chunks), so a row's sums are DPP reductions in a
-// fixed order.  A lane pair (even, odd chunk) shares one PS 8-group: the even lane loads / stores its 8 hi halves, the odd lane
-// the 8 lo halves, and one DPP exchange gives each lane hi and lo of its own four columns.
+// EpiResidPS: z (fp16 hi + lo) = (z - previous mean) + tile + bias, and the row statistics of the new segment.  A lane owns one whole PS
+// group of a tile row -- 8 columns: two 16-byte chunks of the parked tile, one 16-byte hi and one 16-byte lo vector of z -- so
+// nothing is exchanged between lanes; the 16 lanes of a DPP row share a tile row (BN / 8 <= 16 of them active), a wave covers 4 rows
+// per pass, 12 waves 48, six passes the tile.  Statistics are taken over the fp32 values before the split (the stored row differs by
+// 2^-23 relative per element: 1e-9 on a mean that the fold multiplies by O(1)) with DPP reductions in a fixed order.
 template <int BN>
 __device__ __forceinline__ void lds_drain_resid_ps(const EpiResidPS& epi, const char* smem, int m0, int n0, int nt, int tid) {
-  constexpr int SROW = BN * 4 + 16, CPR = BN / 4, NIT = 11;     // 12 waves x 2 rows x 11 passes = 264 >= 256 rows
-  static_assert(CPR <= 32, "a tile row fits a half wave");
+  constexpr int SROW = BN * 4 + 16, GPR = BN / 8, NIT = 6;     // 12 waves x 4 rows x 6 passes = 288 >= 256 rows
+  static_assert(GPR <= 16, "a tile row fits one DPP row of lanes");
   const int lane = tid & 63, wave = tid >> 6;
-  const int c = lane & 31, half = lane >> 5;
-  const int n = n0 + 4 * c;
-  const bool col_ok = c < CPR && n < epi.N;
-  const bool odd = (c & 1) != 0;
-  float4 b4 = col_ok ? *reinterpret_cast<const float4*>(epi.bias + n) : float4{0.f, 0.f, 0.f, 0.f};
-  const int gofs = 2 * (n & ~7) + (odd ? 8 : 0);
-  const int rbase = 2 * wave + half;
-  uint4 zraw[NIT];
+  const int c = lane & 15;
+  const int n = n0 + 8 * c;
+  const bool col_ok = c < GPR && n < epi.N;      // N % 8 == 0
+  const int rbase = 4 * wave + (lane >> 4);
+  f32x2v b2[4];
+  {
+    const float4 ba = col_ok ? *reinterpret_cast<const float4*>(epi.bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+    const float4 bb = col_ok ? *reinterpret_cast<const float4*>(epi.bias + n + 4) : float4{0.f, 0.f, 0.f, 0.f};
+    b2[0] = f32x2v{ba.x, ba.y}; b2[1] = f32x2v{ba.z, ba.w}; b2[2] = f32x2v{bb.x, bb.y}; b2[3] = f32x2v{bb.z, bb.w};
+  }
+  uint4 zh[NIT], zl[NIT];
   float pmean[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int row = rbase + 24 * it;
+    const int row = rbase + 48 * it;
     const bool ok = col_ok && row < 256 && m0 + row < epi.M;
-    zraw[it] = ok ? *reinterpret_cast<const uint4*>(epi.z + (size_t)(m0 + row) * epi.ldz + gofs) : uint4{0u, 0u, 0u, 0u};
+    const uint16_t* zp = epi.z + (size_t)(m0 + row) * epi.ldz + 2 * n;
+    zh[it] = ok ? *reinterpret_cast<const uint4*>(zp) : uint4{0u, 0u, 0u, 0u};
+    zl[it] = ok ? *reinterpret_cast<const uint4*>(zp + 8) : uint4{0u, 0u, 0u, 0u};
     pmean[it] = (ok && epi.prev != nullptr) ? epi.prev[(size_t)(m0 + row) * epi.prev_stride].y : 0.f;
   }
-  f32x4 vals[NIT];
-  const char* src = smem + rbase * SROW + c * 16;
+  f32x4 va[NIT], vb[NIT];
+  const char* src = smem + rbase * SROW + c * 32;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int row = rbase + 24 * it;
-    vals[it] = (c < CPR && row < 256) ? *reinterpret_cast<const f32x4*>(src + it * 24 * SROW) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int row = rbase + 48 * it;
+    const bool rd = c < GPR && row < 256;
+    va[it] = rd ? *reinterpret_cast<const f32x4*>(src + it * 48 * SROW) : f32x4{0.f, 0.f, 0.f, 0.f};
+    vb[it] = rd ? *reinterpret_cast<const f32x4*>(src + it * 48 * SROW + 16) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(vals[it]));
-  settle(b4);
+  for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(va[it]), "+v"(vb[it]));
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(zraw[it].x), "+v"(zraw[it].y), "+v"(zraw[it].z), "+v"(zraw[it].w), "+v"(pmean[it]));
+  for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(b2[i]));
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+    asm volatile("" : "+v"(zh[it].x), "+v"(zh[it].y), "+v"(zh[it].z), "+v"(zh[it].w), "+v"(zl[it].x), "+v"(zl[it].y), "+v"(zl[it].z), "+v"(zl[it].w),
+                 "+v"(pmean[it]));
   __builtin_amdgcn_sched_barrier(0);
-  float xs[NIT][4], s[NIT];
+  f32x2v xs[NIT][4];
+  float s[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int row = rbase + 24 * it;
+    const int row = rbase + 48 * it;
     const bool ok = col_ok && row < 256 && m0 + row < epi.M;
-    // even lane holds hi[0..7] and needs lo[0..3] (the odd lane's x, y); odd lane holds lo[0..7] and needs hi[4..7] (the even lane's z, w)
-    const uint32_t sx = odd ? zraw[it].x : zraw[it].z, sy = odd ? zraw[it].y : zraw[it].w;
-    const uint32_t rx = (uint32_t)__builtin_amdgcn_mov_dpp((int)sx, 0xB1, 0xF, 0xF, true);
-    const uint32_t ry = (uint32_t)__builtin_amdgcn_mov_dpp((int)sy, 0xB1, 0xF, 0xF, true);
-    const uint32_t hx = odd ? rx : zraw[it].x, hy = odd ? ry : zraw[it].y;
-    const uint32_t lx = odd ? zraw[it].z : rx, ly = odd ? zraw[it].w : ry;
-    const f32x2 h01 = unpack_f16(hx), h23 = unpack_f16(hy), l01 = unpack_f16(lx), l23 = unpack_f16(ly);
-    const f32x4& v = vals[it];
-    const float pm = pmean[it];
-    float x[4] = {((h01[0] + l01[0]) - pm) + (v[0] + b4.x), ((h01[1] + l01[1]) - pm) + (v[1] + b4.y), ((h23[0] + l23[0]) - pm) + (v[2] + b4.z),
-                  ((h23[1] + l23[1]) - pm) + (v[3] + b4.w)};
-    uint2 nh, nl;
-    split4(x, nh, nl);
-    const uint32_t tx = odd ? nh.x : nl.x, ty = odd ? nh.y : nl.y;
-    const uint32_t ux = (uint32_t)__builtin_amdgcn_mov_dpp((int)tx, 0xB1, 0xF, 0xF, true);
-    const uint32_t uy = (uint32_t)__builtin_amdgcn_mov_dpp((int)ty, 0xB1, 0xF, 0xF, true);
-    const u32x4 o = odd ? u32x4{ux, uy, nl.x, nl.y} : u32x4{nh.x, nh.y, ux, uy};
-    if (ok) *reinterpret_cast<u32x4*>(epi.z + (size_t)(m0 + row) * epi.ldz + gofs) = o;
-    // statistics of what was stored (hi + lo is exact in fp32)
-    const f32x2 a01 = unpack_f16(nh.x), a23 = unpack_f16(nh.y), c01 = unpack_f16(nl.x), c23 = unpack_f16(nl.y);
-    xs[it][0] = a01[0] + c01[0]; xs[it][1] = a01[1] + c01[1]; xs[it][2] = a23[0] + c23[0]; xs[it][3] = a23[1] + c23[1];
-    s[it] = ok ? (xs[it][0] + xs[it][1]) + (xs[it][2] + xs[it][3]) : 0.f;
+    const uint32_t hw[4] = {zh[it].x, zh[it].y, zh[it].z, zh[it].w}, lw[4] = {zl[it].x, zl[it].y, zl[it].z, zl[it].w};
+    const f32x2v acc2[4] = {f32x2v{va[it][0], va[it][1]}, f32x2v{va[it][2], va[it][3]}, f32x2v{vb[it][0], vb[it][1]}, f32x2v{vb[it][2], vb[it][3]}};
+    const f32x2v pm = {pmean[it], pmean[it]};
+    uint32_t nh[4], nl[4];
+    f32x2v tot = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {      // two columns at a time: packed fp32 adds
+      const f32x2 h = unpack_f16(hw[j]), l = unpack_f16(lw[j]);
+      const f32x2v zo = f32x2v{h[0], h[1]} + f32x2v{l[0], l[1]};      // hi + lo: exact
+      f32x2v x = (zo - pm) + (acc2[j] + b2[j]);
+      x.x = clamp_f16_range(x.x); x.y = clamp_f16_range(x.y);
+      nh[j] = cvt_pk_f16(x.x, x.y);
+      const f32x2 hb = unpack_f16(nh[j]);
+      const f32x2v r = x - f32x2v{hb[0], hb[1]};
+      nl[j] = cvt_pk_f16(r.x, r.y);
+      xs[it][j] = x;
+      tot += x;
+    }
+    if (ok) {
+      uint16_t* zp = epi.z + (size_t)(m0 + row) * epi.ldz + 2 * n;
+      *reinterpret_cast<u32x4*>(zp) = u32x4{nh[0], nh[1], nh[2], nh[3]};
+      *reinterpret_cast<u32x4*>(zp + 8) = u32x4{nl[0], nl[1], nl[2], nl[3]};
+    }
+    s[it] = ok ? tot.x + tot.y : 0.f;
   }
   if (epi.part == nullptr) return;
   const int ncols = (epi.N - n0) < BN ? (epi.N - n0) : BN;
   const float inv = 1.0f / (float)ncols;
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) s[it] = half_wave_sum(s[it]) * inv;       // tile mean of the row
+  for (int it = 0; it < NIT; ++it) s[it] = row16_sum(s[it]) * inv;       // tile mean of the row
   float q[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int row = rbase + 24 * it;
+    const int row = rbase + 48 * it;
     const bool ok = col_ok && row < 256 && m0 + row < epi.M;
-    const float d0 = xs[it][0] - s[it], d1 = xs[it][1] - s[it], d2 = xs[it][2] - s[it], d3 = xs[it][3] - s[it];
-    q[it] = ok ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
+    const f32x2v mu = {s[it], s[it]};
+    f32x2v qq = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const f32x2v d = xs[it][j] - mu; qq += d * d; }
+    q[it] = ok ? qq.x + qq.y : 0.f;
   }
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) q[it] = half_wave_sum(q[it]);
+  for (int it = 0; it < NIT; ++it) q[it] = row16_sum(q[it]);
   if (c == 0) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int row = rbase + 24 * it;
+      const int row = rbase + 48 * it;
       if (row < 256 && m0 + row < epi.M) epi.part[(size_t)nt * epi.M + m0 + row] = float2{s[it], q[it]};
     }
   }
