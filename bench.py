@@ -43,20 +43,43 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the Annotator (boundary path) timing")
     ap.add_argument("--impute", action="store_true", help="BASELINE config 5: last full-panel marker missing, imputed by the MAE (infer=True)")
-    ap.add_argument("--cpu-sample", type=int, default=512, help="cells of the CPU-oracle sample")
+    ap.add_argument("--cpu-sample", type=int, default=2000, help="cells of the CPU-oracle sample (SURVEY 8(d): 2000)")
     ap.add_argument("--config1", action="store_true", help="BASELINE configs[0] stand-in (example_1 mask, Basic panel, bs 8): drop-in on the GPU "
                                                             "beside the CPU oracle timed IN FULL")
     ap.add_argument("--launch-check", action="store_true", help="rendezvous + one all-gather only (no GPU work): CPU test of the N-rank launch path")
     return ap.parse_args()
 
 
+def visible_gpu_count() -> int:
+    """GPUs this process tree will see, WITHOUT any HIP / torch.cuda call (the launcher parent must never initialise the GPU:
+    it starts the ranks as children): HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES if set, else the
+    kfd topology (nodes with simd_count > 0 and a gfx target are GPUs)."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    n = 0
+    try:
+        for node in sorted(os.listdir(base)):
+            try:
+                props = dict(l.split(None, 1) for l in open(os.path.join(base, node, "properties")).read().splitlines() if " " in l)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0 and int(props.get("gfx_target_version", "0")) > 0:
+                n += 1
+    except OSError:
+        return 0
+    return n
+
+
 def launch_ranks(args) -> int:
     """Start ``args.gpus`` ranks of this script under torch.distributed.run as a CHILD process.  Nothing in this (parent) process
-    has touched a GPU: counting devices does not initialise HIP, and the library is only compiled here, not loaded."""
+    touches a GPU: devices are counted from the environment / sysfs (no HIP runtime call), the library is only compiled here."""
     import socket
     import subprocess
     share = os.environ.get("RIBCA_SHARE_GPU") == "1" or args.launch_check
-    have = torch.cuda.device_count()
+    have = visible_gpu_count()
     if have < args.gpus and not share:
         print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
         return 2
@@ -80,14 +103,30 @@ def launch_check(args, world, rank, backend):
     n = 1001
     lo, hi = dist.shard_bounds(n, rank, world)
     local = torch.arange(lo, hi, dtype=torch.float32).reshape(-1, 1).repeat(1, 33)
+    t0 = time.perf_counter()
     full = dist.all_gather_rows(local, n)
+    ag_ms = (time.perf_counter() - t0) * 1e3
     ok = bool(torch.equal(full[:, 0], torch.arange(n, dtype=torch.float32)))
+    coll = collective_record(world, ag_ms, 1, local)
     if world > 1:
         tdist.barrier()
         tdist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"metric": "launch check (no measurement)", "value": None, "n_gpus": world, "gather_ok": ok}))
+        print(json.dumps({"metric": "launch check (no measurement)", "value": None, "n_gpus": world, "gather_ok": ok, "collective": coll,
+                          "visible_gpus_no_hip": visible_gpu_count()}))
     return 0 if ok else 1
+
+
+def collective_record(world, allgather_ms_total, steps, local_rows):
+    """What the data-path collective actually was, so that an N > 1 line can be checked: the backend torch.distributed reports
+    ("nccl" = RCCL on ROCm), the world size THE PROCESS GROUP sees, the time of the per-tile all-gather and its payload."""
+    import torch.distributed as tdist
+    if world <= 1 or not tdist.is_initialized():
+        return {"backend": None, "world_size_seen": 1, "allgather_ms_per_step": 0.0, "bytes_per_rank": 0}
+    return {"backend": tdist.get_backend(), "world_size_seen": tdist.get_world_size(),
+            "allgather_ms_per_step": round(allgather_ms_total / max(steps, 1), 4),
+            "bytes_per_rank": int(local_rows.numel() * local_rows.element_size()),
+            "call": "ONE all_gather_into_tensor per tile (dist.all_gather_rows), shards padded to the largest"}
 
 
 def main():
@@ -167,6 +206,8 @@ def main():
     tc = [-1.0] * 18
     vote_pair = ("immune_full", "struct") if "immune_full" in models and "struct" in models else (next(iter(models)), None)
 
+    ag_events, ag_state = [], {}
+
     def one_pass(streams=None, models_sel=None):
         streams = args.streams if streams is None else streams
         image = ops.normalize_image(raw, blur=0.3, amax=99.8, u16_bits=True)
@@ -192,7 +233,13 @@ def main():
         if sharded:         # ONE all-gather per tile: the five models' probability columns side by side (33 floats per cell)
             names = list(probs)
             widths = [probs[k].shape[1] for k in names]
-            full = dist.all_gather_rows(torch.cat([probs[k] for k in names], dim=1), n)
+            local_rows = torch.cat([probs[k] for k in names], dim=1)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            full = dist.all_gather_rows(local_rows, n)
+            ev1.record()
+            ag_events.append((ev0, ev1))
+            ag_state["local"] = local_rows
             probs = {k: t.contiguous() for k, t in zip(names, torch.split(full, widths, dim=1))}
         a, b = vote_pair if models_sel is None else (next(iter(probs)), None)
         lab, conf = ops.vote(probs[a], [gid[c] for c in CLASS_NAMES[a]], probs[b] if b else None,
@@ -214,6 +261,7 @@ def main():
         one_pass()
         note(f"warmup {i + 1}/{args.warmup} done")
     sync_all()
+    ag_events.clear()
     t0 = time.perf_counter()
     n_cells = 0
     for i in range(args.steps):
@@ -248,7 +296,12 @@ def main():
                                    else f"cells sharded over {world} rank(s), one all-gather of per-cell probabilities")},
         "vit_gflop_per_cell": round(flops_cell / 1e9, 4),
         "vit_mfma_util_vs_bf16_dense": round(value * flops_cell / (world * PEAK_BF16_DENSE_TFLOPS * 1e12), 5),
+        "mfma_cap_3_pass": 0.3333,      # three fp16 MFMA passes per product: the algorithmic fraction of the 16-bit dense peak cannot exceed 1/3
+        "lib_sha256": lib_sha256(),
     }
+    if sharded:
+        ag_ms = sum(a.elapsed_time(b) for a, b in ag_events)
+        out["collective"] = collective_record(world, ag_ms, args.steps, ag_state.get("local", torch.zeros(0)))
 
     # ---- roofline of the dominant kernel (the bf16x3 GEMM family), one extra profiled pass -----------------------------
     if not args.no_roofline and rank == 0:
@@ -288,41 +341,61 @@ def main():
         g_n = sum(prof[k][1] for k in ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2"))
         achieved = gemm_flops / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
         # committed rocprofv3 evidence for the same kernels (tools/collect_profiles.sh, tools/collect_pmc_sq.sh): HBM/fabric bytes per
-        # launch from the FETCH_SIZE / WRITE_SIZE passes, MFMA-busy and LDS-active fractions from the SQ counter passes
-        traffic, traffic_src, busy, lds = None, None, None, None
-        for tag in ("r2", "r1_final"):
-            tpath = os.path.join(ROOT, "profiles", tag, "gemm_traffic.json")
-            if os.path.exists(tpath):
-                traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"])
-                traffic_src = f"profiles/{tag}/gemm_traffic.json"
-                break
-        spath = os.path.join(ROOT, "profiles", "r2", "sq_summary.json")
+        # launch from the FETCH_SIZE / WRITE_SIZE passes, MFMA-busy and LDS-active fractions from the SQ counter passes.  Both files
+        # carry the sha256 of the libribca_hip.so they were measured on: a different library being timed here -> null, not stale numbers
+        traffic, traffic_src, busy, lds, pass_bytes = None, None, None, None, None
+        sha = out["lib_sha256"]
+        tpath = os.path.join(ROOT, "profiles", "r3", "gemm_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("lib_sha256") == sha:
+                traffic = round(tj["traffic_bytes_per_launch"])
+                traffic_src = "profiles/r3/gemm_traffic.json"
+                if tj.get("vit_bytes_per_cell"):
+                    pass_bytes = tj["vit_bytes_per_cell"] * n_local
+        spath = os.path.join(ROOT, "profiles", "r3", "sq_summary.json")
         if os.path.exists(spath):
             sq = json.load(open(spath))
-            gem = [v for k, v in sq.items() if k.startswith("gemm_ps_split_kernel") or k.startswith("gemm_ps_duo_kernel")]
-            cyc = sum(v["kernel_cycles"] for v in gem)
-            if cyc > 0:
-                busy = round(sum(v["mfma_busy_frac"] * v["kernel_cycles"] for v in gem) / cyc, 4)
-                lds = round(sum(v["lds_active_frac"] * v["kernel_cycles"] for v in gem) / cyc, 4)
+            if sq.get("lib_sha256") == sha:
+                gem = [v for k, v in sq.items() if k.startswith("gemm_ps_split_kernel") or k.startswith("gemm_ps_duo_kernel")]
+                cyc = sum(v["kernel_cycles"] for v in gem)
+                if cyc > 0:
+                    busy = round(sum(v["mfma_busy_frac"] * v["kernel_cycles"] for v in gem) / cyc, 4)
+                    lds = round(sum(v["lds_active_frac"] * v["kernel_cycles"] for v in gem) / cyc, 4)
         alg_bytes = 0.0
         for name, model in models.items():      # algorithmic bytes per pass of the four GEMMs: A read once, output written once, z RMW
             d = model.D
             per_row = 4.0 * d * (1 + 3) + 4.0 * d * (1 + 2) + 4.0 * d * (1 + 4) + 4.0 * d * (4 + 2)      # qkv, proj, fc1, fc2
             alg_bytes += n_local * 101 * (model.depth - 1) * per_row + 12.0 * d * d * 4.0 * model.depth * ((n_local + args.chunk - 1) // args.chunk)
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_ps_split_kernel (qkv/proj/fc2) + gemm_ps_duo_kernel (fc1), fp16x3", "achieved": round(achieved, 2),
+        # the bound that binds most of the GEMM time: every classifier's GEMMs are priced against their own roofline (per_model_*),
+        # the family's label is the time-weighted majority
+        t_mfma = sum(m["gemm_ms"] for m in per_model if m["bound"] == "mfma")
+        t_hbm = sum(m["gemm_ms"] for m in per_model if m["bound"] == "hbm")
+        out["per_kernel_ms"] = {k: round(v[0], 3) for k, v in prof.items() if v[1]}
+        out["per_model_gemm_ms"] = {m["model"]: m["gemm_ms"] for m in per_model}
+        out["per_model_bound"] = {m["model"]: m["bound"] for m in per_model}
+        out["per_model_frac_of_bound"] = {m["model"]: m["frac_of_bound"] for m in per_model}
+        out["per_model_flop_per_byte"] = {m["model"]: m["flop_per_byte"] for m in per_model}
+        # whole ViT pass against HBM: counter bytes (GEMM + attention + statistics kernels, 2 x FETCH_SIZE + WRITE_SIZE of the
+        # committed, sha-matched passes, scaled per cell) over the timed step
+        out["hbm_gb_per_s_pass"] = round(pass_bytes / (ms_per_step * 1e-3) / 1e9, 1) if pass_bytes else None
+        out["hbm_frac_of_8tbs_pass"] = round(pass_bytes / (ms_per_step * 1e-3) / 8.0e12, 4) if pass_bytes else None
+        out["roofline"] = {"bound": "mfma" if t_mfma >= t_hbm else "hbm",
+                           "bound_note": f"time-weighted over the classifiers: {t_mfma:.0f} ms of GEMMs MFMA-bound (D >= 384), {t_hbm:.0f} ms HBM-bound (D <= 288)",
+                           "kernel": "gemm_ps_split_kernel (qkv/proj/fc2) + gemm_ps_duo_kernel (fc1), fp16x3", "achieved": round(achieved, 2),
                            "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 5),
                            "traffic": traffic, "traffic_unit": f"bytes/launch (2*FETCH_SIZE + WRITE_SIZE, {traffic_src})",
                            "algorithmic_bytes_per_launch": round(alg_bytes / max(g_n, 1)),
                            "mfma_busy_frac": busy, "lds_active_frac": lds,
-                           "counters": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), SQ_LDS_IDX_ACTIVE / (256 CUs x ...): profiles/r2/sq_summary.json",
+                           "counters": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), SQ_LDS_IDX_ACTIVE / (256 CUs x ...): "
+                                       "profiles/r3/sq_summary.json; null = the committed counters belong to another build of the library",
                            "launches": int(g_n), "avg_launch_ms": round(g_ms / max(g_n, 1), 5),
                            "algorithmic_gflop_per_launch": round(gemm_flops / max(g_n, 1) / 1e9, 4), "mfma_passes_per_product": 3,
                            "issued_mfma_frac_of_peak": round(3 * achieved / PEAK_BF16_DENSE_TFLOPS, 4),
-                           "per_kernel_ms": {k: round(v[0], 3) for k, v in prof.items() if v[1]},
-                           "per_model": per_model,
                            "per_model_note": "GEMMs of one classifier: algorithmic FLOP per algorithmic byte against the ridge of the ISSUED "
                                              "work (3 MFMA passes per product at 2.5 PF dense / 8 TB/s = 104 FLOP/B); frac_of_bound = issued "
-                                             "MFMA fraction of peak where MFMA-bound, algorithmic GB/s of 8 TB/s where HBM-bound"}
+                                             "MFMA fraction of peak where MFMA-bound, algorithmic GB/s of 8 TB/s where HBM-bound "
+                                             "(top-level per_model_* keys)"}
 
     # ---- the boundary itself: Annotator.preprocess -> predict -> export_annotations from host files ------------------------
     if not args.no_dropin and rank == 0 and world == 1 and not args.impute:
@@ -338,6 +411,16 @@ def main():
         print(json.dumps(out))
     if world > 1:
         tdist.destroy_process_group()
+
+
+def lib_sha256():
+    """sha256 of the libribca_hip.so being timed (the committed counter files are stamped with the one they were measured on)"""
+    import hashlib
+    from multiplexed_image_annotator_amd import _lib
+    try:
+        return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+    except OSError:
+        return None
 
 
 def config1_bench(args):

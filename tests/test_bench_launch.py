@@ -29,6 +29,29 @@ def test_gpus2_launches_two_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     out = _last_json(r.stdout)
     assert out["n_gpus"] == 2 and out["gather_ok"] is True
+    # what makes a future 8-GPU line checkable: the backend and the world size THE COLLECTIVE saw, its time and payload
+    coll = out["collective"]
+    assert coll["backend"] == "gloo" and coll["world_size_seen"] == 2
+    assert coll["allgather_ms_per_step"] > 0 and coll["bytes_per_rank"] == 501 * 33 * 4      # rank 0's shard of 1001 rows x 33 floats
+
+
+def test_parent_counts_gpus_without_hip(monkeypatch):
+    """the launcher parent must not initialise the GPU: devices are counted from the environment or the kfd topology"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    assert mod.visible_gpu_count() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert mod.visible_gpu_count() == 0
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    assert mod.visible_gpu_count() >= 0          # sysfs path: no exception without /sys/class/kfd
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def launch_ranks"):src.index("def launch_check")]
+    assert "torch.cuda" not in body
 
 
 def test_gpus1_stays_in_process():

@@ -63,7 +63,25 @@ if launches:
         other[k.split("(")[0].replace("void ribca::", "")[:90]] = {
             "launches": fetch[k][1], "bytes_per_launch": (2.0 * fetch[k][0] + write.get(k, [0.0, 0])[0]) * 1024.0 / fetch[k][1]}
     res["other_kernels"] = other
-dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "prof_" + tag)
+import hashlib
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+try:
+    res["lib_sha256"] = hashlib.sha256(open(os.path.join(root, "multiplexed-image-annotator_amd", "libribca_hip.so"), "rb").read()).hexdigest()
+except OSError:
+    res["lib_sha256"] = None
+# every kernel of the ViT forward (GEMMs, attention, statistics / LayerNorm, embed, head): counter bytes per CELL of the reduced pass
+vit = [k for k in fetch if "ribca::" in k and any(t in k for t in ("gemm_ps_", "attention", "layernorm", "row_stats", "ln_finalize", "embed_f32", "head_softmax", "cls_rows"))]
+n_cells_line = None
+try:
+    n_cells_line = json.load(open(os.path.join(out, "fetch.json")))["config"]["cells"]
+except Exception:
+    pass
+if n_cells_line:
+    vb = sum((2.0 * fetch[k][0] + write.get(k, [0.0, 0])[0]) * 1024.0 for k in vit)
+    res["vit_bytes_per_cell"] = vb / n_cells_line
+    res["vit_bytes_per_cell_by_kernel"] = {k.split("(")[0].replace("void ribca::", "")[:80]: (2.0 * fetch[k][0] + write.get(k, [0.0, 0])[0]) * 1024.0 / n_cells_line for k in vit}
+    res["cells_in_counter_pass"] = n_cells_line
+dst = os.path.join(root, "gpurun_out", "prof_" + tag)
 os.makedirs(dst, exist_ok=True)
 with open(os.path.join(dst, "gemm_traffic.json"), "w") as f:
     json.dump(res, f, indent=1)
