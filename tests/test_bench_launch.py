@@ -32,7 +32,7 @@ def test_gpus2_launches_two_ranks():
     # what makes a future 8-GPU line checkable: the backend and the world size THE COLLECTIVE saw, its time and payload
     coll = out["collective"]
     assert coll["backend"] == "gloo" and coll["world_size_seen"] == 2
-    assert coll["allgather_ms_per_step"] > 0 and coll["bytes_per_rank"] == 501 * 33 * 4      # rank 0's shard of 1001 rows x 33 floats
+    assert coll["allgather_ms_per_step"] > 0 and coll["bytes_per_rank"] == 500 * 33 * 4      # rank 0 holds rows [0, 500) of 1001, 33 floats each
 
 
 def test_parent_counts_gpus_without_hip(monkeypatch):
