@@ -506,9 +506,12 @@ def _config3_inputs(dev, n_cells=100000, seed_offset=3, markers_last=None):
 
 
 def test_config3_parity_audit_2000_cells():
-    """at BASELINE config 3's inputs, 2000 cells spread over the tile through ALL FIVE full-depth classifiers
-    against the fp32 CPU oracle: cell-type argmax identical, max |dp| under the north-star 1e-3 (and under the 2e-5 this path
-    holds), plus the top-2 margin histogram of the synthetic weights that SURVEY 8(d) asks to report."""
+    """at BASELINE config 3's inputs, 2000 cells spread over the tile through ALL FIVE full-depth
+    classifiers against the fp32 CPU oracle: cell-type argmax identical, max |dp| under the north-star 1e-3 (and under E2E_TOL),
+    plus the top-2 margin histogram SURVEY 8(d) asks to report.  "Identical labels" must have teeth on every model: each head is
+    calibrated on the oracle's own features (synth.calibrate_head_bias, as test_config2_matches_oracle does) with a softer head
+    (gain 1.5 instead of 4) so that every model uses >= 3 classes (nerve: its 2) and >= 20 of the 2000 cells are undecided to
+    within 1e-2 -- both asserted."""
     from multiplexed_image_annotator_amd import _lib, ops
     from oracle import ref_vit
     dev = _lib.require_gpu()
@@ -523,9 +526,12 @@ def test_config3_parity_audit_2000_cells():
     report = {}
     edges = [0.0, 1e-4, 1e-3, 1e-2, 0.1, 0.3, 0.6, 1.0001]
     for name, (d, c, k) in synth.VIT_CONFIGS.items():
-        sd = synth.make_vit_state_dict(name, seed)
+        sd = synth.make_vit_state_dict(name, seed, head_gain=1.5)
+        with torch.no_grad():
+            feat = torch.cat([ref_vit.forward_features(sd, x_cpu[i:i + 128, :c]) for i in range(0, len(sel), 128)])
+            sd["head.bias"] = synth.calibrate_head_bias(sd, feat[:256])
+            ref = torch.softmax(torch.nn.functional.linear(feat, sd["head.weight"], sd["head.bias"]), dim=1)      # = ref_vit.predict_proba
         got = ops.VitModel(sd, dev).predict_proba(patches, list(range(c)), chunk_cells=1024, streams=3).cpu()
-        ref = ref_vit.predict_proba(sd, x_cpu[:, :c], 128)
         err = (got - ref).abs().max().item()
         srt = ref.sort(dim=1, descending=True).values
         margin = (srt[:, 0] - srt[:, 1]).numpy()
@@ -535,6 +541,8 @@ def test_config3_parity_audit_2000_cells():
                         "margin_hist": hist, "classes_used": int(len(torch.unique(ref.argmax(1))))}
         print(f"[parity audit] {name}: 2000 cells, max|dp| {err:.2e}, flips {flips}, top-2 margin min {margin.min():.2e} hist {hist}")
         assert flips == 0, (name, flips)
+        assert report[name]["classes_used"] >= min(3, k), (name, report[name]["classes_used"])      # the audit is not vacuous:
+        assert int((margin < 1e-2).sum()) >= 20, (name, int((margin < 1e-2).sum()))                  # close calls exist on every model
         assert err < 1e-3, (name, err)          # north star
         assert err < E2E_TOL, (name, err)       # fp32 summation-order floor of real patches (E2E_TOL)
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
