@@ -54,8 +54,10 @@ def _setup():
 
 
 def _pipeline(annotator, bs, n_regions):
-    """The call sequence of reference main.py:19-28 / 43-52, verbatim.  Its plotting calls (generate_heatmap,
-    cell_type_composition) are outside the accelerated path: this Annotator logs and skips them."""
+    """The call sequence of reference main.py:19-28 / 43-52: the CSV is exported ONCE, before the tissue-region analysis, so its
+    "Tissue Region" column reads None exactly as the reference's does (RIBCA_EXPORT_REGIONS=1 opts in to a second export that
+    carries the regions).  Two guards the reference lacks keep small images from raising inside its k-NN queries.  Its plotting
+    calls (generate_heatmap, cell_type_composition) are outside the accelerated path: this Annotator logs and skips them."""
     p = annotator.channel_parser
     if not p.immune_base and not p.immune_extended and not p.immune_full and not p.struct and not p.nerve:
         raise ValueError("No panels are applied. Please check the marker list.")
@@ -66,7 +68,8 @@ def _pipeline(annotator, bs, n_regions):
     n_cells = min((len(ids) for ids in annotator.preprocessor.cell_ids), default=0)
     if n_regions > 0 and n_cells >= 201:           # the reference's 201-neighbour query raises on smaller images
         annotator.tissue_region_analysis(n_regions)
-        annotator.export_annotations()              # so that the CSV carries the Tissue Region column the analysis just produced
+        if os.environ.get("RIBCA_EXPORT_REGIONS") == "1":      # opt-in deviation: the reference's CSV never carries the regions
+            annotator.export_annotations()
     if n_cells >= 25:                               # the reference's kNN (25 neighbours) raises on smaller images
         annotator.neighborhood_analysis(integrate=True, normalize=True)
     annotator.colorize(from_script=True)

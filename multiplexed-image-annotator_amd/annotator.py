@@ -333,6 +333,10 @@ class Annotator(object):
             # 0.5360000133514404) and the int -1 of a thresholded cell as "-1".  Same text, rounded and widened in one numpy call
             # instead of 100 k Python round() calls when the confidences are still the float32 table predict() produced.
             arr = self._conf_arrays[i] if i < len(getattr(self, "_conf_arrays", [])) and len(self._conf_arrays[i]) == len(conf) else None
+            # ``confidence`` is public state (the reference's own _find_extra_cell_types edits it after predict()): the cached table is
+            # only used while it still says the same thing
+            if arr is not None and not np.array_equal(arr, np.asarray(conf, dtype=np.float32)):
+                arr = None
             if arr is not None:
                 conf_txt = ["-1" if v == -1.0 else repr(v) for v in np.round(arr, 3).tolist()]
             else:

@@ -3,11 +3,16 @@
 // Numerics ("fp16x3"): every matrix product on the path runs on the 16-bit matrix cores with each fp32 operand split as
 // x = hi + lo (hi = fp16(x), lo = fp16(x - hi)) and three MFMA passes
 //     acc += hi_a*hi_b ; acc += lo_a*hi_b ; acc += hi_a*lo_b        (fp32 accumulate)
-// which carries ~22 mantissa bits per operand (the dropped lo*lo term is 2^-22 relative).  A single bf16 or fp16 pass misses
+// which carries ~22 mantissa bits per operand WHILE lo IS A NORMAL fp16, i.e. for |x| >= 2^-3: hi keeps 11 bits, lo (|lo| <= 2^-11 |x|)
+// another 11.  Below that lo is subnormal (quantum 2^-24) and the split's error is ABSOLUTE, <= 2^-25 -- about 20 bits at the 0.02
+// scale of typical weights, still 2^-25 / |x| relative.  The dropped lo*lo term is 2^-22 relative.  A single bf16 or fp16 pass misses
 // the reference's 1e-3 confidence tolerance by 3-16x after 12 blocks; the round-1 bf16 split (16 bits) met it with 30x margin;
 // the fp16 split costs the same three v_mfma_f32_16x16x32 passes and the same 4 bytes per element and is ~5x closer to the
 // fp32 reference (tests/precision_study.py): max |dp| 4-6e-6 instead of 2-2.5e-5.
-// Range: fp16 saturates at 65504, so values are clamped to +-65504 before the split (no inf / NaN can enter an MFMA); lo is
+// Range: fp16 saturates at 65504, so values are clamped to +-65504 before the split: no inf can enter an MFMA, but an operand beyond
+// that range SATURATES SILENTLY (and v_med3 maps a NaN operand to a finite value): the result is then finite and wrong rather than
+// inf / NaN as in the fp32 reference.  Residual-stream values, LayerNorm outputs, GELU outputs and weights of a trained ViT sit
+// orders of magnitude below (tests/test_gpu_kernels.py::test_split_operand_range pins the behaviour at 3e4 and beyond 65504).  lo is
 // usually SUBNORMAL in fp16 (|lo| <= 2^-12 |x|): v_mfma_f32_16x16x32_f16 and the VALU keep fp16 subnormals on gfx950
 // (tools/f16_probe.hip: exact), and lo of a subnormal-range hi is exactly zero.
 //

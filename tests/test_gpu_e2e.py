@@ -84,6 +84,11 @@ def test_annotator_matches_reference_golden(golden_dir, tmp_path, name):
     a.neighborhood_analysis(n_neighbors=25, integrate=True, normalize=True)
     assert open(tmp_path / "results" / "g_integrated_neighborhood.csv").read() == gn[f"{name}__k25"]
     csv_equal_up_to_conf(open(tmp_path / "results" / "g_annotation_0.csv").read(), meta["csv"], 1.5e-3)
+    # ``confidence`` is public state: an edit after predict() (the reference's _find_extra_cell_types sets entries to -1) reaches the CSV
+    first = next(j for j, c in enumerate(a.confidence[0]) if c != -1)
+    a.confidence[0][first] = -1
+    a.export_annotations()
+    assert open(tmp_path / "results" / "g_annotation_0.csv").read().splitlines()[1 + first].split(",")[2] == "-1"
     # pixel lists of the lazy cell_pos_dict agree with the mask
     key = meta["cell_ids"][3]
     r, c = a.preprocessor.cell_pos_dict[0][key]

@@ -127,6 +127,41 @@ def test_gemm_gelu(dev, m, n, k):
     assert err < 2e-5, err
 
 
+def test_split_operand_range(dev):
+    """the fp16 hi+lo split has a range the bf16 split did not.  (a) activations of 1e3 ... 3e4 against small weights and
+    (b) weights of 1e-5 (lo subnormal: absolute 2^-25 error per operand) still match fp64 to the documented precision;
+    (c) an operand beyond 65504 saturates SILENTLY at +-65504 (finite, wrong by construction) -- pinned so that a change is noticed."""
+    from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
+    m, n, k = 300, 288, 288
+    kp = k
+    for tag, a_scale, w_scale in (("large activations", 1.0e4, 1e-3), ("tiny weights", 1.0, 1e-5)):
+        a = rnd((m, k), 70, dev, a_scale)
+        w = rnd((n, k), 71, dev, w_scale)
+        bias = torch.zeros(n, device=dev)
+        z = torch.zeros((m, n), device=dev)
+        check(lib().ribca_test_gemm(0, ptr(ps_encode(a, kp)), 2 * kp, ptr(ps_encode(w, kp, lib().ribca_gemm_padded_n(n))), 2 * kp, m, n, kp, ptr(bias),
+                                    ptr(z), n, stream_ptr()), "gemm")
+        ref = a.double() @ w.double().t()
+        mag = a.double().abs() @ w.double().abs().t()
+        # per product: 2^-22 relative (dropped lo*lo) + the operands' split error: relative 2^-23 where lo is normal, absolute 2^-25 below
+        bound = mag * 2.0 ** -20 + (a.double().abs().sum(1, keepdim=True) * 2.0 ** -25 + 2.0 ** -25 * w.double().abs().sum(1)[None, :]) + 1e-12
+        err = ((z.double() - ref).abs() / bound).max().item()
+        note_err(f"split operand range: {tag} (error / bound)", err)
+        assert err < 1.0, (tag, err)
+    a = rnd((m, k), 72, dev, 1.0)
+    a[:, 0] = 1.0e6                                  # beyond fp16: clamps to 65504
+    w = rnd((n, k), 73, dev, 0.05)
+    bias = torch.zeros(n, device=dev)
+    z = torch.zeros((m, n), device=dev)
+    check(lib().ribca_test_gemm(0, ptr(ps_encode(a, kp)), 2 * kp, ptr(ps_encode(w, kp, lib().ribca_gemm_padded_n(n))), 2 * kp, m, n, kp, ptr(bias), ptr(z), n,
+                                stream_ptr()), "gemm")
+    assert torch.isfinite(z).all()
+    a_sat = a.clone()
+    a_sat[:, 0] = 65504.0
+    ref = a_sat.double() @ w.double().t()
+    assert ((z.double() - ref).abs() / (1.0 + ref.abs())).max().item() < 1e-5
+
+
 def _ln_case(m, d, seed, dev, mean=0.5, std=3.0, row_scale=False):
     """rows of a packed-split residual stream with a chosen mean / spread, their exact (fp64) decode, LayerNorm parameters"""
     z = rnd((m, d), seed, dev, std) + mean
