@@ -148,13 +148,25 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
 
 // ---------------------------------------------------------------------------------------------- LDS-staged form (classifiers)
 // The kernel above is bound by its dependent chain (Q load -> MFMA -> softmax -> V^T loads from L2 -> MFMA -> store) at 1-3
-// waves/SIMD: K fragments of all 112 keys live in registers (114-296 VGPRs).  Here K and V^T of one (cell, head) are copied
+// waves/SIMD: K fragments of all 112 keys live in registers (114-296 VGPRs).  Here K and V of one (cell, head) are copied
 // ONCE into LDS (direct-to-LDS loads, 13-45 KB), WPP waves share them and split the query tiles (tile qt belongs to wave
 // qt % WPP), every fragment read is an LDS read of ~100 cycles, and the next query tile's Q fragments are prefetched while
 // the current tile is processed.  Same arithmetic, same operation order per query row as above -> identical results.
+//
+// V arrives ROW-MAJOR, [token][2 * hdq] packed-split rows exactly like K (the qkv epilogue then writes whole row segments instead of
+// sixteen 2-byte pieces per value), and is transposed on the way out of LDS: O^T = V^T P^T needs, in lane (d = lane & 15, g), the 8
+// keys {32 t + 4 g + r, 32 t + 16 + 4 g + r} of head dim 16 dt + d.  ds_read_b64_tr_b16 hands the 16 lanes of group g a 4-row x
+// 16-column block of 16-bit elements column-major (lane 4q + p supplies the address of row q, columns 4p .. 4p + 3; lane i receives
+// column i of the four rows): one read per key quartet, hi and lo halves separately = 4 reads per (dt, t) where the V^T form had two
+// 16-byte ones.  Rows 101 .. 111 are zero in memory (never written), rows 112 .. 127 are zeroed in LDS: their P is exactly 0.
+typedef __attribute__((__vector_size__(4 * sizeof(_Float16)))) _Float16 f16x4;
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4;
+__device__ __forceinline__ f16x4 lds_read_tr16(const char* p) {
+  return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p)));
+}
 template <int HD, int NT, int WPP>
 __global__ __launch_bounds__(64 * WPP) void attention_lds_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K,
-                                                                 const uint16_t* __restrict__ Vt, uint16_t* __restrict__ out, int ldo,
+                                                                 const uint16_t* __restrict__ V, uint16_t* __restrict__ out, int ldo,
                                                                  int H, int T, int q_tiles) {
   constexpr int KS = (HD + 31) / 32;
   constexpr int DT = (HD + 15) / 16;
@@ -164,11 +176,12 @@ __global__ __launch_bounds__(64 * WPP) void attention_lds_kernel(const uint16_t*
   constexpr int TP = 16 * NT;
   constexpr int ROW = 2 * hdq;                       // 16-bit elements per Q/K row
   constexpr int ngrp = hdq >> 3;
-  constexpr int VROW = 2 * 32 * KST;                 // 16-bit elements per V^T row
-  constexpr int K_BYTES = TP * ROW * 2;
-  constexpr int V_BYTES = hd * VROW * 2;             // only the hd real rows
+  constexpr int ROWB = ROW * 2;                      // bytes per Q / K / V row
+  constexpr int K_BYTES = TP * ROWB;
   constexpr int K_LDS = (K_BYTES + 1023) / 1024 * 1024;
-  constexpr int V_LDS = (V_BYTES + 1023) / 1024 * 1024;
+  constexpr int V_DMA = K_LDS;                       // V has K's shape: the same 1 KB pieces
+  constexpr int V_ROWS = 32 * KST;                   // keys the P V product runs over (128): rows >= TP are zeroed here
+  constexpr int V_LDS = ((V_ROWS * ROWB > V_DMA ? V_ROWS * ROWB : V_DMA) + 64 * DT + 15) / 16 * 16;   // + the overshoot of dims >= hdq in the last row
   __shared__ __attribute__((aligned(16))) char lds[K_LDS + V_LDS];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -177,24 +190,22 @@ __global__ __launch_bounds__(64 * WPP) void attention_lds_kernel(const uint16_t*
   const int r16 = lane & 15, g = lane >> 4;
   const uint16_t* qb = Q + (size_t)pair * TP * ROW;
   const char* kb = reinterpret_cast<const char*>(K + (size_t)pair * TP * ROW);
-  const char* vb = reinterpret_cast<const char*>(Vt + (size_t)pair * (DT * 16) * VROW);
+  const char* vb = reinterpret_cast<const char*>(V + (size_t)pair * TP * ROW);
 
-  // ---- stage K and V^T: 1 KB per wave instruction, linear
+  // ---- stage K and V: 1 KB per wave instruction, linear.  (Behind V's rows: zeros, written before the copies are issued; the tail
+  // piece of the copy re-reads the last chunk of row TP - 1, a pad token row that is zero in memory, so both leave zeros.)
+  for (int o = K_BYTES / 1024 * 1024 + threadIdx.x * 16; o < V_LDS; o += 64 * WPP * 16)
+    *reinterpret_cast<uint4*>(lds + K_LDS + o) = uint4{0u, 0u, 0u, 0u};
+  __syncthreads();
   for (int i = wave; i < K_LDS / 1024; i += WPP) {
     int off = i * 1024 + lane * 16;
     off = off < K_BYTES ? off : K_BYTES - 16;        // the tail instruction re-reads the last chunk into LDS padding
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + off),
                                      (__attribute__((address_space(3))) void*)(lds + i * 1024), 16, 0, 0);
   }
-  // V^T rows are 512 bytes = a whole number of bank rows: the 16 rows of a fragment read would all hit the same banks.  The
-  // copy is linear in LDS, so the XOR swizzle (32-byte hi|lo pair p of row r lives at pair p ^ (r & 15)) is applied to the
-  // global source address of each lane.
-  static_assert(VROW * 2 == 512, "V^T row pitch");
-  for (int i = wave; i < V_LDS / 1024; i += WPP) {
-    const int o = i * 1024 + lane * 16;
-    const int row = o >> 9, c = (o & 511) >> 4;
-    int off = row * 512 + ((((c >> 1) ^ (row & 15)) << 1) | (c & 1)) * 16;
-    off = o < V_BYTES ? off : V_BYTES - 16;
+  for (int i = wave; i < V_DMA / 1024; i += WPP) {
+    int off = i * 1024 + lane * 16;
+    off = off < K_BYTES ? off : K_BYTES - 16;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb + off),
                                      (__attribute__((address_space(3))) void*)(lds + K_LDS + i * 1024), 16, 0, 0);
   }
@@ -281,12 +292,12 @@ __global__ __launch_bounds__(64 * WPP) void attention_lds_kernel(const uint16_t*
       f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int t = 0; t < KST; ++t) {
-        uint4 h4 = {0u, 0u, 0u, 0u}, l4 = {0u, 0u, 0u, 0u};
-        if (dt * 16 + 15 < hd || dt * 16 + r16 < hd) {
-          const uint4* p = reinterpret_cast<const uint4*>(vl + (dt * 16 + r16) * (VROW * 2) + (((4 * t + g) ^ r16) << 5));   // row & 15 == r16
-          h4 = p[0]; l4 = p[1];
-        }
-        const f16x8 vhi = __builtin_bit_cast(f16x8, h4), vlo = __builtin_bit_cast(f16x8, l4);
+        // lane 4q + p of its 16-lane group: row (key) 32 t + 4 g + q, columns (dims) 16 dt + 4p .. + 3 of the hi halves; + 16 bytes: lo
+        const char* va = vl + (32 * t + 4 * g + (r16 >> 2)) * ROWB + (2 * dt + ((r16 & 3) >> 1)) * 32 + (r16 & 1) * 8;
+        const f16x4 h0 = lds_read_tr16(va), l0 = lds_read_tr16(va + 16);
+        const f16x4 h1 = lds_read_tr16(va + 16 * ROWB), l1 = lds_read_tr16(va + 16 * ROWB + 16);
+        const f16x8 vhi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        const f16x8 vlo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
         o = mfma_f16(vlo, phi[t], o);
         o = mfma_f16(vhi, plo[t], o);
         o = mfma_f16(vhi, phi[t], o);
@@ -319,8 +330,7 @@ void launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, 
   if (q_tiles <= 0 || q_tiles > a.NT) q_tiles = a.NT;
   const int pairs = cells * a.H;
   if (pairs <= 0) return;
-  static const int lds_form = getenv("RIBCA_ATTN_REGS") ? 0 : 1;     // A/B switch: the register-resident form above
-  if (lds_form && a.NT == 7) {
+  if (a.NT == 7) {
 #define RIBCA_ATT_LDS(HD_, WPP_) \
   hipLaunchKernelGGL((attention_lds_kernel<HD_, 7, WPP_>), dim3(pairs), dim3(64 * WPP_), 0, s, q, k, vt, out, ldo, a.H, a.T, q_tiles)
     // 4 waves per (cell, head) measured 2 % faster than 2 (871.6 vs 887.6 ms per pass over the five classifiers)
@@ -333,15 +343,15 @@ void launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, 
   const dim3 grid((pairs + 3) / 4), block(256);
 #define RIBCA_ATT(HD_, NT_) \
   hipLaunchKernelGGL((attention_kernel<HD_, NT_>), grid, block, 0, s, q, k, vt, out, ldo, pairs, a.H, a.T, q_tiles)
-  if (a.NT == 7 && a.hd == 12) RIBCA_ATT(12, 7);
-  else if (a.NT == 7 && a.hd == 24) RIBCA_ATT(24, 7);
-  else if (a.NT == 7 && a.hd == 32) RIBCA_ATT(32, 7);
-  else if (a.NT == 7 && a.hd == 48) RIBCA_ATT(48, 7);
-  else if (a.NT == 1 && a.hd == 64) RIBCA_ATT(64, 1);
+  if (a.NT == 1 && a.hd == 64) RIBCA_ATT(64, 1);
   else abort();   // geometry is validated by the C ABI before any launch
 #undef RIBCA_ATT
 }
 
+bool attention_v_rowmajor(const AttnGeom& a) { return a.NT == 7; }
+size_t attention_v_elems(const AttnGeom& a, int cells) {
+  return attention_v_rowmajor(a) ? (size_t)cells * a.H * a.TP * 2 * a.hdq : (size_t)cells * a.H * a.hdv * 2 * a.KP;
+}
 bool attention_supported(const AttnGeom& a) {
   return (a.NT == 7 && (a.hd == 12 || a.hd == 24 || a.hd == 32 || a.hd == 48)) || (a.NT == 1 && a.hd == 64);
 }

@@ -159,6 +159,10 @@ struct EpiQKVT {
   int nt = 0;
   unsigned magicT = 0;   // ceil(2^32 / T): m / T as one v_mul_hi + a fix-up (the epilogue does one such division per output row)
   const float2* rowstat = nullptr; const float* csum = nullptr;     // FOLD only
+  // vrow != 0: V is stored like K -- row-major packed-split rows [cell][head][TP][2 * hdq] in `vt` -- and the attention kernel
+  // transposes it on the way out of LDS (ds_read_b64_tr_b16): every tile of the product then takes the row-contiguous LDS drain,
+  // none the sixteen 2-byte scattered stores per value of the V^T form (15 % of the qkv launch)
+  int vrow = 0;
   struct Ctx {};
   // row / column decompositions are computed once per accumulator row (4) and column group (TN), not once per tile
   struct Row { int cell, t, vpos; };
@@ -187,7 +191,7 @@ struct EpiQKVT {
     return (bias != nullptr && n < N) ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
   }
   __device__ __forceinline__ EpiQKVT<false> plain() const {
-    return EpiQKVT<false>{q, k, vt, nullptr, D, hd, hdp, hdv, scale, M, N, T, TP, H, KP, nt, magicT};
+    return EpiQKVT<false>{q, k, vt, nullptr, D, hd, hdp, hdv, scale, M, N, T, TP, H, KP, nt, magicT, nullptr, nullptr, vrow};
   }
   __device__ __forceinline__ void fetch(int, int, Ctx&) const {}
   template <int PX = 16>
@@ -197,12 +201,12 @@ struct EpiQKVT {
     const float4 xf = ln_fold4<FOLD>(v, b, cs, rs);
     float x[4] = {xf.x, xf.y, xf.z, xf.w};
     const size_t ch = (size_t)r.cell * H + c.head;
-    if (c.which < 2) {
+    if (c.which < 2 || vrow) {
       if (c.which == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) x[i] *= scale;
       }
-      uint16_t* rowp = (c.which == 0 ? q : k) + (ch * TP + r.t) * (size_t)(2 * hdp);
+      uint16_t* rowp = (c.which == 0 ? q : c.which == 1 ? k : vt) + (ch * TP + r.t) * (size_t)(2 * hdp);
       if ((hd & 7) == 0) ps_store4_pair<PX>(rowp, c.d, x, nt != 0);   // the partner lane's 4 columns are in the same head
       else ps_store4(rowp, c.d, x);
     } else {

@@ -59,7 +59,7 @@ __device__ __forceinline__ unsigned long long stamp_now() { return __builtin_amd
 // the GELU / split work is spread over 768 threads, and a chunk's PS partner (the other 4 columns of its 8-group) is the
 // neighbouring lane.  A V tile of the qkv product scatters 2-byte elements along V^T rows and keeps the register path.
 template <class Epi> __device__ __forceinline__ bool lepi_tile_uses_registers(const Epi&, int, int) { return false; }
-template <> __device__ __forceinline__ bool lepi_tile_uses_registers<EpiQKV>(const EpiQKV& e, int n0, int bn) { return n0 + bn > 2 * e.D; }
+template <> __device__ __forceinline__ bool lepi_tile_uses_registers<EpiQKV>(const EpiQKV& e, int n0, int bn) { return !e.vrow && n0 + bn > 2 * e.D; }
 
 
 template <class Epi> __device__ __forceinline__ auto lepi_plain(const Epi& e) {
@@ -893,13 +893,13 @@ void launch_gemm_gelu_ln(const GemmArgs& g, const float2* rowstat, const float* 
 void launch_gemm_qkv_ln(const GemmArgs& g, const float2* rowstat, const float* csum, uint16_t* q, uint16_t* k, uint16_t* vt, const AttnGeom& a,
                         float scale, hipStream_t s) {
   launch_any(g, EpiQKVLn{q, k, vt, g.bias, a.D, a.hd, a.hdq, a.hdv, scale, g.M, g.N, a.T, a.TP, a.H, a.KP, (nt_mask() >> 1) & 1,
-                         (unsigned)((0x100000000ull + (unsigned long long)a.T - 1) / (unsigned long long)a.T), rowstat, csum}, s);
+                         (unsigned)((0x100000000ull + (unsigned long long)a.T - 1) / (unsigned long long)a.T), rowstat, csum, attention_v_rowmajor(a) ? 1 : 0}, s);
 }
 int gemm_resid_tiles(int N) { return gemm_padded_n(N) / gemm_pick_bn(N); }
 int gemm_resid_bn(int N) { return gemm_pick_bn(N); }
 void launch_gemm_qkv(const GemmArgs& g, uint16_t* q, uint16_t* k, uint16_t* vt, const AttnGeom& a, float scale, hipStream_t s) {
   launch_any(g, EpiQKV{q, k, vt, g.bias, a.D, a.hd, a.hdq /* Q/K row pitch: compact */, a.hdv, scale, g.M, g.N, a.T, a.TP, a.H, a.KP, (nt_mask() >> 1) & 1,
-                       (unsigned)((0x100000000ull + (unsigned long long)a.T - 1) / (unsigned long long)a.T)}, s);
+                       (unsigned)((0x100000000ull + (unsigned long long)a.T - 1) / (unsigned long long)a.T), nullptr, nullptr, attention_v_rowmajor(a) ? 1 : 0}, s);
 }
 void launch_gemm_rowmap(const GemmArgs& g, float* out, int ldo, const float* add, int ldadd, const int* slot, const int* addrow, int R,
                         int dst_per_cell, hipStream_t s) {

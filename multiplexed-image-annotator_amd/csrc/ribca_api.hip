@@ -231,7 +231,7 @@ BlockWs carve_blocks(Carver& c, int cells, const AttnGeom& a, bool fold = false)
   w.qk_bytes = qk * sizeof(uint16_t);
   w.q = c.take<uint16_t>(qk);
   w.k = c.take<uint16_t>(qk);
-  const size_t vt = (size_t)cells * a.H * a.hdv * 2 * a.KP;
+  const size_t vt = attention_v_elems(a, cells);
   w.vt_bytes = vt * sizeof(uint16_t);
   w.vt = c.take<uint16_t>(vt);
   w.h = c.take<uint16_t>(Mc * 2 * 4 * a.D);

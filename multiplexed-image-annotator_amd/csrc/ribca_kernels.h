@@ -42,6 +42,10 @@ struct AttnGeom {
 };
 AttnGeom make_attn_geom(int D, int H, int T);
 bool attention_supported(const AttnGeom& a);
+// true: the attention kernel for this geometry reads V ROW-MAJOR, [cell][head][TP][2 * hdq] like K (the 101-token classifiers: LDS-staged
+// kernel with transposing LDS reads); false: V^T [cell][head][hdv][2 * KP] in fragment order (the imputer's <= 16-token problems)
+bool attention_v_rowmajor(const AttnGeom& a);
+size_t attention_v_elems(const AttnGeom& a, int cells);   // 16-bit elements of the V operand buffer for `cells` cells
 // qkv: scatter into per-head attention operands (Q pre-scaled by hd^-0.5, V transposed + key-permuted)
 void launch_gemm_qkv(const GemmArgs& g, uint16_t* q, uint16_t* k, uint16_t* vt, const AttnGeom& a, float scale, hipStream_t s);
 // fp32 output through a per-cell row map (imputer embeddings / predictions), see EpiRowMap
@@ -51,7 +55,7 @@ void launch_gemm_rowmap(const GemmArgs& g, float* out, int ldo, const float* add
                         int dst_per_cell, hipStream_t s);
 
 // ----- attention (attention.hip) ---------------------------------------------------------------------------
-// q,k: [cells][H][TP][2*hdp]  vt: [cells][H][hdv][2*KP]  out: packed-split [cells*T][ldo]
+// q,k: [cells][H][TP][2*hdq]  vt: V operand, layout per attention_v_rowmajor()  out: packed-split [cells*T][ldo]
 // q_tiles > 0 restricts the QUERY rows to the first q_tiles 16-token tiles (keys/values are always complete)
 void launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int ldo, int cells, const AttnGeom& a,
                       hipStream_t s, int q_tiles = 0);

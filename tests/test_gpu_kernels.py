@@ -363,7 +363,7 @@ def test_qkv_attention_fold(dev, d, cells, mean, std):
     rs = _row_stats(z_ps, dp, m, d, dev)
     q = torch.zeros((cells, heads, 112, 2 * hdp), dtype=torch.int16, device=dev)
     k = torch.zeros_like(q)
-    vt = torch.zeros((cells, heads, hdv, 256), dtype=torch.int16, device=dev)
+    vt = torch.zeros_like(q)
     out = torch.zeros((m, 2 * dp), dtype=torch.int16, device=dev)
     check(lib().ribca_test_qkv_attention_fold(ptr(z_ps), 2 * dp, ptr(w_ps), 2 * dp, cells, d, dp, ptr(bias2), ptr(csum), ptr(rs), ptr(q), ptr(k),
                                               ptr(vt), ptr(out), 2 * dp, stream_ptr()), "qkv fold")
@@ -397,13 +397,13 @@ def test_qkv_attention(dev, d, cells):
     w_ps = ps_encode(w, dp, lib().ribca_gemm_padded_n(3 * d))
     q = torch.zeros((cells, heads, 112, 2 * hdp), dtype=torch.int16, device=dev)
     k = torch.zeros_like(q)
-    vt = torch.zeros((cells, heads, hdv, 256), dtype=torch.int16, device=dev)
+    vt = torch.zeros_like(q)
     out = torch.zeros((m, 2 * dp), dtype=torch.int16, device=dev)
     check(lib().ribca_test_qkv_attention(ptr(y_ps), 2 * dp, ptr(w_ps), 2 * dp, cells, d, dp, ptr(bias), ptr(q), ptr(k), ptr(vt),
                                          ptr(out), 2 * dp, stream_ptr()), "qkv+attention")
     qkv = (y.double() @ w.double().t() + bias.double()).reshape(cells, ntok, 3, heads, hd).permute(2, 0, 3, 1, 4)
     qq, kk, vv = qkv[0], qkv[1], qkv[2]
-    # intermediate layouts first (localises a failure): Q rows pre-scaled, K rows, V transposed + key-permuted
+    # intermediate layouts first (localises a failure): Q rows pre-scaled, K rows, V rows
     qd = ps_decode(q.reshape(-1, 2 * hdp), hdp).reshape(cells, heads, 112, hdp)
     kd = ps_decode(k.reshape(-1, 2 * hdp), hdp).reshape(cells, heads, 112, hdp)
     def close(got, ref):   # stored as hi+lo fp16 (2^-23 relative) + fp32 accumulation of K <= 576 products (measured <= 2.6e-6 relative to 1 + |ref|)
@@ -411,11 +411,10 @@ def test_qkv_attention(dev, d, cells):
     assert close(qd[:, :, :ntok, :hd], qq * hd ** -0.5)
     assert close(kd[:, :, :ntok, :hd], kk)
     assert torch.all(qd[:, :, ntok:] == 0) and torch.all(qd[..., hd:] == 0)
-    t = torch.arange(128)
-    pos = (t & ~31) | (((t >> 2) & 3) << 3) | (((t >> 4) & 1) << 2) | (t & 3)
-    vd = ps_decode(vt.reshape(-1, 256), 128).reshape(cells, heads, hdv, 128)
-    vd_nat = vd[..., pos.to(dev)]          # natural key order
-    assert close(vd_nat[:, :, :hd, :ntok], vv.transpose(-1, -2))
+    # V is stored row-major like K (the attention kernel transposes it out of LDS); pad rows / dims stay zero
+    vd = ps_decode(vt.reshape(-1, 2 * hdp), hdp).reshape(cells, heads, 112, hdp)
+    assert close(vd[:, :, :ntok, :hd], vv)
+    assert torch.all(vd[:, :, ntok:] == 0) and torch.all(vd[..., hd:] == 0)
     att = torch.softmax((qq * hd ** -0.5) @ kk.transpose(-1, -2), dim=-1)
     ref = (att @ vv).transpose(1, 2).reshape(m, d)
     err = (ps_decode(out, d) - ref).abs().max().item()

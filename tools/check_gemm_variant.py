@@ -75,7 +75,7 @@ def compare(variants, shapes=SHAPES, qkv_cases=QKV_CASES, verbose=True):
                     lib().ribca_set_gemm_variant(var)
                     q = torch.zeros((cells, heads, 112, 2 * hdp), dtype=torch.int16, device=dev)
                     kk = torch.zeros_like(q)
-                    vt = torch.zeros((cells, heads, hdv, 256), dtype=torch.int16, device=dev)
+                    vt = torch.zeros_like(q)
                     out = torch.zeros((m, 2 * dp), dtype=torch.int16, device=dev)
                     check(lib().ribca_test_qkv_attention(ptr(y_ps), 2 * dp, ptr(w_ps), 2 * dp, cells, d, dp, ptr(bias), ptr(q), ptr(kk), ptr(vt), ptr(out),
                                                          2 * dp, stream_ptr()), "qkv")
