@@ -203,8 +203,13 @@ __global__ __launch_bounds__(64 * WPP) void attention_lds_kernel(const uint16_t*
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + off),
                                      (__attribute__((address_space(3))) void*)(lds + i * 1024), 16, 0, 0);
   }
+  // Bank swizzle of the V image (HD = 32 only: 128-byte rows put every second row on the same banks, and a transposed read spans 8
+  // rows per half wave: SQ_LDS_BANK_CONFLICT 0.31 of the kernel's cycles without it).  The copy is linear in LDS, so the XOR is applied
+  // to the GLOBAL source address: LDS chunk p of row r holds the row's 16-byte chunk p ^ vswz(r).
+  auto vswz = [](int row) { return HD == 32 ? (((row >> 1) & 1) | (((row >> 2) & 1) << 2)) : 0; };
   for (int i = wave; i < V_DMA / 1024; i += WPP) {
     int off = i * 1024 + lane * 16;
+    if (HD == 32) { const int row = off / ROWB, ch = (off % ROWB) >> 4; off = row * ROWB + ((ch ^ vswz(row)) << 4); }
     off = off < K_BYTES ? off : K_BYTES - 16;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb + off),
                                      (__attribute__((address_space(3))) void*)(lds + K_LDS + i * 1024), 16, 0, 0);
@@ -293,9 +298,12 @@ __global__ __launch_bounds__(64 * WPP) void attention_lds_kernel(const uint16_t*
 #pragma unroll
       for (int t = 0; t < KST; ++t) {
         // lane 4q + p of its 16-lane group: row (key) 32 t + 4 g + q, columns (dims) 16 dt + 4p .. + 3 of the hi halves; + 16 bytes: lo
-        const char* va = vl + (32 * t + 4 * g + (r16 >> 2)) * ROWB + (2 * dt + ((r16 & 3) >> 1)) * 32 + (r16 & 1) * 8;
-        const f16x4 h0 = lds_read_tr16(va), l0 = lds_read_tr16(va + 16);
-        const f16x4 h1 = lds_read_tr16(va + 16 * ROWB), l1 = lds_read_tr16(va + 16 * ROWB + 16);
+        const int vrow = 32 * t + 4 * g + (r16 >> 2);                 // vswz(vrow + 16) == vswz(vrow)
+        const int vch = 2 * (2 * dt + ((r16 & 3) >> 1));             // 16-byte chunk of the hi half; the lo half is the next one
+        const char* va = vl + vrow * ROWB + (r16 & 1) * 8;
+        const int oh = ((vch ^ vswz(vrow)) << 4), ol = (((vch | 1) ^ vswz(vrow)) << 4);
+        const f16x4 h0 = lds_read_tr16(va + oh), l0 = lds_read_tr16(va + ol);
+        const f16x4 h1 = lds_read_tr16(va + 16 * ROWB + oh), l1 = lds_read_tr16(va + 16 * ROWB + ol);
         const f16x8 vhi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
         const f16x8 vlo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
         o = mfma_f16(vlo, phi[t], o);

@@ -139,8 +139,8 @@ def test_split_operand_range(dev):
         w = rnd((n, k), 71, dev, w_scale)
         bias = torch.zeros(n, device=dev)
         z = torch.zeros((m, n), device=dev)
-        check(lib().ribca_test_gemm(0, ptr(ps_encode(a, kp)), 2 * kp, ptr(ps_encode(w, kp, lib().ribca_gemm_padded_n(n))), 2 * kp, m, n, kp, ptr(bias),
-                                    ptr(z), n, stream_ptr()), "gemm")
+        a_ps, w_ps = ps_encode(a, kp), ps_encode(w, kp, lib().ribca_gemm_padded_n(n))      # named: they must outlive the launch
+        check(lib().ribca_test_gemm(0, ptr(a_ps), 2 * kp, ptr(w_ps), 2 * kp, m, n, kp, ptr(bias), ptr(z), n, stream_ptr()), "gemm")
         ref = a.double() @ w.double().t()
         mag = a.double().abs() @ w.double().abs().t()
         # per product: 2^-22 relative (dropped lo*lo) + the operands' split error: relative 2^-23 where lo is normal, absolute 2^-25 below
@@ -153,13 +153,14 @@ def test_split_operand_range(dev):
     w = rnd((n, k), 73, dev, 0.05)
     bias = torch.zeros(n, device=dev)
     z = torch.zeros((m, n), device=dev)
-    check(lib().ribca_test_gemm(0, ptr(ps_encode(a, kp)), 2 * kp, ptr(ps_encode(w, kp, lib().ribca_gemm_padded_n(n))), 2 * kp, m, n, kp, ptr(bias), ptr(z), n,
-                                stream_ptr()), "gemm")
+    a_ps, w_ps = ps_encode(a, kp), ps_encode(w, kp, lib().ribca_gemm_padded_n(n))
+    check(lib().ribca_test_gemm(0, ptr(a_ps), 2 * kp, ptr(w_ps), 2 * kp, m, n, kp, ptr(bias), ptr(z), n, stream_ptr()), "gemm")
     assert torch.isfinite(z).all()
     a_sat = a.clone()
     a_sat[:, 0] = 65504.0
     ref = a_sat.double() @ w.double().t()
-    assert ((z.double() - ref).abs() / (1.0 + ref.abs())).max().item() < 1e-5
+    # the saturated operand meets weights of ~0.05 whose lo halves are subnormal (absolute 2^-25): 65504 x 2^-25 = 2e-3 per product
+    assert (z.double() - ref).abs().max().item() < 65504 * 2.0 ** -23
 
 
 def _ln_case(m, d, seed, dev, mean=0.5, std=3.0, row_scale=False):
