@@ -113,10 +113,11 @@ struct EpiGeluT {
   static constexpr bool kTouch = false, kFold = FOLD;
   uint16_t* out; int ldo; const float* bias; int M, N; int nt = 0;
   const float2* rowstat = nullptr; const float* csum = nullptr;     // FOLD only
+  int rs_stride = 1;                                                 // rowstat[m * rs_stride] belongs to GEMM row m
   struct Ctx {};
   typedef std::conditional_t<FOLD, LnRow, NoRow> RowS;
   __device__ __forceinline__ RowS fetch_row(int m) const {
-    if constexpr (FOLD) { const float2 r = this->rowstat[m < M ? m : M - 1]; return RowS{r.x, -r.y * r.x}; }
+    if constexpr (FOLD) { const float2 r = this->rowstat[(size_t)(m < M ? m : M - 1) * rs_stride]; return RowS{r.x, -r.y * r.x}; }
     else return RowS{};
   }
   __device__ __forceinline__ float4 fetch_csum(int n) const {
@@ -147,7 +148,7 @@ struct EpiQKVT {
   static constexpr bool kTouch = false, kFold = FOLD;
   typedef std::conditional_t<FOLD, LnRow, NoRow> RowS;
   __device__ __forceinline__ RowS fetch_row(int m) const {
-    if constexpr (FOLD) { const float2 r = this->rowstat[m < M ? m : M - 1]; return RowS{r.x, -r.y * r.x}; }
+    if constexpr (FOLD) { const float2 r = this->rowstat[(size_t)(m < M ? m : M - 1) * rs_stride]; return RowS{r.x, -r.y * r.x}; }
     else return RowS{};
   }
   __device__ __forceinline__ float4 fetch_csum(int n) const {
@@ -163,12 +164,17 @@ struct EpiQKVT {
   // transposes it on the way out of LDS (ds_read_b64_tr_b16): every tile of the product then takes the row-contiguous LDS drain,
   // none the sixteen 2-byte scattered stores per value of the V^T form (15 % of the qkv launch)
   int vrow = 0;
+  // a column / row window of the full qkv product (the classifiers' LAST block: only the CLS query is ever used, so K and V are
+  // computed for every token -- columns D .. 3D, n_off = D -- and Q for the CLS rows alone -- cls_rows = 1: GEMM row m is token 0 of
+  // cell m)
+  int n_off = 0, cls_rows = 0, rs_stride = 1;
   struct Ctx {};
   // row / column decompositions are computed once per accumulator row (4) and column group (TN), not once per tile
   struct Row { int cell, t, vpos; };
   struct Col { int which, head, d; };
   __device__ __forceinline__ Row row(int m) const {
     Row r;
+    if (cls_rows) { r.cell = m; r.t = 0; r.vpos = 0; return r; }
     // m * ceil(2^32 / T) >> 32 is m / T or one more (m < 2^32): a runtime integer division costs ~25 VALU instructions, and the
     // drain evaluates it 8-11 times per thread
     r.cell = (int)__umulhi((unsigned)m, magicT);
@@ -181,8 +187,9 @@ struct EpiQKVT {
   }
   __device__ __forceinline__ Col col(int n) const {
     Col c;
-    c.which = n / D;
-    const int f = n - c.which * D;
+    const int nn = n + n_off;
+    c.which = nn / D;
+    const int f = nn - c.which * D;
     c.head = f / hd;
     c.d = f - c.head * hd;   // multiple of 4, d+3 < hd (hd % 4 == 0)
     return c;
@@ -191,7 +198,7 @@ struct EpiQKVT {
     return (bias != nullptr && n < N) ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
   }
   __device__ __forceinline__ EpiQKVT<false> plain() const {
-    return EpiQKVT<false>{q, k, vt, nullptr, D, hd, hdp, hdv, scale, M, N, T, TP, H, KP, nt, magicT, nullptr, nullptr, vrow};
+    return EpiQKVT<false>{q, k, vt, nullptr, D, hd, hdp, hdv, scale, M, N, T, TP, H, KP, nt, magicT, nullptr, nullptr, vrow, n_off, cls_rows, 1};
   }
   __device__ __forceinline__ void fetch(int, int, Ctx&) const {}
   template <int PX = 16>

@@ -390,7 +390,7 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
     if constexpr (Epi::kFold) {
       int gm = m0 + lw * 64 + lane;
       gm = gm < M ? gm : M - 1;
-      const float2* rp = epi.rowstat + gm;
+      const float2* rp = epi.rowstat + (size_t)gm * epi.rs_stride;
       asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(fold_rs) : "v"(rp) : "memory");
       if (lw < 2) {
         const int n = n0 + 4 * lane;
@@ -891,9 +891,10 @@ void launch_gemm_gelu_ln(const GemmArgs& g, const float2* rowstat, const float* 
   launch_any(g, EpiGeluLn{out, ldo, g.bias, g.M, g.N, nt_mask() & 1, rowstat, csum}, s);
 }
 void launch_gemm_qkv_ln(const GemmArgs& g, const float2* rowstat, const float* csum, uint16_t* q, uint16_t* k, uint16_t* vt, const AttnGeom& a,
-                        float scale, hipStream_t s) {
+                        float scale, hipStream_t s, int n_off, int cls_rows, int rs_stride) {
   launch_any(g, EpiQKVLn{q, k, vt, g.bias, a.D, a.hd, a.hdq, a.hdv, scale, g.M, g.N, a.T, a.TP, a.H, a.KP, (nt_mask() >> 1) & 1,
-                         (unsigned)((0x100000000ull + (unsigned long long)a.T - 1) / (unsigned long long)a.T), rowstat, csum, attention_v_rowmajor(a) ? 1 : 0}, s);
+                         (unsigned)((0x100000000ull + (unsigned long long)a.T - 1) / (unsigned long long)a.T), rowstat, csum, attention_v_rowmajor(a) ? 1 : 0,
+                         n_off, cls_rows, rs_stride}, s);
 }
 int gemm_resid_tiles(int N) { return gemm_padded_n(N) / gemm_pick_bn(N); }
 int gemm_resid_bn(int N) { return gemm_pick_bn(N); }

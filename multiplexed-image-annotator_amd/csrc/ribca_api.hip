@@ -347,9 +347,14 @@ void run_last_block_cls_fold(const BlockW& L, const BlockWs& w, int cells, const
   const int D = a.D, Dp = round_up(D, 32), ld_x = 2 * Dp, ld_h = 2 * 4 * D, Mc = cells * a.T;
   const float scale = 1.0f / sqrtf((float)a.hd);
   {
+    // only the CLS query is used (launch_attention below: one query tile, and only its row 0 is read afterwards): K and V for every
+    // token (output columns D .. 3D of the product), Q for the CLS rows alone -- a third of this block's qkv work is never done.
+    // (Rows 1 .. 15 of the first Q tile keep the previous block's values: finite, feeding output rows nothing reads.)
     ProfScope ps(P_QKV, s);
-    GemmArgs g{w.zps, ld_x, L.qkvw, ld_x, Mc, 3 * D, Dp, L.qkvb2};
-    launch_gemm_qkv_ln(g, w.rs, L.qkvc, w.q, w.k, w.vt, a, scale, s);
+    GemmArgs gkv{w.zps, ld_x, L.qkvw + (size_t)D * ld_x, ld_x, Mc, 2 * D, Dp, L.qkvb2 + D};
+    launch_gemm_qkv_ln(gkv, w.rs, L.qkvc + D, w.q, w.k, w.vt, a, scale, s, D, 0, 1);
+    GemmArgs gq{w.zps, a.T * ld_x, L.qkvw, ld_x, cells, D, Dp, L.qkvb2};
+    launch_gemm_qkv_ln(gq, w.rs, L.qkvc, w.q, w.k, w.vt, a, scale, s, 0, 1, a.T);
   }
   { ProfScope ps(P_ATTN, s); launch_attention(w.q, w.k, w.vt, w.xa, ld_x, cells, a, s, 1); }
   {

@@ -49,8 +49,11 @@ size_t attention_v_elems(const AttnGeom& a, int cells);   // 16-bit elements of 
 // qkv: scatter into per-head attention operands (Q pre-scaled by hd^-0.5, V transposed + key-permuted)
 void launch_gemm_qkv(const GemmArgs& g, uint16_t* q, uint16_t* k, uint16_t* vt, const AttnGeom& a, float scale, hipStream_t s);
 // fp32 output through a per-cell row map (imputer embeddings / predictions), see EpiRowMap
+// n_off / cls_rows / rs_stride: a window of the full product (EpiQKVT): g.W, g.bias and csum already point at output column n_off,
+// g.N columns are computed; cls_rows = 1: GEMM row m is token 0 of cell m (g.A addressed with a row stride of T rows) and its
+// statistics are rowstat[m * rs_stride]
 void launch_gemm_qkv_ln(const GemmArgs& g, const float2* rowstat, const float* csum, uint16_t* q, uint16_t* k, uint16_t* vt, const AttnGeom& a,
-                        float scale, hipStream_t s);
+                        float scale, hipStream_t s, int n_off = 0, int cls_rows = 0, int rs_stride = 1);
 void launch_gemm_rowmap(const GemmArgs& g, float* out, int ldo, const float* add, int ldadd, const int* slot, const int* addrow, int R,
                         int dst_per_cell, hipStream_t s);
 
