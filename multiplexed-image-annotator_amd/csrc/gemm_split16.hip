@@ -211,14 +211,11 @@ __device__ __forceinline__ void lds_drain_resid_ps(const EpiResidPS& epi, const 
     f32x2v tot = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {      // two columns at a time: packed fp32 adds
-      const f32x2 h = unpack_f16(hw[j]), l = unpack_f16(lw[j]);
-      const f32x2v zo = f32x2v{h[0], h[1]} + f32x2v{l[0], l[1]};      // hi + lo: exact
+      const f32x2v zo = {f16lo_plus_f16lo(hw[j], lw[j]), f16hi_plus_f16hi(hw[j], lw[j])};      // hi + lo: exact
       f32x2v x = (zo - pm) + (acc2[j] + b2[j]);
       x.x = clamp_f16_range(x.x); x.y = clamp_f16_range(x.y);
       nh[j] = cvt_pk_f16(x.x, x.y);
-      const f32x2 hb = unpack_f16(nh[j]);
-      const f32x2v r = x - f32x2v{hb[0], hb[1]};
-      nl[j] = cvt_pk_f16(r.x, r.y);
+      nl[j] = cvt_pk_f16(f32_minus_f16lo(x.x, nh[j]), f32_minus_f16hi(x.y, nh[j]));
       xs[it][j] = x;
       tot += x;
     }

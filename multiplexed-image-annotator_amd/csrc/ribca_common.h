@@ -58,13 +58,36 @@ __device__ __forceinline__ uint32_t cvt_pk_f16(float a, float b) {
 __device__ __forceinline__ f32x2 unpack_f16(uint32_t p) {
   return __builtin_convertvector(__builtin_bit_cast(f16x2, p), f32x2);
 }
+// Mixed-precision FMA (v_fma_mix_f32: every source is an fp32 register or one fp16 half of a register, the arithmetic is one fp32
+// fma): "fp32 minus an fp16 half" and "fp16 half plus fp16 half" in ONE instruction where v_cvt_f32_f16 + v_sub / v_add took two or
+// three.  Same values bit for bit: h * (-1) + x and h * 1 + l are exact products and a single rounding, as the separate convert +
+// add is.  The split and the packed-split residual epilogue are VALU-bound on exactly these conversions.
+__device__ __forceinline__ float f32_minus_f16lo(float x, uint32_t h) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+  return r;
+}
+__device__ __forceinline__ float f32_minus_f16hi(float x, uint32_t h) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+  return r;
+}
+__device__ __forceinline__ float f16lo_plus_f16lo(uint32_t a, uint32_t b) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float f16hi_plus_f16hi(uint32_t a, uint32_t b) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ void split4(const float v[4], uint2& hi, uint2& lo) {
   const float c0 = clamp_f16_range(v[0]), c1 = clamp_f16_range(v[1]), c2 = clamp_f16_range(v[2]), c3 = clamp_f16_range(v[3]);
   hi.x = cvt_pk_f16(c0, c1);
   hi.y = cvt_pk_f16(c2, c3);
-  const f32x2 h01 = unpack_f16(hi.x), h23 = unpack_f16(hi.y);
-  lo.x = cvt_pk_f16(c0 - h01[0], c1 - h01[1]);
-  lo.y = cvt_pk_f16(c2 - h23[0], c3 - h23[1]);
+  lo.x = cvt_pk_f16(f32_minus_f16lo(c0, hi.x), f32_minus_f16hi(c1, hi.x));
+  lo.y = cvt_pk_f16(f32_minus_f16lo(c2, hi.y), f32_minus_f16hi(c3, hi.y));
 }
 // element offset (in fp16 units) of the hi part of logical column k in a PS row; lo part is +8
 __device__ __host__ __forceinline__ int ps_off(int k) { return ((k >> 3) << 4) + (k & 7); }
