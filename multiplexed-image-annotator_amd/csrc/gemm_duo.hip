@@ -430,10 +430,10 @@ bool launch_duo(const GemmArgs& g, const Epi& epi, hipStream_t s, int abl) {
 #define RIBCA_DUO_INST(BN, EPI) template bool launch_duo<BN, EPI>(const GemmArgs&, const EPI&, hipStream_t, int);
 RIBCA_DUO_INST(128, EpiGelu) RIBCA_DUO_INST(96, EpiGelu) RIBCA_DUO_INST(64, EpiGelu)
 RIBCA_DUO_INST(128, EpiGeluLn) RIBCA_DUO_INST(96, EpiGeluLn) RIBCA_DUO_INST(64, EpiGeluLn)
+RIBCA_DUO_INST(128, EpiQKVLn) RIBCA_DUO_INST(96, EpiQKVLn) RIBCA_DUO_INST(64, EpiQKVLn)
 #ifdef RIBCA_DIAG
 RIBCA_DUO_INST(128, EpiResid) RIBCA_DUO_INST(96, EpiResid) RIBCA_DUO_INST(64, EpiResid)
 RIBCA_DUO_INST(128, EpiQKV) RIBCA_DUO_INST(96, EpiQKV) RIBCA_DUO_INST(64, EpiQKV)
-RIBCA_DUO_INST(128, EpiQKVLn) RIBCA_DUO_INST(96, EpiQKVLn) RIBCA_DUO_INST(64, EpiQKVLn)
 RIBCA_DUO_INST(128, EpiRowMap) RIBCA_DUO_INST(96, EpiRowMap) RIBCA_DUO_INST(64, EpiRowMap)
 #endif
 #undef RIBCA_DUO_INST

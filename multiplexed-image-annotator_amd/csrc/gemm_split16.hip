@@ -819,6 +819,13 @@ static void launch_bn(const GemmArgs& g, const Epi& epi, hipStream_t s) {
     static const bool duo_on = !(getenv("RIBCA_GEMM_DUO") && atoi(getenv("RIBCA_GEMM_DUO")) == 0);
     if (g_variant == 0 && duo_on && g.WF != nullptr && g.M >= 4096 && launch_duo<BN, Epi>(g, epi, s, 0)) return;
   }
+  // The folded qkv product too, now that V is stored row-major (round 2 measured this epilogue 5-25 % slower on the duo kernel because
+  // of its eight 2-byte V^T stores per value on one wave per SIMD; with 16-byte row stores it is the GELU epilogue's shape): qkv family
+  // 1939 -> 1808 ms per pass, +0.65 % end to end in an interleaved same-box A/B (profiles/r3/ab_qkv_on_duo.txt).  RIBCA_QKV_DUO=0: off.
+  if constexpr (std::is_same<Epi, EpiQKVLn>::value) {
+    static const bool qkv_duo = !(getenv("RIBCA_QKV_DUO") && atoi(getenv("RIBCA_QKV_DUO")) == 0);
+    if (g_variant == 0 && qkv_duo && g.WF != nullptr && g.M >= 4096 && epi.vrow && launch_duo<BN, Epi>(g, epi, s, 0)) return;
+  }
 #ifdef RIBCA_DIAG
   if constexpr (!std::is_same<Epi, EpiResidPS>::value) {
     if (g_variant >= 40 && g_variant <= 49) {   // two workgroups per CU (gemm_duo.hip); 41-47 = its timing ablations (bit mask), 48 = stamps

@@ -77,6 +77,7 @@ void prof_drain() {
 struct BlockW {
   const float *ln1w, *ln1b, *qkvb, *projb, *ln2w, *ln2b, *fc1b, *fc2b;
   const uint16_t *qkvw, *projw, *fc1w, *fc2w;
+  const uint16_t* qkvwf = nullptr;   // folded qkv weight in fragment order: the qkv product runs on the duo kernel as well
   const uint16_t* fc1wf;   // fc1 weight again, in MFMA fragment order (gemm_duo.hip): the GELU GEMMs run on the two-workgroups-per-CU kernel
   // LayerNorm folded into qkv / fc1 (classifiers): qkvw / fc1w then hold gamma o W, and per output column the sum of the packed row
   // and the bias with beta folded in (vit_misc.hip pack_weight_fold_kernel)
@@ -128,6 +129,7 @@ void layout_block(Carver& c, BlockW& L, int D, bool fold = false) {
   L.ln2w = c.take<float>(D); L.ln2b = c.take<float>(D);
   L.fc1b = c.take<float>(4 * D); L.fc2b = c.take<float>(D);
   L.qkvw = c.take<uint16_t>((size_t)gemm_padded_n(3 * D) * 2 * Dp);
+  if (fold) L.qkvwf = c.take<uint16_t>((size_t)gemm_padded_n(3 * D) * 2 * Dp);
   L.projw = c.take<uint16_t>((size_t)gemm_padded_n(D) * 2 * Dp);
   L.fc1w = c.take<uint16_t>((size_t)gemm_padded_n(4 * D) * 2 * Dp);
   L.fc1wf = c.take<uint16_t>((size_t)gemm_padded_n(4 * D) * 2 * Dp);
@@ -191,8 +193,10 @@ struct BlobReader {
   void block(const BlockW& L, int D, bool fold = false) {
     const int Dp = round_up(D, 32);
     copy(L.ln1w, D); copy(L.ln1b, D);
-    if (fold) pack_fold(L.qkvw, 3 * D, D, Dp, L.ln1w, L.ln1b, L.qkvc, L.qkvb2);
-    else pack(L.qkvw, 3 * D, D, Dp);
+    if (fold) {
+      pack_fold(L.qkvw, 3 * D, D, Dp, L.ln1w, L.ln1b, L.qkvc, L.qkvb2);
+      launch_pack_wf(L.qkvw, 2 * Dp, gemm_padded_n(3 * D), Dp, const_cast<uint16_t*>(L.qkvwf), s);
+    } else pack(L.qkvw, 3 * D, D, Dp);
     copy(L.qkvb, 3 * D);
     pack(L.projw, D, D, Dp); copy(L.projb, D);
     copy(L.ln2w, D); copy(L.ln2b, D);
@@ -321,7 +325,7 @@ void run_block_fold(const BlockW& L, const BlockWs& w, int cells, const AttnGeom
   const float scale = 1.0f / sqrtf((float)a.hd);
   {
     ProfScope ps(P_QKV, s);
-    GemmArgs g{w.zps, ld_x, L.qkvw, ld_x, Mc, 3 * D, Dp, L.qkvb2};
+    GemmArgs g{w.zps, ld_x, L.qkvw, ld_x, Mc, 3 * D, Dp, L.qkvb2, L.qkvwf};
     launch_gemm_qkv_ln(g, w.rs, L.qkvc, w.q, w.k, w.vt, a, scale, s);
   }
   { ProfScope ps(P_ATTN, s); launch_attention(w.q, w.k, w.vt, w.xa, ld_x, cells, a, s); }
