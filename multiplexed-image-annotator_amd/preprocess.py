@@ -27,8 +27,9 @@ from . import _lib, ops
 def read_image(path: str) -> np.ndarray:
     """Image / mask reader standing in for ``skimage.io.imread`` (reference preprocess.py:244-246), which hands ``.tif`` files to
     tifffile: a multi-page TIFF comes back as (pages, H, W) in page order, a PNG as (H, W) or (H, W, samples).  ``tifffile`` is used
-    when it is installed (it also reads the planar / OME / BigTIFF layouts PIL cannot); otherwise PIL page by page.  ``.npy`` is an
-    extension of this package (device-ready arrays)."""
+    when it is installed; otherwise the baseline-TIFF reader below (``read_tiff``: the layouts multiplexed-imaging exports use and PIL
+    cannot read -- planar multi-sample, tiled, deflate + predictor, BigTIFF, OME-TIFF page stacks with pyramid levels), and PIL page by
+    page for what that reader declines (LZW / JPEG compression).  ``.npy`` is an extension of this package (device-ready arrays)."""
     p = str(path)
     low = p.lower()
     if low.endswith(".npy"):
@@ -40,6 +41,10 @@ def read_image(path: str) -> np.ndarray:
             tifffile = None
         if tifffile is not None:
             return np.asarray(tifffile.imread(p))
+        try:
+            return read_tiff(p)
+        except TiffUnsupported:
+            pass
     from PIL import Image
     im = Image.open(p)
     frames = getattr(im, "n_frames", 1)
@@ -52,6 +57,137 @@ def read_image(path: str) -> np.ndarray:
             raise ValueError(f"{p}: pages of different shapes cannot be stacked into (C, H, W)")
         return np.stack(planes, axis=0)
     return np.array(im)
+
+
+class TiffUnsupported(ValueError):
+    """a TIFF feature ``read_tiff`` does not implement (the caller falls back to PIL)"""
+
+
+_TIFF_TYPES = {1: "B", 2: "c", 3: "H", 4: "I", 5: "II", 6: "b", 7: "B", 8: "h", 9: "i", 10: "ii", 11: "f", 12: "d", 13: "I", 16: "Q", 17: "q", 18: "Q"}
+
+
+def read_tiff(path: str) -> np.ndarray:
+    """Baseline TIFF 6.0 / BigTIFF reader in numpy + zlib, returning what ``tifffile.imread`` returns for the first series:
+
+    * little- or big-endian, classic (II*\0 / MM\0*) or BigTIFF (version 43);
+    * every top-level page that is NOT a reduced-resolution image (NewSubfileType bit 0: pyramid levels of OME / QPTIFF exports are
+      skipped, SubIFDs are never followed) and has the first page's shape and dtype, stacked in file order: (pages, H, W);
+    * strips or tiles; compression none (1) or deflate (8 / 32946), optional horizontal differencing (Predictor 2);
+    * 8 / 16 / 32-bit unsigned or signed integers and 32 / 64-bit floats; SamplesPerPixel S > 1 either planar
+      (PlanarConfiguration 2 -> (S, H, W), the channel-first layout the hot path wants) or chunky ((H, W, S), as tifffile does);
+    * an OME-XML ImageDescription is accepted as is: with SizeZ = SizeT = 1 the page order is the channel order.
+    Anything else (LZW, JPEG, palette, sub-byte samples) raises ``TiffUnsupported``."""
+    import struct
+    import zlib
+    with open(path, "rb") as f:
+        data = f.read()
+    if len(data) < 8 or data[:2] not in (b"II", b"MM"):
+        raise TiffUnsupported(f"{path}: not a TIFF file")
+    bo = "<" if data[:2] == b"II" else ">"
+    version = struct.unpack(bo + "H", data[2:4])[0]
+    if version == 42:
+        big, off = False, struct.unpack(bo + "I", data[4:8])[0]
+    elif version == 43:
+        big, off = True, struct.unpack(bo + "Q", data[8:16])[0]
+    else:
+        raise TiffUnsupported(f"{path}: unknown TIFF version {version}")
+
+    def read_ifd(o):
+        n = struct.unpack(bo + ("Q" if big else "H"), data[o:o + (8 if big else 2)])[0]
+        o += 8 if big else 2
+        esz, vsz = (20, 8) if big else (12, 4)
+        tags = {}
+        for i in range(n):
+            e = data[o + i * esz:o + (i + 1) * esz]
+            tag, typ = struct.unpack(bo + "HH", e[:4])
+            cnt = struct.unpack(bo + ("Q" if big else "I"), e[4:4 + vsz])[0]
+            fmt = _TIFF_TYPES.get(typ)
+            if fmt is None:
+                continue
+            per = struct.calcsize("=" + fmt)
+            nbytes = per * cnt
+            if nbytes <= vsz:
+                raw = e[4 + vsz:4 + vsz + nbytes]
+            else:
+                vo = struct.unpack(bo + ("Q" if big else "I"), e[4 + vsz:4 + 2 * vsz])[0]
+                raw = data[vo:vo + nbytes]
+            if typ == 2:
+                tags[tag] = raw.rstrip(b"\0").decode("latin-1")
+            else:
+                vals = struct.unpack(bo + fmt * cnt, raw)
+                tags[tag] = vals
+        nxt = struct.unpack(bo + ("Q" if big else "I"), data[o + n * esz:o + n * esz + vsz])[0]
+        return tags, nxt
+
+    def one(tags, tag, default=None):
+        v = tags.get(tag)
+        return default if v is None else v[0]
+
+    def page_array(tags):
+        w, h = one(tags, 256), one(tags, 257)
+        spp = one(tags, 277, 1)
+        bits = tags.get(258, (1,))
+        fmt = one(tags, 339, 1)
+        comp = one(tags, 259, 1)
+        planar = one(tags, 284, 1)
+        pred = one(tags, 317, 1)
+        if w is None or h is None or len(set(bits)) != 1 or bits[0] not in (8, 16, 32, 64):
+            raise TiffUnsupported(f"{path}: unsupported sample layout {bits}")
+        if comp not in (1, 8, 32946):
+            raise TiffUnsupported(f"{path}: compression {comp} is not implemented")
+        if one(tags, 262, 1) == 3:
+            raise TiffUnsupported(f"{path}: palette images are not implemented")
+        kind = {1: "u", 2: "i", 3: "f"}.get(fmt)
+        if kind is None or (kind == "f" and bits[0] < 32) or pred not in (1, 2) or (pred == 2 and kind == "f"):
+            raise TiffUnsupported(f"{path}: sample format {fmt} / predictor {pred}")
+        dt = np.dtype(bo + kind + str(bits[0] // 8))
+        tiled = 322 in tags
+        if tiled:
+            tw, th = one(tags, 322), one(tags, 323)
+            offs, cnts = tags[324], tags[325]
+        else:
+            tw, th = w, one(tags, 278, h)
+            th = min(th, h)
+            offs, cnts = tags[273], tags[279]
+        across, down = (w + tw - 1) // tw, (h + th - 1) // th
+        planes = spp if planar == 2 else 1
+        per_chunk = spp if planar == 1 else 1
+        if len(offs) != across * down * planes:
+            raise TiffUnsupported(f"{path}: {len(offs)} strips / tiles, expected {across * down * planes}")
+        out = np.zeros((planes, h, w, per_chunk), dtype=dt.newbyteorder("="))
+        for idx, (o, c) in enumerate(zip(offs, cnts)):
+            pl, rem = divmod(idx, across * down)
+            ty, tx = divmod(rem, across)
+            buf = data[o:o + c]
+            if comp != 1:
+                buf = zlib.decompress(buf)
+            rows = th if tiled else min(th, h - ty * th)
+            chunk = np.frombuffer(buf, dtype=dt, count=rows * tw * per_chunk).reshape(rows, tw, per_chunk)
+            if pred == 2:
+                chunk = np.cumsum(chunk.astype(dt.newbyteorder("=")), axis=1, dtype=dt.newbyteorder("="))
+            y0, x0 = ty * th, tx * tw
+            y1, x1 = min(y0 + rows, h), min(x0 + tw, w)
+            out[pl, y0:y1, x0:x1] = chunk[:y1 - y0, :x1 - x0]
+        if planar == 2 and spp > 1:
+            return out[..., 0]                       # (S, H, W)
+        if spp > 1:
+            return out[0]                            # (H, W, S)
+        return out[0, :, :, 0]
+
+    pages, seen = [], set()
+    while off and off not in seen and off + 2 <= len(data):
+        seen.add(off)
+        tags, off = read_ifd(off)
+        if one(tags, 254, 0) & 1:                    # reduced-resolution page of a pyramid
+            continue
+        pages.append(page_array(tags))
+    if not pages:
+        raise TiffUnsupported(f"{path}: no image pages")
+    first = pages[0]
+    same = [pg for pg in pages if pg.shape == first.shape and pg.dtype == first.dtype]
+    if len(same) == 1:
+        return same[0]
+    return np.stack(same, axis=0)
 
 
 def as_channel_planes(image: np.ndarray, path: str = "") -> np.ndarray:
