@@ -2,6 +2,8 @@
 """GEMM micro-benchmark on the shapes of the five classifiers (A/B of kernel variants in ONE process, interleaved rounds).
 usage: python tools/bench_gemm.py [cells] [variants...]"""
 import os
+
+os.environ.setdefault("RIBCA_DIAG", "1")      # the variant / ablation / stamp kernel forms live in libribca_hip_diag.so (build --diag)
 import sys
 import time
 

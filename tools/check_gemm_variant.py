@@ -3,6 +3,8 @@
 QKV epilogues, ragged M, every column-tile width.  usage: python tools/check_gemm_variant.py VARIANT [VARIANT...]
 (tests/test_gpu_kernels.py::test_gemm_duo_variant_bit_identical runs `compare` on a reduced list)"""
 import os
+
+os.environ.setdefault("RIBCA_DIAG", "1")      # the variant / ablation / stamp kernel forms live in libribca_hip_diag.so (build --diag)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -3,6 +3,8 @@
 epilogue at the same moment)?  One wave of tiles (<= 256 workgroups, one per CU) of the fc1 / proj shapes at D = 576 with a growing
 number of active CUs; the launch time is then one tile's time.  Variant 9 = same kernel without the epilogue."""
 import os
+
+os.environ.setdefault("RIBCA_DIAG", "1")      # the variant / ablation / stamp kernel forms live in libribca_hip_diag.so (build --diag)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
