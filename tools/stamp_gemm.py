@@ -19,20 +19,30 @@ dev = _lib.require_gpu()
 cells = 1024
 M = cells * 101
 g = torch.Generator().manual_seed(0)
-for name, d, n, kp, kind in (("proj576", 576, 576, 576, 0), ("fc1_576", 576, 2304, 576, 1), ("fc2_576", 576, 576, 2304, 0), ("fc1_288", 288, 1152, 288, 1)):
+# kind 0: fp32 residual epilogue (imputer), 1: GELU, 2: packed-split residual epilogue with row statistics (the classifiers' proj / fc2)
+for name, d, n, kp, kind in (("proj576", 576, 576, 576, 0), ("proj576_ps", 576, 576, 576, 2), ("proj288_ps", 288, 288, 288, 2), ("fc2_576_ps", 576, 576, 2304, 2),
+                             ("fc1_576", 576, 2304, 576, 1), ("fc2_576", 576, 576, 2304, 0), ("fc1_288", 288, 1152, 288, 1)):
     a = (torch.randn((M, 2 * kp), generator=g) * 0.1).to(torch.float16).view(torch.int16).to(dev)
     npad = lib().ribca_gemm_padded_n(n)
     w = (torch.randn((npad, 2 * kp), generator=g) * 0.1).to(torch.float16).view(torch.int16).to(dev)
     bias = torch.zeros(n, device=dev)
     out = torch.zeros((M, n if kind == 0 else 2 * n), dtype=torch.float32 if kind == 0 else torch.int16, device=dev)
     ldo = n if kind == 0 else 2 * n
+    if kind == 2:
+        part = torch.zeros((lib().ribca_test_resid_tiles(n), M, 2), dtype=torch.float32, device=dev)
+        rs = torch.zeros((M, 2), dtype=torch.float32, device=dev)
+        prev = torch.zeros((M, 2), dtype=torch.float32, device=dev)
     bn = 128 if n % 128 == 0 else (96 if n % 96 == 0 else 64)
     nblk = ((M + 255) // 256) * (npad // bn)
     stamps = torch.zeros((nblk, 20), dtype=torch.int64, device=dev)
     lib().ribca_set_gemm_stamps(ptr(stamps), nblk)
     lib().ribca_set_gemm_variant(12)
     for _ in range(2):
-        check(lib().ribca_test_gemm(kind, ptr(a), 2 * kp, ptr(w), 2 * kp, M, n, kp, ptr(bias), ptr(out), ldo, stream_ptr()), "gemm")
+        if kind == 2:
+            check(lib().ribca_test_gemm_resid_ps(ptr(a), 2 * kp, ptr(w), 2 * kp, M, n, kp, ptr(bias), ptr(out), ldo, ptr(part), ptr(rs), ptr(prev), stream_ptr()),
+                  "resid_ps")
+        else:
+            check(lib().ribca_test_gemm(kind, ptr(a), 2 * kp, ptr(w), 2 * kp, M, n, kp, ptr(bias), ptr(out), ldo, stream_ptr()), "gemm")
     torch.cuda.synchronize()
     lib().ribca_set_gemm_variant(0)
     lib().ribca_set_gemm_stamps(None, 0)
