@@ -155,7 +155,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 // per pass, 12 waves 48, six passes the tile.  Statistics are taken over the fp32 values before the split (the stored row differs by
 // 2^-23 relative per element: 1e-9 on a mean that the fold multiplies by O(1)) with DPP reductions in a fixed order.
 template <int BN>
-__device__ __forceinline__ void lds_drain_resid_ps(const EpiResidPS& epi, const char* smem, int m0, int n0, int nt, int tid) {
+__device__ __forceinline__ void lds_drain_resid_ps(const EpiResidPS& epi, const char* smem, const char* stage, int m0, int n0, int nt, int tid) {
   constexpr int SROW = BN * 4 + 16, GPR = BN / 8, NIT = 6;     // 12 waves x 4 rows x 6 passes = 288 >= 256 rows
   static_assert(GPR <= 16, "a tile row fits one DPP row of lanes");
   const int lane = tid & 63, wave = tid >> 6;
@@ -163,14 +163,7 @@ __device__ __forceinline__ void lds_drain_resid_ps(const EpiResidPS& epi, const 
   const int n = n0 + 8 * c;
   const bool col_ok = c < GPR && n < epi.N;      // N % 8 == 0
   const int rbase = 4 * wave + (lane >> 4);
-  f32x2v b2[4];
-  {
-    const float4 ba = col_ok ? *reinterpret_cast<const float4*>(epi.bias + n) : float4{0.f, 0.f, 0.f, 0.f};
-    const float4 bb = col_ok ? *reinterpret_cast<const float4*>(epi.bias + n + 4) : float4{0.f, 0.f, 0.f, 0.f};
-    b2[0] = f32x2v{ba.x, ba.y}; b2[1] = f32x2v{ba.z, ba.w}; b2[2] = f32x2v{bb.x, bb.y}; b2[3] = f32x2v{bb.z, bb.w};
-  }
   uint4 zh[NIT], zl[NIT];
-  float pmean[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int row = rbase + 48 * it;
@@ -178,9 +171,9 @@ __device__ __forceinline__ void lds_drain_resid_ps(const EpiResidPS& epi, const 
     const uint16_t* zp = epi.z + (size_t)(m0 + row) * epi.ldz + 2 * n;
     zh[it] = ok ? *reinterpret_cast<const uint4*>(zp) : uint4{0u, 0u, 0u, 0u};
     zl[it] = ok ? *reinterpret_cast<const uint4*>(zp + 8) : uint4{0u, 0u, 0u, 0u};
-    pmean[it] = (ok && epi.prev != nullptr) ? epi.prev[(size_t)(m0 + row) * epi.prev_stride].y : 0.f;
   }
   f32x4 va[NIT], vb[NIT];
+  float pmean[NIT];
   const char* src = smem + rbase * SROW + c * 32;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -188,15 +181,13 @@ __device__ __forceinline__ void lds_drain_resid_ps(const EpiResidPS& epi, const 
     const bool rd = c < GPR && row < 256;
     va[it] = rd ? *reinterpret_cast<const f32x4*>(src + it * 48 * SROW) : f32x4{0.f, 0.f, 0.f, 0.f};
     vb[it] = rd ? *reinterpret_cast<const f32x4*>(src + it * 48 * SROW + 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    pmean[it] = row < 256 ? reinterpret_cast<const float2*>(stage + row * 8)->y : 0.f;      // mean of the stored row (0: no re-centring)
   }
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(va[it]), "+v"(vb[it]));
-#pragma unroll
-  for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(b2[i]));
+  for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(va[it]), "+v"(vb[it]), "+v"(pmean[it]));
 #pragma unroll
   for (int it = 0; it < NIT; ++it)
-    asm volatile("" : "+v"(zh[it].x), "+v"(zh[it].y), "+v"(zh[it].z), "+v"(zh[it].w), "+v"(zl[it].x), "+v"(zl[it].y), "+v"(zl[it].z), "+v"(zl[it].w),
-                 "+v"(pmean[it]));
+    asm volatile("" : "+v"(zh[it].x), "+v"(zh[it].y), "+v"(zh[it].z), "+v"(zh[it].w), "+v"(zl[it].x), "+v"(zl[it].y), "+v"(zl[it].z), "+v"(zl[it].w));
   __builtin_amdgcn_sched_barrier(0);
   f32x2v xs[NIT][4];
   float s[NIT];
@@ -212,7 +203,7 @@ __device__ __forceinline__ void lds_drain_resid_ps(const EpiResidPS& epi, const 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {      // two columns at a time: packed fp32 adds
       const f32x2v zo = {f16lo_plus_f16lo(hw[j], lw[j]), f16hi_plus_f16hi(hw[j], lw[j])};      // hi + lo: exact
-      f32x2v x = (zo - pm) + (acc2[j] + b2[j]);
+      f32x2v x = (zo - pm) + acc2[j];              // the tile already carries the bias (consumers, before parking)
       x.x = clamp_f16_range(x.x); x.y = clamp_f16_range(x.y);
       nh[j] = cvt_pk_f16(x.x, x.y);
       nl[j] = cvt_pk_f16(f32_minus_f16lo(x.x, nh[j]), f32_minus_f16hi(x.y, nh[j]));
@@ -254,7 +245,7 @@ __device__ __forceinline__ void lds_drain_resid_ps(const EpiResidPS& epi, const 
 }
 template <int BN, class Epi>
 __device__ __forceinline__ void lds_drain_any(const Epi& epi, const char* smem, int m0, int n0, int nt, int tid) {
-  if constexpr (std::is_same<Epi, EpiResidPS>::value) lds_drain_resid_ps<BN>(epi, smem, m0, n0, nt, tid);
+  if constexpr (std::is_same<Epi, EpiResidPS>::value) lds_drain_resid_ps<BN>(epi, smem, smem + 3 * (256 + BN) * ROWB, m0, n0, nt, tid);
   else if constexpr (Epi::kFold) lds_drain<BN>(epi.plain(), smem, m0, n0, tid);      // the consumers folded before parking
   else lds_drain<BN>(epi, smem, m0, n0, tid);
 }
@@ -384,14 +375,31 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
     // in FRONT of the first ring stage -- vmcnt retires in order, so the wait for stage 0 covers them -- and copied behind the ring
     unsigned long long fold_rs = 0;
     u32x4 fold_cb = {0u, 0u, 0u, 0u};
+    constexpr bool kResidPS = std::is_same<Epi, EpiResidPS>::value;
     if constexpr (Epi::kFold) {
       int gm = m0 + lw * 64 + lane;
       gm = gm < M ? gm : M - 1;
       const float2* rp = epi.rowstat + (size_t)gm * epi.rs_stride;
       asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(fold_rs) : "v"(rp) : "memory");
-      if (lw < 2) {
+      {      // every loader wave issues it (no branch around an asynchronous load, see below); waves 0 / 1 keep theirs
         const int n = n0 + 4 * lane;
         const float* cp = (lw == 0 ? epi.csum : epi.bias) + ((lane < BN / 4 && n < epi.N) ? n : 0);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fold_cb) : "v"(cp) : "memory");
+      }
+    }
+    // packed-split residual epilogue: the mean each stored row had (re-centring) and the tile's bias travel the same way: the consumers
+    // add the bias to their accumulators before parking, the drain reads the row's mean from LDS instead of global memory
+    // ((z - mean) is kept as its own, nearly exact, subtraction: that is what makes the re-centring free of rounding)
+    if constexpr (kResidPS) {
+      int gm = m0 + lw * 64 + lane;
+      gm = gm < M ? gm : M - 1;
+      // (unconditional: a load whose destination the compiler may merge with another value behind a branch would be copied before
+      // its data has arrived -- the asm statement only ISSUES it; without re-centring it reads the bias and the value is dropped below)
+      const float2* rp = epi.prev != nullptr ? epi.prev + (size_t)gm * epi.prev_stride : reinterpret_cast<const float2*>(epi.bias);
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(fold_rs) : "v"(rp) : "memory");
+      {
+        const int n = n0 + 4 * lane;
+        const float* cp = epi.bias + ((lane < BN / 4 && n < epi.N) ? n : 0);
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fold_cb) : "v"(cp) : "memory");
       }
     }
@@ -410,6 +418,18 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
       } else {
         if (after_touch) wait_vmcnt<NT>();
         else wait_vmcnt<0>();
+      }
+      if constexpr (kResidPS) {
+        if (kk == 0) {
+          asm volatile("" : "+v"(fold_rs), "+v"(fold_cb));
+          char* xs = smem + NST * STAGE;
+          const float2 sm = __builtin_bit_cast(float2, fold_rs);      // (rstd, mean) of the stored row, or zeros
+          *reinterpret_cast<float2*>(xs + (lw * 64 + lane) * 8) = float2{0.f, epi.prev != nullptr ? sm.y : 0.f};
+          if (lw == 1 && lane < BN / 4) {
+            const bool ok = n0 + 4 * lane < epi.N;
+            *reinterpret_cast<u32x4*>(xs + kFoldRowBytes + 4 * BN + lane * 16) = ok ? fold_cb : u32x4{0u, 0u, 0u, 0u};
+          }
+        }
       }
       if constexpr (Epi::kFold) {
         if (kk == 0) {      // consumers read this after the K loop, many barriers from here
@@ -552,6 +572,15 @@ __global__ __launch_bounds__(768) void gemm_ps_split_kernel(const uint16_t* __re
       lds_drain<BN>(pe, smem, m0, n0, tid);
     }
   } else if constexpr (LEPI && STAG) {
+    if constexpr (std::is_same<Epi, EpiResidPS>::value) {      // acc += bias (staged behind the ring by the loaders): one add the drain need not do
+      const char* xs = smem + NST * STAGE;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float4 b4 = *reinterpret_cast<const float4*>(xs + kFoldRowBytes + 4 * BN + (wn * (BN / 2) + j * 16 + 4 * g) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[i][j][0] += b4.x; acc[i][j][1] += b4.y; acc[i][j][2] += b4.z; acc[i][j][3] += b4.w; }
+      }
+    }
     if (lepi_tile_uses_registers(epi, n0, BN)) run_epilogue<TN>(epi, m0 + wm * 64 + r16, n0 + wn * (BN / 2) + 4 * g, acc);
     else {
       lds_park<BN>(smem, acc, wm, wn, r16, g);
@@ -765,7 +794,7 @@ template <int BN, class Epi, int ABL = 0, bool STAG = false, bool LEPI = false>
 static void launch_split(const GemmArgs& g, const Epi& epi, hipStream_t s) {
   const int mtiles = (g.M + 255) / 256;
   const int ntiles = gemm_padded_n(g.N) / BN;
-  const size_t lds = (size_t)3 * (256 + BN) * ROWB + (Epi::kFold ? fold_lds_bytes<BN>() : 0);
+  const size_t lds = (size_t)3 * (256 + BN) * ROWB + ((Epi::kFold || std::is_same<Epi, EpiResidPS>::value) ? fold_lds_bytes<BN>() : 0);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ps_split_kernel<BN, Epi, ABL, STAG, LEPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
