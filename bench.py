@@ -297,7 +297,7 @@ def main():
         "vit_gflop_per_cell": round(flops_cell / 1e9, 4),
         "vit_mfma_util_vs_bf16_dense": round(value * flops_cell / (world * PEAK_BF16_DENSE_TFLOPS * 1e12), 5),
         "mfma_cap_3_pass": 0.3333,      # three fp16 MFMA passes per product: the algorithmic fraction of the 16-bit dense peak cannot exceed 1/3
-        "lib_sha256": lib_sha256(),
+        "kernel_source_sha256": lib_sha256(),
     }
     if sharded:
         ag_ms = sum(a.elapsed_time(b) for a, b in ag_events)
@@ -342,13 +342,13 @@ def main():
         achieved = gemm_flops / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
         # committed rocprofv3 evidence for the same kernels (tools/collect_profiles.sh, tools/collect_pmc_sq.sh): HBM/fabric bytes per
         # launch from the FETCH_SIZE / WRITE_SIZE passes, MFMA-busy and LDS-active fractions from the SQ counter passes.  Both files
-        # carry the sha256 of the libribca_hip.so they were measured on: a different library being timed here -> null, not stale numbers
+        # carry the fingerprint of the kernel sources they were measured on: other sources being timed here -> null, not stale numbers
         traffic, traffic_src, busy, lds, pass_bytes = None, None, None, None, None
-        sha = out["lib_sha256"]
+        sha = out["kernel_source_sha256"]
         tpath = os.path.join(ROOT, "profiles", "r3", "gemm_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("lib_sha256") == sha:
+            if tj.get("kernel_source_sha256") == sha:
                 traffic = round(tj["traffic_bytes_per_launch"])
                 traffic_src = "profiles/r3/gemm_traffic.json"
                 if tj.get("vit_bytes_per_cell"):
@@ -356,7 +356,7 @@ def main():
         spath = os.path.join(ROOT, "profiles", "r3", "sq_summary.json")
         if os.path.exists(spath):
             sq = json.load(open(spath))
-            if sq.get("lib_sha256") == sha:
+            if sq.get("kernel_source_sha256") == sha:
                 gem = [v for k, v in sq.items() if k.startswith("gemm_ps_split_kernel") or k.startswith("gemm_ps_duo_kernel")]
                 cyc = sum(v["kernel_cycles"] for v in gem)
                 if cyc > 0:
@@ -414,11 +414,11 @@ def main():
 
 
 def lib_sha256():
-    """sha256 of the libribca_hip.so being timed (the committed counter files are stamped with the one they were measured on)"""
-    import hashlib
-    from multiplexed_image_annotator_amd import _lib
+    """fingerprint of the kernel sources + flags the timed library is built from (build.source_fingerprint; __graft_entry__.build()
+    has just rebuilt the library if any of them changed).  The committed counter files carry the one they were measured on."""
+    from multiplexed_image_annotator_amd import build as _build
     try:
-        return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+        return _build.source_fingerprint()
     except OSError:
         return None
 

@@ -19,6 +19,21 @@ HEADERS = ["ribca_common.h", "ribca_kernels.h", "gemm_epi.h", os.path.join("..",
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
+def source_fingerprint() -> str:
+    """sha256 over the kernel sources, headers and compile flags: identifies the code a measurement was taken on.  (The .so itself is
+    not byte-reproducible across checkout directories -- hipcc derives its compilation-unit ids from the source path -- so the
+    committed counter files are stamped with this instead; bench.py compares it with the tree it runs from.)"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES) + sorted(HEADERS):
+        path = os.path.normpath(os.path.join(CSRC, name))
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):

@@ -65,10 +65,12 @@ if launches:
     res["other_kernels"] = other
 import hashlib
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
 try:
-    res["lib_sha256"] = hashlib.sha256(open(os.path.join(root, "multiplexed-image-annotator_amd", "libribca_hip.so"), "rb").read()).hexdigest()
-except OSError:
-    res["lib_sha256"] = None
+    from multiplexed_image_annotator_amd import build as _build
+    res["kernel_source_sha256"] = _build.source_fingerprint()
+except Exception:
+    res["kernel_source_sha256"] = None
 # every kernel of the ViT forward (GEMMs, attention, statistics / LayerNorm, embed, head): counter bytes per CELL of the reduced pass
 vit = [k for k in fetch if "ribca::" in k and any(t in k for t in ("gemm_ps_", "attention", "layernorm", "row_stats", "ln_finalize", "embed_f32", "head_softmax", "cls_rows"))]
 n_cells_line = None

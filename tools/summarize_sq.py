@@ -48,11 +48,12 @@ for k, s in sorted(sums.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE@p1",
                  f"bank_conf {d['lds_bank_conflict_frac']:.4f}  wait_any {d['wait_any_of_wave_cycles']:.3f}  wait_inst {d['wait_inst_any_of_wave_cycles']:.3f}  "
                  f"wait_lds {d['wait_inst_lds_of_wave_cycles']:.3f}")
 import hashlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 try:
-    res["lib_sha256"] = hashlib.sha256(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multiplexed-image-annotator_amd",
-                                                         "libribca_hip.so"), "rb").read()).hexdigest()
-except OSError:
-    res["lib_sha256"] = None
+    from multiplexed_image_annotator_amd import build as _build
+    res["kernel_source_sha256"] = _build.source_fingerprint()
+except Exception:
+    res["kernel_source_sha256"] = None
 json.dump(res, open(os.path.join(out, "sq_summary.json"), "w"), indent=1)
 open(os.path.join(out, "sq_summary.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[:25]))
