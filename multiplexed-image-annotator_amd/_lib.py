@@ -69,6 +69,8 @@ SIGNATURES = {
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "ribca_test_gemm_duo_gelu": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_int32, c_void_p]),
+    "ribca_test_cell_attention": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                            c_void_p]),
     "ribca_gemm_padded_n": (c_int32, [c_int32]),
     "ribca_set_gemm_variant": (c_int32, [c_int32]),
     "ribca_set_gemm_stamps": (c_int32, [c_void_p, c_int64]),

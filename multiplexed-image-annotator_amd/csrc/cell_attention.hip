@@ -1,0 +1,309 @@
+// Per-cell fusion of  norm1 -> attn.qkv -> softmax(q k^T) v  for the classifiers with head dims <= 24 (D = 144: hd 12, D = 288: hd 24;
+// timm Block.norm1 / Attention reached from reference cell_type_annotation/model.py:54-55, 402).
+//
+// Why: per row and layer the unfused pair writes Q, K, V (12 D bytes) from the qkv GEMM and reads them back in the attention kernel
+// -- 24 D of the 88 D bytes a block moves -- and the qkv GEMM streams BOTH operands through L2 -> LDS (57 bytes per kMAC at 256 x 96
+// tiles).  Here one workgroup owns one cell: its 101 token rows of the packed-split residual stream are the MFMA operand of seven waves
+// for the whole kernel (registers: 16 rows x D each), only the weight streams (36 bytes per kMAC), and q, k, v never leave the CU.
+//
+// * grid = cells, 512 threads: waves 0-6 own tokens 16 w .. 16 w + 15 (rows >= 101 are clamped copies whose results are dropped),
+//   wave 7 only issues the direct-to-LDS weight loads (3-stage ring, one 32-deep K step of 144 weight rows = 18 KB per stage,
+//   counted vmcnt, one s_barrier per step, XOR-swizzled 128-byte rows exactly as gemm_split16.hip).
+// * heads are processed in GROUPS of 48 feature dims (2 heads of 24 or 4 heads of 12 = three 16-column MFMA tiles each for q, k
+//   and v): per group a 9-tile x K = D product per wave (transposed tiles: a lane holds 4 consecutive output columns of its token),
+//   then the folded LayerNorm  x = rstd acc + (-mean rstd c + b')  (gemm_epi.h), then attention for the group's heads.
+// * q stays in the registers of the wave that owns the queries; k is published to LDS in MFMA FRAGMENT order (a common permutation
+//   of the head's dims on q and k leaves q.k unchanged, so the accumulator layout IS the operand layout: lane (token, g) contributes
+//   columns 4g .. 4g+3 of the one or two 16-column tiles the head overlaps, the rest of the 32-deep K block is zero); v is published
+//   row-major (packed-split rows of 48 dims) and transposed on the way out of LDS with ds_read_b64_tr_b16, as attention.hip does.
+// * S^T = K Q^T per 16-key tile, softmax over keys in registers + two xor-shuffles, P in place as the next operand, O^T = V^T P^T:
+//   the arithmetic and its order per (query, key, dim) are those of gemm + attention.hip, so results agree to rounding with the
+//   unfused path (tests/test_gpu_kernels.py::test_cell_attention_fused compares with fp64 and with the unfused kernels).
+#include <cstdlib>
+
+#include "gemm_epi.h"
+#include "ribca_common.h"
+#include "ribca_kernels.h"
+
+namespace ribca {
+
+namespace {
+
+typedef __attribute__((__vector_size__(4 * sizeof(_Float16)))) _Float16 f16x4c;
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4c;
+__device__ __forceinline__ f16x4c lds_read_tr16c(const char* p) {
+  return __builtin_bit_cast(f16x4c, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4c __attribute__((address_space(3)))*)(p)));
+}
+
+constexpr int kGroupDims = 48;                 // feature dims per head group: 3 MFMA tiles each of q, k, v
+constexpr int kWRows = 3 * kGroupDims;         // weight rows per ring stage
+constexpr int kWStage = kWRows * ROWB;         // 18 KB
+constexpr int kRing = 3;
+constexpr int kTP = 112, kVRows = 128;
+
+template <int D, int HD> struct CellGeom {
+  static constexpr int Dp = (D + 31) / 32 * 32;
+  static constexpr int NK = Dp / 32;
+  static constexpr int GROUPS = D / kGroupDims;
+  static constexpr int HPG = kGroupDims / HD;  // heads per group
+  static constexpr int KIMG = kTP * ROWB;      // one head's K image: 112 tokens x 128 B (fragment order, swizzled like a GEMM tile)
+  static constexpr int VROWB = 4 * kGroupDims; // 192 B: 48 dims packed-split
+  static constexpr int VIMG = kVRows * VROWB + 64;
+  static constexpr int CB = 2 * 3 * D * 4;     // column sums and folded bias of the whole qkv product
+  static constexpr int OFF_K = kRing * kWStage;
+  static constexpr int OFF_V = OFF_K + HPG * KIMG;
+  static constexpr int OFF_CB = OFF_V + (VIMG + 15) / 16 * 16;
+  static constexpr int LDS = OFF_CB + CB;
+  static_assert(D % kGroupDims == 0 && kGroupDims % HD == 0 && HD % 4 == 0 && HD <= 32, "head geometry");
+};
+
+}  // namespace
+
+template <int D, int HD>
+__global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t* __restrict__ z, int ldz, const uint16_t* __restrict__ W, int ldw,
+                                                                 const float* __restrict__ bias2, const float* __restrict__ csum,
+                                                                 const float2* __restrict__ rowstat, uint16_t* __restrict__ out, int ldo, int T,
+                                                                 float scale) {
+  using G = CellGeom<D, HD>;
+  constexpr int NK = G::NK, GROUPS = G::GROUPS, HPG = G::HPG;
+  constexpr int TOTAL = GROUPS * NK;           // K steps of the whole cell
+  constexpr int GPL = kWRows / 8;              // 18 DMA instructions (1 KB each) per stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cell = blockIdx.x;
+  const int r16 = lane & 15, g = lane >> 4;
+
+  // ---- once per cell: column sums / folded bias of all 3 D outputs, zero rows behind V
+  for (int i = tid; i < 3 * D / 4; i += 512) {
+    reinterpret_cast<float4*>(smem + G::OFF_CB)[i] = reinterpret_cast<const float4*>(csum)[i];
+    reinterpret_cast<float4*>(smem + G::OFF_CB + 3 * D * 4)[i] = reinterpret_cast<const float4*>(bias2)[i];
+  }
+  for (int o = kTP * G::VROWB + tid * 16; o < G::VIMG; o += 512 * 16) *reinterpret_cast<uint4*>(smem + G::OFF_V + o) = uint4{0u, 0u, 0u, 0u};
+  __syncthreads();
+
+  if (wave == 7) {
+    // ------------------------------------------------------------------ loader: the weight stream of all head groups, two steps ahead
+    auto issue = [&](int step) {
+      const int hg = step / NK, s = step - hg * NK;
+      char* st = smem + (step % kRing) * kWStage;
+#pragma unroll
+      for (int i = 0; i < GPL; ++i) {
+        const int row = i * 8 + (lane >> 3);                   // 0 .. 143: [q 48 | k 48 | v 48] of this group
+        const int which = row / kGroupDims, c = row - which * kGroupDims;
+        const int n = which * D + hg * kGroupDims + c;
+        const int ch = (lane & 7) ^ swz_f(row);
+        const uint16_t* src = W + (size_t)n * ldw + s * (2 * BK) + ch * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(st + i * 1024), 16,
+                                         0, 0);
+      }
+    };
+    issue(0);
+    issue(1);
+    for (int step = 0; step < TOTAL; ++step) {
+      if (step + 1 < TOTAL) wait_vmcnt<GPL>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();                            // stage `step` landed; the slot of step - 1 has been read by everyone
+      asm volatile("" ::: "memory");
+      if (step + 2 < TOTAL) issue(step + 2);
+      if ((step + 1) % NK == 0) __builtin_amdgcn_s_barrier();  // the group's "k, v published" barrier
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumers: wave w owns tokens 16 w .. 16 w + 15
+  const int tok = wave * 16 + r16;
+  const int trow = tok < T ? tok : T - 1;                      // pad rows compute on a copy of the last token; nothing of theirs is stored
+  const uint16_t* zr = z + ((size_t)cell * T + trow) * ldz;
+  f16x8 ahi[NK], alo[NK];
+#pragma unroll
+  for (int s = 0; s < NK; ++s) {
+    const uint4* p = reinterpret_cast<const uint4*>(zr + (4 * s + g) * 16);
+    ahi[s] = __builtin_bit_cast(f16x8, p[0]);
+    alo[s] = __builtin_bit_cast(f16x8, p[1]);
+  }
+  const float2 rs = rowstat[(size_t)cell * T + trow];
+  const float rstd = rs.x, nm = -rs.y * rs.x;
+  const char* cb = smem + G::OFF_CB;
+  uint16_t* orow = out + ((size_t)cell * T + tok) * ldo;
+  int w_rd[3 * 3];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) w_rd[j] = lds_off(16 * j + r16, 2 * g);
+  const int k_wr = lds_off(tok, 2 * g);                        // this lane's 32 bytes (hi | lo) of a K image row
+  constexpr int KST = 4, NT = 7;
+
+  int step = 0;
+  for (int hg = 0; hg < GROUPS; ++hg) {
+    f32x4 acc[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NK; ++s, ++step) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char* st = smem + (step % kRing) * kWStage;
+#pragma unroll
+      for (int jb = 0; jb < 3; ++jb) {
+        f16x8 whi[3], wlo[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          whi[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(st + w_rd[3 * jb + j]));
+          wlo[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(st + (w_rd[3 * jb + j] ^ 16)));
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[3 * jb + j] = mfma_f16(wlo[j], ahi[s], acc[3 * jb + j]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[3 * jb + j] = mfma_f16(whi[j], alo[s], acc[3 * jb + j]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[3 * jb + j] = mfma_f16(whi[j], ahi[s], acc[3 * jb + j]);
+      }
+    }
+    // ---- folded LayerNorm + bias: tile j of part `which` holds output columns which D + 48 hg + 16 (j % 3) + 4 g .. + 3 of this token
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const int n = (j / 3) * D + hg * kGroupDims + 16 * (j % 3) + 4 * g;
+      const float4 c4 = *reinterpret_cast<const float4*>(cb + n * 4), b4 = *reinterpret_cast<const float4*>(cb + 3 * D * 4 + n * 4);
+      acc[j][0] = fmaf(rstd, acc[j][0], fmaf(nm, c4.x, b4.x));
+      acc[j][1] = fmaf(rstd, acc[j][1], fmaf(nm, c4.y, b4.y));
+      acc[j][2] = fmaf(rstd, acc[j][2], fmaf(nm, c4.z, b4.z));
+      acc[j][3] = fmaf(rstd, acc[j][3], fmaf(nm, c4.w, b4.w));
+    }
+    // ---- publish k (fragment order, one image per head) and v (row-major packed-split rows of 48 dims)
+    f16x8 qhi[HPG], qlo[HPG];
+#pragma unroll
+    for (int h = 0; h < HPG; ++h) {
+      constexpr int dummy = 0; (void)dummy;
+      const int d_lo = h * HD, d_hi = d_lo + HD;               // dims of this head inside the group
+      const int tA = d_lo / 16, tB = (d_hi - 1) / 16;
+      // a lane's 4 columns of a tile lie wholly inside or outside the head (HD % 4 == 0)
+      const bool inA = 16 * tA + 4 * g >= d_lo && 16 * tA + 4 * g < d_hi;
+      const bool inB = tB != tA && 16 * tB + 4 * g >= d_lo && 16 * tB + 4 * g < d_hi;
+      float qa[4], qb[4], ka[4], kb[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        qa[r] = inA ? acc[tA][r] * scale : 0.f;
+        qb[r] = inB ? acc[tB][r] * scale : 0.f;
+        ka[r] = inA ? acc[3 + tA][r] : 0.f;
+        kb[r] = inB ? acc[3 + tB][r] : 0.f;
+      }
+      uint2 h0, l0, h1, l1;
+      split4(qa, h0, l0);
+      split4(qb, h1, l1);
+      qhi[h] = __builtin_bit_cast(f16x8, uint4{h0.x, h0.y, h1.x, h1.y});
+      qlo[h] = __builtin_bit_cast(f16x8, uint4{l0.x, l0.y, l1.x, l1.y});
+      split4(ka, h0, l0);
+      split4(kb, h1, l1);
+      char* kimg = smem + G::OFF_K + h * G::KIMG;
+      *reinterpret_cast<uint4*>(kimg + k_wr) = uint4{h0.x, h0.y, h1.x, h1.y};
+      *reinterpret_cast<uint4*>(kimg + (k_wr ^ 16)) = uint4{l0.x, l0.y, l1.x, l1.y};
+    }
+    {
+      uint16_t* vrow = reinterpret_cast<uint16_t*>(smem + G::OFF_V + tok * G::VROWB);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float v4[4] = {acc[6 + j][0], acc[6 + j][1], acc[6 + j][2], acc[6 + j][3]};
+        ps_store4_pair<16>(vrow, 16 * j + 4 * g, v4);          // lanes g and g ^ 1 complete an 8-dim group: 16 bytes each
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                              // k, v of every token are in LDS
+    asm volatile("" ::: "memory");
+
+    // ---- attention of the group's heads for this wave's 16 queries
+#pragma unroll
+    for (int h = 0; h < HPG; ++h) {
+      const char* kimg = smem + G::OFF_K + h * G::KIMG;
+      f32x4 s[2 * KST];
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+        const int ko = lds_off(16 * kt + r16, 2 * g);
+        const f16x8 kh = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(kimg + ko));
+        const f16x8 kl = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(kimg + (ko ^ 16)));
+        s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        s[kt] = mfma_f16(kl, qhi[h], s[kt]);
+        s[kt] = mfma_f16(kh, qlo[h], s[kt]);
+        s[kt] = mfma_f16(kh, qhi[h], s[kt]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * (NT - 1) + 4 * g + r >= T) s[NT - 1][r] = -INFINITY;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __expf(s[kt][r] - mx);
+          s[kt][r] = e;
+          sum += e;
+        }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.0f / sum;
+      s[NT] = f32x4{0.f, 0.f, 0.f, 0.f};
+      f16x8 phi[KST], plo[KST];
+#pragma unroll
+      for (int t = 0; t < KST; ++t) {
+        float pa[4], pb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pa[r] = s[2 * t][r] * inv; pb[r] = s[2 * t + 1][r] * inv; }
+        uint2 ha, la, hb, lb;
+        split4(pa, ha, la);
+        split4(pb, hb, lb);
+        phi[t] = __builtin_bit_cast(f16x8, uint4{ha.x, ha.y, hb.x, hb.y});
+        plo[t] = __builtin_bit_cast(f16x8, uint4{la.x, la.y, lb.x, lb.y});
+      }
+      constexpr int DT = (HD + 15) / 16;
+      const char* vimg = smem + G::OFF_V;
+      const int head = hg * HPG + h;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int dcol = h * HD + 16 * dt + 4 * (r16 & 3);     // first of the 4 dims this lane addresses for the transposed read
+        const int voff = (dcol >> 3) * 32 + (dcol & 7) * 2;    // byte offset of their hi halves inside a V row; + 16: lo halves
+#pragma unroll
+        for (int t = 0; t < KST; ++t) {
+          const char* va = vimg + (32 * t + 4 * g + (r16 >> 2)) * G::VROWB + voff;
+          const f16x4c h0 = lds_read_tr16c(va), l0 = lds_read_tr16c(va + 16);
+          const f16x4c h1 = lds_read_tr16c(va + 16 * G::VROWB), l1 = lds_read_tr16c(va + 16 * G::VROWB + 16);
+          const f16x8 vhi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+          const f16x8 vlo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+          o = mfma_f16(vlo, phi[t], o);
+          o = mfma_f16(vhi, plo[t], o);
+          o = mfma_f16(vhi, phi[t], o);
+        }
+        const int d = 16 * dt + 4 * g;                         // o[r] = O[query tok][head dim d + r]
+        if (tok < T && d < HD) {
+          const float v4[4] = {o[0], o[1], o[2], o[3]};
+          ps_store4(orow, head * HD + d, v4);
+        }
+      }
+    }
+  }
+}
+
+bool cell_attention_supported(int D, int H, int T) { return H == kHeads && T == kTokens && (D == 144 || D == 288); }
+
+void launch_cell_qkv_attention(const uint16_t* z, int ldz, const uint16_t* W, int ldw, const float* bias2, const float* csum, const float2* rowstat,
+                               uint16_t* out, int ldo, int cells, int D, float scale, hipStream_t s) {
+  if (cells <= 0) return;
+  auto go = [&](auto kern, int lds) {
+    static bool attr_set[2] = {false, false};
+    const int slot = D == 288 ? 1 : 0;
+    if (!attr_set[slot]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_set[slot] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(cells), dim3(512), lds, s, z, ldz, W, ldw, bias2, csum, rowstat, out, ldo, (int)kTokens, scale);
+  };
+  if (D == 288) go(cell_qkv_attention_kernel<288, 24>, CellGeom<288, 24>::LDS);
+  else go(cell_qkv_attention_kernel<144, 12>, CellGeom<144, 12>::LDS);
+}
+
+}  // namespace ribca

@@ -320,15 +320,25 @@ void resid_ps_and_stats(const GemmArgs& g, const BlockWs& w, int ldz_rows, int D
   launch_gemm_resid_ps(g, w.zps, ldz_rows, want_stats ? w.part : nullptr, w.rs, prev_stride, s);
   if (want_stats) launch_ln_finalize(w.part, gemm_resid_tiles(D), g.M, gemm_resid_bn(D), D, w.rs, s);
 }
+// RIBCA_CELL_ATTN=1: norm1 -> qkv -> attention of a whole block in ONE per-cell kernel (cell_attention.hip) where the geometry allows
+bool cell_attn_on(const AttnGeom& a) {
+  static const int v = getenv("RIBCA_CELL_ATTN") ? atoi(getenv("RIBCA_CELL_ATTN")) : 0;
+  return v != 0 && cell_attention_supported(a.D, a.H, a.T);
+}
 void run_block_fold(const BlockW& L, const BlockWs& w, int cells, const AttnGeom& a, hipStream_t s) {
   const int D = a.D, Dp = round_up(D, 32), ld_x = 2 * Dp, ld_h = 2 * 4 * D, Mc = cells * a.T;
   const float scale = 1.0f / sqrtf((float)a.hd);
-  {
+  if (cell_attn_on(a)) {
     ProfScope ps(P_QKV, s);
-    GemmArgs g{w.zps, ld_x, L.qkvw, ld_x, Mc, 3 * D, Dp, L.qkvb2, L.qkvwf};
-    launch_gemm_qkv_ln(g, w.rs, L.qkvc, w.q, w.k, w.vt, a, scale, s);
+    launch_cell_qkv_attention(w.zps, ld_x, L.qkvw, ld_x, L.qkvb2, L.qkvc, w.rs, w.xa, ld_x, cells, D, scale, s);
+  } else {
+    {
+      ProfScope ps(P_QKV, s);
+      GemmArgs g{w.zps, ld_x, L.qkvw, ld_x, Mc, 3 * D, Dp, L.qkvb2, L.qkvwf};
+      launch_gemm_qkv_ln(g, w.rs, L.qkvc, w.q, w.k, w.vt, a, scale, s);
+    }
+    { ProfScope ps(P_ATTN, s); launch_attention(w.q, w.k, w.vt, w.xa, ld_x, cells, a, s); }
   }
-  { ProfScope ps(P_ATTN, s); launch_attention(w.q, w.k, w.vt, w.xa, ld_x, cells, a, s); }
   {
     ProfScope ps(P_PROJ, s);
     GemmArgs g{w.xa, ld_x, L.projw, ld_x, Mc, D, Dp, L.projb};
@@ -857,6 +867,12 @@ int ribca_test_qkv_attention_fold(const uint16_t* z_ps, int32_t lda, const uint1
                                   const float* bias2, const float* csum, const float* rowstat, uint16_t* q, uint16_t* k, uint16_t* vt,
                                   uint16_t* out, int32_t ldo, void* stream) {
   const AttnGeom a = make_attn_geom(D, kHeads, kTokens);
+  if (cell_attn_on(a)) {      // (q, k, vt stay untouched: the fused kernel keeps them on chip)
+    launch_cell_qkv_attention(z_ps, lda, W, ldw, bias2, csum, reinterpret_cast<const float2*>(rowstat), out, ldo, cells, D, 1.0f / sqrtf((float)a.hd),
+                              (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   GemmArgs g{z_ps, lda, W, ldw, cells * kTokens, 3 * D, Kp, bias2};
   launch_gemm_qkv_ln(g, reinterpret_cast<const float2*>(rowstat), csum, q, k, vt, a, 1.0f / sqrtf((float)a.hd), (hipStream_t)stream);
   launch_attention(q, k, vt, out, ldo, cells, a, (hipStream_t)stream);
@@ -873,6 +889,14 @@ int ribca_test_gemm_duo_gelu(const uint16_t* A, int32_t lda, const uint16_t* W, 
   GemmArgs g{A, lda, W, ldw, M, N, Kp, bias, wf_scratch};
   if (csum) launch_gemm_gelu_ln(g, reinterpret_cast<const float2*>(rowstat), csum, out, ldo, (hipStream_t)stream);
   else launch_gemm_gelu(g, out, ldo, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int ribca_test_cell_attention(const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t cells, int32_t D,
+                              const float* bias2, const float* csum, const float* rowstat, uint16_t* out, int32_t ldo, void* stream) {
+  if (!cell_attention_supported(D, kHeads, kTokens)) return fail("ribca_test_cell_attention: D must be 144 or 288");
+  launch_cell_qkv_attention(z_ps, lda, W, ldw, bias2, csum, reinterpret_cast<const float2*>(rowstat), out, ldo, cells, D,
+                            1.0f / sqrtf((float)(D / kHeads)), (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -63,6 +63,13 @@ void launch_gemm_rowmap(const GemmArgs& g, float* out, int ldo, const float* add
 void launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int ldo, int cells, const AttnGeom& a,
                       hipStream_t s, int q_tiles = 0);
 
+// ----- per-cell fusion norm1 -> qkv -> attention (cell_attention.hip): D = 144 / 288 (head dims 12 / 24), 101 tokens, 12 heads.
+// z: packed-split residual rows, W / bias2 / csum: the folded qkv weight (row-major packed-split) and its vectors, rowstat: (rstd, mean)
+// per row; out: packed-split attention output rows.  Replaces launch_gemm_qkv_ln + launch_attention for whole blocks.
+bool cell_attention_supported(int D, int H, int T);
+void launch_cell_qkv_attention(const uint16_t* z, int ldz, const uint16_t* W, int ldw, const float* bias2, const float* csum, const float2* rowstat,
+                               uint16_t* out, int ldo, int cells, int D, float scale, hipStream_t s);
+
 // ----- small ViT kernels (vit_misc.hip) ----------------------------------------------------------------------
 void launch_layernorm_ps(const float* z, int ldz, const float* gamma, const float* beta, uint16_t* out, int ldo, int M, int D,
                          hipStream_t s);

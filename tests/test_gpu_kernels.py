@@ -383,6 +383,45 @@ def test_qkv_attention_fold(dev, d, cells, mean, std):
     assert err < 4e-5 * amp, err
 
 
+@pytest.mark.parametrize("d,cells", [(144, 1), (288, 1), (144, 37), (288, 130), (288, 600)])
+@pytest.mark.parametrize("mean,std", [(0.5, 1.0), (30.0, 1.0)])
+def test_cell_attention_fused(dev, d, cells, mean, std):
+    """cell_attention.hip: norm1 -> qkv -> attention of one cell per workgroup (q, k, v stay on chip) against LayerNorm + qkv + softmax
+    attention in fp64 and against the unfused kernels on the same inputs"""
+    from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
+    heads, ntok = 12, 101
+    hd = d // heads
+    hdp = (hd + 7) // 8 * 8
+    m = cells * ntok
+    z_ps, zq, g, b, dp = _ln_case(m, d, 80, dev, mean, std)
+    w = rnd((3 * d, d), 83, dev, 1.0 / np.sqrt(d))
+    bias = rnd((3 * d,), 84, dev, 0.1)
+    w_ps, csum, bias2 = _fold(w, g, b, bias, dp, dev)
+    rs = _row_stats(z_ps, dp, m, d, dev)
+    out = torch.zeros((m, 2 * dp), dtype=torch.int16, device=dev)
+    check(lib().ribca_test_cell_attention(ptr(z_ps), 2 * dp, ptr(w_ps), 2 * dp, cells, d, ptr(bias2), ptr(csum), ptr(rs), ptr(out), 2 * dp, stream_ptr()),
+          "cell attention")
+    ln = torch.nn.functional.layer_norm(zq, (d,), g.double(), b.double(), 1e-6)
+    qkv = (ln @ w.double().t() + bias.double()).reshape(cells, ntok, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    att = torch.softmax(qkv[0] @ qkv[1].transpose(-1, -2) * hd ** -0.5, dim=-1) @ qkv[2]
+    ref = att.permute(0, 2, 1, 3).reshape(m, d)
+    got = ps_decode(out, d)
+    err = (got - ref).abs().max().item()
+    note_err(f"cell_attention_fused d={d} cells={cells} mean {mean}", err)
+    assert err < 4e-5 * (1.0 + abs(mean) / std), err           # test_qkv_attention_fold's bound
+    assert torch.all(ps_decode(out, dp)[:, d:] == 0)
+    # the unfused pair on the same inputs: the same arithmetic up to the order of two roundings (q, k are split before / after the
+    # head permutation, identical values) -- far inside the bound above
+    q = torch.zeros((cells, heads, 112, 2 * hdp), dtype=torch.int16, device=dev)
+    k, vt = torch.zeros_like(q), torch.zeros_like(q)
+    out2 = torch.zeros_like(out)
+    check(lib().ribca_test_qkv_attention_fold(ptr(z_ps), 2 * dp, ptr(w_ps), 2 * dp, cells, d, dp, ptr(bias2), ptr(csum), ptr(rs), ptr(q), ptr(k), ptr(vt),
+                                              ptr(out2), 2 * dp, stream_ptr()), "unfused")
+    d2 = (got - ps_decode(out2, d)).abs().max().item()
+    note_err(f"cell_attention_fused vs unfused d={d}", d2)
+    assert d2 < 1e-5 * (1.0 + abs(mean) / std), d2
+
+
 @pytest.mark.parametrize("d,cells", [(144, 3), (288, 3), (384, 3), (576, 3), (288, 130), (384, 130), (576, 131), (288, 400)])
 def test_qkv_attention(dev, d, cells):
     from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
