@@ -38,7 +38,6 @@ __device__ __forceinline__ f16x4c lds_read_tr16c(const char* p) {
 constexpr int kGroupDims = 48;                 // feature dims per head group: 3 MFMA tiles each of q, k, v
 constexpr int kWRows = 3 * kGroupDims;         // weight rows per ring stage
 constexpr int kWStage = kWRows * ROWB;         // 18 KB
-constexpr int kRing = 3;
 constexpr int kTP = 112, kVRows = 128;
 
 template <int D, int HD> struct CellGeom {
@@ -50,7 +49,8 @@ template <int D, int HD> struct CellGeom {
   static constexpr int VROWB = 4 * kGroupDims; // 192 B: 48 dims packed-split
   static constexpr int VIMG = kVRows * VROWB + 64;
   static constexpr int CB = 2 * 3 * D * 4;     // column sums and folded bias of the whole qkv product
-  static constexpr int OFF_K = kRing * kWStage;
+  static constexpr int RING = 3;               // stage s + 1 is written while stage s is read; the slot of s - 1 is free by then
+  static constexpr int OFF_K = RING * kWStage;
   static constexpr int OFF_V = OFF_K + HPG * KIMG;
   static constexpr int OFF_CB = OFF_V + (VIMG + 15) / 16 * 16;
   static constexpr int LDS = OFF_CB + CB;
@@ -63,9 +63,9 @@ template <int D, int HD>
 __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t* __restrict__ z, int ldz, const uint16_t* __restrict__ W, int ldw,
                                                                  const float* __restrict__ bias2, const float* __restrict__ csum,
                                                                  const float2* __restrict__ rowstat, uint16_t* __restrict__ out, int ldo, int T,
-                                                                 float scale) {
+                                                                 float scale, int dbg) {
   using G = CellGeom<D, HD>;
-  constexpr int NK = G::NK, GROUPS = G::GROUPS, HPG = G::HPG;
+  constexpr int NK = G::NK, GROUPS = G::GROUPS, HPG = G::HPG, kRing = G::RING;
   constexpr int TOTAL = GROUPS * NK;           // K steps of the whole cell
   constexpr int GPL = kWRows / 8;              // 18 DMA instructions (1 KB each) per stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -83,7 +83,11 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
   __syncthreads();
 
   if (wave == 7) {
-    // ------------------------------------------------------------------ loader: the weight stream of all head groups, two steps ahead
+    // ------------------------------------------------------------------ loader: the weight stream of all head groups, two steps ahead.
+    // (ONE wave issues an LDS-DMA instruction every ~67 cycles = 30 GB/s, and that stream is the kernel's floor: 131 of 300 us at
+    // D = 288 with neither MFMAs nor attention, tools/bench_cell_attention.py.  A deeper ring does not help -- issue-bound, not
+    // latency-bound -- and a register-staged loader (global_load_dwordx4 + ds_write_b128, one or two stages in flight) was 2.4-5x
+    // slower: profiles/r3/cell_attention_loader_experiments.txt.  The GEMMs use four loader waves for this reason.)
     auto issue = [&](int step) {
       const int hg = step / NK, s = step - hg * NK;
       char* st = smem + (step % kRing) * kWStage;
@@ -142,6 +146,7 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       const char* st = smem + (step % kRing) * kWStage;
+      if (dbg & 2) continue;                                   // timing ablation: barriers and the weight stream only
 #pragma unroll
       for (int jb = 0; jb < 3; ++jb) {
         f16x8 whi[3], wlo[3];
@@ -209,79 +214,93 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
     __builtin_amdgcn_s_barrier();                              // k, v of every token are in LDS
     asm volatile("" ::: "memory");
 
-    // ---- attention of the group's heads for this wave's 16 queries
+    if (dbg & 1) continue;                                     // timing ablation (RIBCA_CELL_DBG=1): no attention phase, results wrong
+    // ---- attention of the group's heads for this wave's 16 queries, TWO heads at a time: the S^T MFMAs of one head cover the softmax
+    // VALU of the other, and the two P V products interleave (a wave is in-order: without a second independent chain every
+    // exp / split waits behind the MFMAs that feed it)
+    constexpr int DT = (HD + 15) / 16;
+    const char* vimg = smem + G::OFF_V;
 #pragma unroll
-    for (int h = 0; h < HPG; ++h) {
-      const char* kimg = smem + G::OFF_K + h * G::KIMG;
-      f32x4 s[2 * KST];
+    for (int hp = 0; hp < HPG; hp += 2) {
+      f32x4 s[2][2 * KST];
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
         const int ko = lds_off(16 * kt + r16, 2 * g);
-        const f16x8 kh = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(kimg + ko));
-        const f16x8 kl = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(kimg + (ko ^ 16)));
-        s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        s[kt] = mfma_f16(kl, qhi[h], s[kt]);
-        s[kt] = mfma_f16(kh, qlo[h], s[kt]);
-        s[kt] = mfma_f16(kh, qhi[h], s[kt]);
-      }
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (16 * (NT - 1) + 4 * g + r >= T) s[NT - 1][r] = -INFINITY;
-      float mx = -INFINITY;
-#pragma unroll
-      for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      float sum = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __expf(s[kt][r] - mx);
-          s[kt][r] = e;
-          sum += e;
+        for (int e = 0; e < 2; ++e) {
+          const char* kimg = smem + G::OFF_K + (hp + e) * G::KIMG;
+          const f16x8 kh = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(kimg + ko));
+          const f16x8 kl = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(kimg + (ko ^ 16)));
+          s[e][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          s[e][kt] = mfma_f16(kl, qhi[hp + e], s[e][kt]);
+          s[e][kt] = mfma_f16(kh, qlo[hp + e], s[e][kt]);
+          s[e][kt] = mfma_f16(kh, qhi[hp + e], s[e][kt]);
         }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
-      const float inv = 1.0f / sum;
-      s[NT] = f32x4{0.f, 0.f, 0.f, 0.f};
-      f16x8 phi[KST], plo[KST];
-#pragma unroll
-      for (int t = 0; t < KST; ++t) {
-        float pa[4], pb[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { pa[r] = s[2 * t][r] * inv; pb[r] = s[2 * t + 1][r] * inv; }
-        uint2 ha, la, hb, lb;
-        split4(pa, ha, la);
-        split4(pb, hb, lb);
-        phi[t] = __builtin_bit_cast(f16x8, uint4{ha.x, ha.y, hb.x, hb.y});
-        plo[t] = __builtin_bit_cast(f16x8, uint4{la.x, la.y, lb.x, lb.y});
       }
-      constexpr int DT = (HD + 15) / 16;
-      const char* vimg = smem + G::OFF_V;
-      const int head = hg * HPG + h;
+      f16x8 phi[2][KST], plo[2][KST];
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int dcol = h * HD + 16 * dt + 4 * (r16 & 3);     // first of the 4 dims this lane addresses for the transposed read
-        const int voff = (dcol >> 3) * 32 + (dcol & 7) * 2;    // byte offset of their hi halves inside a V row; + 16: lo halves
+      for (int e = 0; e < 2; ++e) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * (NT - 1) + 4 * g + r >= T) s[e][NT - 1][r] = -INFINITY;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[e][kt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float ex = __expf(s[e][kt][r] - mx);
+            s[e][kt][r] = ex;
+            sum += ex;
+          }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        s[e][NT] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < KST; ++t) {
-          const char* va = vimg + (32 * t + 4 * g + (r16 >> 2)) * G::VROWB + voff;
-          const f16x4c h0 = lds_read_tr16c(va), l0 = lds_read_tr16c(va + 16);
-          const f16x4c h1 = lds_read_tr16c(va + 16 * G::VROWB), l1 = lds_read_tr16c(va + 16 * G::VROWB + 16);
-          const f16x8 vhi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-          const f16x8 vlo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-          o = mfma_f16(vlo, phi[t], o);
-          o = mfma_f16(vhi, plo[t], o);
-          o = mfma_f16(vhi, phi[t], o);
+          float pa[4], pb[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { pa[r] = s[e][2 * t][r] * inv; pb[r] = s[e][2 * t + 1][r] * inv; }
+          uint2 ha, la, hb, lb;
+          split4(pa, ha, la);
+          split4(pb, hb, lb);
+          phi[e][t] = __builtin_bit_cast(f16x8, uint4{ha.x, ha.y, hb.x, hb.y});
+          plo[e][t] = __builtin_bit_cast(f16x8, uint4{la.x, la.y, lb.x, lb.y});
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int t = 0; t < KST; ++t) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int dcol = (hp + e) * HD + 16 * dt + 4 * (r16 & 3);     // first of the 4 dims this lane addresses for the transposed read
+            const int voff = (dcol >> 3) * 32 + (dcol & 7) * 2;           // byte offset of their hi halves inside a V row; + 16: lo halves
+            const char* va = vimg + (32 * t + 4 * g + (r16 >> 2)) * G::VROWB + voff;
+            const f16x4c h0 = lds_read_tr16c(va), l0 = lds_read_tr16c(va + 16);
+            const f16x4c h1 = lds_read_tr16c(va + 16 * G::VROWB), l1 = lds_read_tr16c(va + 16 * G::VROWB + 16);
+            const f16x8 vhi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            const f16x8 vlo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+            o[e] = mfma_f16(vlo, phi[e][t], o[e]);
+            o[e] = mfma_f16(vhi, plo[e][t], o[e]);
+            o[e] = mfma_f16(vhi, phi[e][t], o[e]);
+          }
         }
         const int d = 16 * dt + 4 * g;                         // o[r] = O[query tok][head dim d + r]
         if (tok < T && d < HD) {
-          const float v4[4] = {o[0], o[1], o[2], o[3]};
-          ps_store4(orow, head * HD + d, v4);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float v4[4] = {o[e][0], o[e][1], o[e][2], o[e][3]};
+            ps_store4(orow, (hg * HPG + hp + e) * HD + d, v4);
+          }
         }
       }
     }
@@ -300,7 +319,8 @@ void launch_cell_qkv_attention(const uint16_t* z, int ldz, const uint16_t* W, in
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       attr_set[slot] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(cells), dim3(512), lds, s, z, ldz, W, ldw, bias2, csum, rowstat, out, ldo, (int)kTokens, scale);
+    static const int dbg = getenv("RIBCA_CELL_DBG") ? atoi(getenv("RIBCA_CELL_DBG")) : 0;      // timing ablations of tools/bench_cell_attention.py
+    hipLaunchKernelGGL(kern, dim3(cells), dim3(512), lds, s, z, ldz, W, ldw, bias2, csum, rowstat, out, ldo, (int)kTokens, scale, dbg);
   };
   if (D == 288) go(cell_qkv_attention_kernel<288, 24>, CellGeom<288, 24>::LDS);
   else go(cell_qkv_attention_kernel<144, 12>, CellGeom<144, 12>::LDS);
