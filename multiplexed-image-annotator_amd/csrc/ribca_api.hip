@@ -320,9 +320,10 @@ void resid_ps_and_stats(const GemmArgs& g, const BlockWs& w, int ldz_rows, int D
   launch_gemm_resid_ps(g, w.zps, ldz_rows, want_stats ? w.part : nullptr, w.rs, prev_stride, s);
   if (want_stats) launch_ln_finalize(w.part, gemm_resid_tiles(D), g.M, gemm_resid_bn(D), D, w.rs, s);
 }
-// RIBCA_CELL_ATTN=1: norm1 -> qkv -> attention of a whole block in ONE per-cell kernel (cell_attention.hip) where the geometry allows
+// norm1 -> qkv -> attention of a whole block in ONE per-cell kernel (cell_attention.hip) where the geometry allows (D = 144, 288):
+// 13.9 -> 14.4 k cells/s in a same-box A/B (profiles/r3/ab_cell_attention.txt).  RIBCA_CELL_ATTN=0: the unfused pair, for A/B.
 bool cell_attn_on(const AttnGeom& a) {
-  static const int v = getenv("RIBCA_CELL_ATTN") ? atoi(getenv("RIBCA_CELL_ATTN")) : 0;
+  static const int v = getenv("RIBCA_CELL_ATTN") ? atoi(getenv("RIBCA_CELL_ATTN")) : 1;
   return v != 0 && cell_attention_supported(a.D, a.H, a.T);
 }
 void run_block_fold(const BlockW& L, const BlockWs& w, int cells, const AttnGeom& a, hipStream_t s) {
