@@ -868,12 +868,6 @@ int ribca_test_qkv_attention_fold(const uint16_t* z_ps, int32_t lda, const uint1
                                   const float* bias2, const float* csum, const float* rowstat, uint16_t* q, uint16_t* k, uint16_t* vt,
                                   uint16_t* out, int32_t ldo, void* stream) {
   const AttnGeom a = make_attn_geom(D, kHeads, kTokens);
-  if (cell_attn_on(a)) {      // (q, k, vt stay untouched: the fused kernel keeps them on chip)
-    launch_cell_qkv_attention(z_ps, lda, W, ldw, bias2, csum, reinterpret_cast<const float2*>(rowstat), out, ldo, cells, D, 1.0f / sqrtf((float)a.hd),
-                              (hipStream_t)stream);
-    HIP_TRY(hipGetLastError());
-    return 0;
-  }
   GemmArgs g{z_ps, lda, W, ldw, cells * kTokens, 3 * D, Kp, bias2};
   launch_gemm_qkv_ln(g, reinterpret_cast<const float2*>(rowstat), csum, q, k, vt, a, 1.0f / sqrtf((float)a.hd), (hipStream_t)stream);
   launch_attention(q, k, vt, out, ldo, cells, a, (hipStream_t)stream);
