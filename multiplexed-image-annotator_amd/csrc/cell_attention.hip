@@ -35,26 +35,27 @@ __device__ __forceinline__ f16x4c lds_read_tr16c(const char* p) {
   return __builtin_bit_cast(f16x4c, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4c __attribute__((address_space(3)))*)(p)));
 }
 
-constexpr int kGroupDims = 48;                 // feature dims per head group: 3 MFMA tiles each of q, k, v
-constexpr int kWRows = 3 * kGroupDims;         // weight rows per ring stage
-constexpr int kWStage = kWRows * ROWB;         // 18 KB
 constexpr int kTP = 112, kVRows = 128;
 
 template <int D, int HD> struct CellGeom {
   static constexpr int Dp = (D + 31) / 32 * 32;
   static constexpr int NK = Dp / 32;
-  static constexpr int GROUPS = D / kGroupDims;
-  static constexpr int HPG = kGroupDims / HD;  // heads per group
+  static constexpr int GD = HD == 32 ? 64 : 48;  // feature dims per head group: two heads of 24 or 32, four of 12 -> 3 or 4 MFMA tiles each of q, k, v
+  static constexpr int NTP = GD / 16;          // 16-column tiles per part (q, k, v)
+  static constexpr int WROWS = 3 * GD;         // weight rows per ring stage
+  static constexpr int WSTAGE = WROWS * ROWB;  // 18 or 24 KB
+  static constexpr int GROUPS = D / GD;
+  static constexpr int HPG = GD / HD;          // heads per group
   static constexpr int KIMG = kTP * ROWB;      // one head's K image: 112 tokens x 128 B (fragment order, swizzled like a GEMM tile)
-  static constexpr int VROWB = 4 * kGroupDims; // 192 B: 48 dims packed-split
+  static constexpr int VROWB = 4 * GD;         // 192 / 256 B: the group's dims packed-split
   static constexpr int VIMG = kVRows * VROWB + 64;
   static constexpr int CB = 2 * 3 * D * 4;     // column sums and folded bias of the whole qkv product
   static constexpr int RING = 3;               // stage s + 1 is written while stage s is read; the slot of s - 1 is free by then
-  static constexpr int OFF_K = RING * kWStage;
+  static constexpr int OFF_K = RING * WSTAGE;
   static constexpr int OFF_V = OFF_K + HPG * KIMG;
   static constexpr int OFF_CB = OFF_V + (VIMG + 15) / 16 * 16;
   static constexpr int LDS = OFF_CB + CB;
-  static_assert(D % kGroupDims == 0 && kGroupDims % HD == 0 && HD % 4 == 0 && HD <= 32, "head geometry");
+  static_assert(D % GD == 0 && GD % HD == 0 && HD % 4 == 0 && HD <= 32 && HPG % 2 == 0 && WROWS % 8 == 0, "head geometry");
 };
 
 }  // namespace
@@ -65,9 +66,10 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
                                                                  const float2* __restrict__ rowstat, uint16_t* __restrict__ out, int ldo, int T,
                                                                  float scale, int dbg) {
   using G = CellGeom<D, HD>;
-  constexpr int NK = G::NK, GROUPS = G::GROUPS, HPG = G::HPG, kRing = G::RING;
+  constexpr int NK = G::NK, GROUPS = G::GROUPS, HPG = G::HPG, kRing = G::RING, kGroupDims = G::GD, NTP = G::NTP, kWStage = G::WSTAGE;
+  constexpr int NTILES = 3 * NTP;              // accumulator tiles per wave and group: q | k | v
   constexpr int TOTAL = GROUPS * NK;           // K steps of the whole cell
-  constexpr int GPL = kWRows / 8;              // 18 DMA instructions (1 KB each) per stage
+  constexpr int GPL = G::WROWS / 8;            // 18 / 24 DMA instructions (1 KB each) per stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
       char* st = smem + (step % kRing) * kWStage;
 #pragma unroll
       for (int i = 0; i < GPL; ++i) {
-        const int row = i * 8 + (lane >> 3);                   // 0 .. 143: [q 48 | k 48 | v 48] of this group
+        const int row = i * 8 + (lane >> 3);                   // [q GD | k GD | v GD] rows of this group
         const int which = row / kGroupDims, c = row - which * kGroupDims;
         const int n = which * D + hg * kGroupDims + c;
         const int ch = (lane & 7) ^ swz_f(row);
@@ -130,17 +132,17 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
   const float rstd = rs.x, nm = -rs.y * rs.x;
   const char* cb = smem + G::OFF_CB;
   uint16_t* orow = out + ((size_t)cell * T + tok) * ldo;
-  int w_rd[3 * 3];
+  int w_rd[NTILES];
 #pragma unroll
-  for (int j = 0; j < 9; ++j) w_rd[j] = lds_off(16 * j + r16, 2 * g);
+  for (int j = 0; j < NTILES; ++j) w_rd[j] = lds_off(16 * j + r16, 2 * g);
   const int k_wr = lds_off(tok, 2 * g);                        // this lane's 32 bytes (hi | lo) of a K image row
   constexpr int KST = 4, NT = 7;
 
   int step = 0;
   for (int hg = 0; hg < GROUPS; ++hg) {
-    f32x4 acc[9];
+    f32x4 acc[NTILES];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NTILES; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NK; ++s, ++step) {
       __builtin_amdgcn_s_barrier();
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
       const char* st = smem + (step % kRing) * kWStage;
       if (dbg & 2) continue;                                   // timing ablation: barriers and the weight stream only
 #pragma unroll
-      for (int jb = 0; jb < 3; ++jb) {
+      for (int jb = 0; jb < NTILES / 3; ++jb) {
         f16x8 whi[3], wlo[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -165,8 +167,8 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
     }
     // ---- folded LayerNorm + bias: tile j of part `which` holds output columns which D + 48 hg + 16 (j % 3) + 4 g .. + 3 of this token
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      const int n = (j / 3) * D + hg * kGroupDims + 16 * (j % 3) + 4 * g;
+    for (int j = 0; j < NTILES; ++j) {
+      const int n = (j / NTP) * D + hg * kGroupDims + 16 * (j % NTP) + 4 * g;
       const float4 c4 = *reinterpret_cast<const float4*>(cb + n * 4), b4 = *reinterpret_cast<const float4*>(cb + 3 * D * 4 + n * 4);
       acc[j][0] = fmaf(rstd, acc[j][0], fmaf(nm, c4.x, b4.x));
       acc[j][1] = fmaf(rstd, acc[j][1], fmaf(nm, c4.y, b4.y));
@@ -188,8 +190,8 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
       for (int r = 0; r < 4; ++r) {
         qa[r] = inA ? acc[tA][r] * scale : 0.f;
         qb[r] = inB ? acc[tB][r] * scale : 0.f;
-        ka[r] = inA ? acc[3 + tA][r] : 0.f;
-        kb[r] = inB ? acc[3 + tB][r] : 0.f;
+        ka[r] = inA ? acc[NTP + tA][r] : 0.f;
+        kb[r] = inB ? acc[NTP + tB][r] : 0.f;
       }
       uint2 h0, l0, h1, l1;
       split4(qa, h0, l0);
@@ -205,9 +207,12 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
     {
       uint16_t* vrow = reinterpret_cast<uint16_t*>(smem + G::OFF_V + tok * G::VROWB);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const float v4[4] = {acc[6 + j][0], acc[6 + j][1], acc[6 + j][2], acc[6 + j][3]};
-        ps_store4_pair<16>(vrow, 16 * j + 4 * g, v4);          // lanes g and g ^ 1 complete an 8-dim group: 16 bytes each
+      for (int j = 0; j < NTP; ++j) {
+        const float v4[4] = {acc[2 * NTP + j][0], acc[2 * NTP + j][1], acc[2 * NTP + j][2], acc[2 * NTP + j][3]};
+        // 256-byte V rows (64-dim groups) would put the 8 rows of a transposed read on the same banks: the 16-dim pair index is
+        // XORed with the low two bits of the row on both sides (write here, read below)
+        const int jj = kGroupDims == 64 ? (j ^ (tok & 3)) : j;
+        ps_store4_pair<16>(vrow, 16 * jj + 4 * g, v4);         // lanes g and g ^ 1 complete an 8-dim group: 16 bytes each
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -282,7 +287,8 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
         for (int t = 0; t < KST; ++t) {
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
-            const int dcol = (hp + e) * HD + 16 * dt + 4 * (r16 & 3);     // first of the 4 dims this lane addresses for the transposed read
+            const int dcol0 = (hp + e) * HD + 16 * dt + 4 * (r16 & 3);    // first of the 4 dims this lane addresses for the transposed read
+            const int dcol = kGroupDims == 64 ? ((((dcol0 >> 4) ^ (r16 >> 2)) << 4) | (dcol0 & 15)) : dcol0;      // (row & 3 == r16 >> 2)
             const int voff = (dcol >> 3) * 32 + (dcol & 7) * 2;           // byte offset of their hi halves inside a V row; + 16: lo halves
             const char* va = vimg + (32 * t + 4 * g + (r16 >> 2)) * G::VROWB + voff;
             const f16x4c h0 = lds_read_tr16c(va), l0 = lds_read_tr16c(va + 16);
@@ -307,14 +313,14 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
   }
 }
 
-bool cell_attention_supported(int D, int H, int T) { return H == kHeads && T == kTokens && (D == 144 || D == 288); }
+bool cell_attention_supported(int D, int H, int T) { return H == kHeads && T == kTokens && (D == 144 || D == 288 || D == 384); }
 
 void launch_cell_qkv_attention(const uint16_t* z, int ldz, const uint16_t* W, int ldw, const float* bias2, const float* csum, const float2* rowstat,
                                uint16_t* out, int ldo, int cells, int D, float scale, hipStream_t s) {
   if (cells <= 0) return;
   auto go = [&](auto kern, int lds) {
-    static bool attr_set[2] = {false, false};
-    const int slot = D == 288 ? 1 : 0;
+    static bool attr_set[3] = {false, false, false};
+    const int slot = D == 288 ? 1 : D == 384 ? 2 : 0;
     if (!attr_set[slot]) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       attr_set[slot] = true;
@@ -323,6 +329,7 @@ void launch_cell_qkv_attention(const uint16_t* z, int ldz, const uint16_t* W, in
     hipLaunchKernelGGL(kern, dim3(cells), dim3(512), lds, s, z, ldz, W, ldw, bias2, csum, rowstat, out, ldo, (int)kTokens, scale, dbg);
   };
   if (D == 288) go(cell_qkv_attention_kernel<288, 24>, CellGeom<288, 24>::LDS);
+  else if (D == 384) go(cell_qkv_attention_kernel<384, 32>, CellGeom<384, 32>::LDS);
   else go(cell_qkv_attention_kernel<144, 12>, CellGeom<144, 12>::LDS);
 }
 

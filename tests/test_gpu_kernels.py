@@ -383,7 +383,7 @@ def test_qkv_attention_fold(dev, d, cells, mean, std):
     assert err < 4e-5 * amp, err
 
 
-@pytest.mark.parametrize("d,cells", [(144, 1), (288, 1), (144, 37), (288, 130), (288, 600)])
+@pytest.mark.parametrize("d,cells", [(144, 1), (288, 1), (384, 1), (144, 37), (288, 130), (384, 70), (288, 600)])
 @pytest.mark.parametrize("mean,std", [(0.5, 1.0), (30.0, 1.0)])
 def test_cell_attention_fused(dev, d, cells, mean, std):
     """cell_attention.hip: norm1 -> qkv -> attention of one cell per workgroup (q, k, v stay on chip) against LayerNorm + qkv + softmax

@@ -16,7 +16,7 @@ from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
 dev = _lib.require_gpu()
 cells = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 g = torch.Generator().manual_seed(0)
-for d in (288, 144):
+for d in (384, 288, 144):
     dp = (d + 31) // 32 * 32
     m = cells * 101
     hd = d // 12
