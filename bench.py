@@ -310,7 +310,9 @@ def main():
         lo, hi = dist.shard_bounds(n_cells, rank, world) if sharded else (0, n_cells)
         n_local = hi - lo
         prof, per_model = {}, []
-        GEMM_OPS = ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2")
+        # the per-cell fused qkv + attention kernel (D <= 384) belongs to the family: it carries the qkv product of those classifiers
+        GEMM_OPS = ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2", "cell_qkv_attention")
+        fused_attn = os.environ.get("RIBCA_CELL_ATTN", "1") != "0"
         for name, model in models.items():
             ops.prof_enable(True)
             one_pass(streams=1, models_sel=[name])
@@ -320,9 +322,12 @@ def main():
             for k, v in pm.items():
                 prof[k] = (prof.get(k, (0.0, 0))[0] + v[0], prof.get(k, (0, 0))[1] + v[1])
             d = model.D
-            m_ms = sum(pm[k][0] for k in GEMM_OPS)
+            m_ms = sum(pm[k][0] for k in GEMM_OPS if k in pm)
             m_fl = n_local * ((model.depth - 1) * 24.0 * 101 * d * d + 6.0 * 101 * d * d + 18.0 * d * d)
-            m_by = n_local * 101 * (model.depth - 1) * 72.0 * d          # A in + output out + z read / written, 4 B per element
+            if fused_attn and d <= 384:      # its attention FLOPs run inside the family's kernel
+                m_fl += n_local * (model.depth - 1) * 4.0 * 101 * 101 * d
+            # A in + output out + z read / written, 4 B per element (the fused qkv + attention kernel writes D instead of 3 D columns)
+            m_by = n_local * 101 * (model.depth - 1) * (64.0 if (fused_attn and d <= 384) else 72.0) * d
             ai = m_fl / m_by
             # ridge of the issued work: 3 MFMA passes per product against the 16-bit dense peak, HBM at 8 TB/s
             ridge = PEAK_BF16_DENSE_TFLOPS * 1e12 / 3.0 / 8.0e12
@@ -337,8 +342,10 @@ def main():
             d = model.D
             # qkv + proj + fc1 + fc2 (algorithmic, unpadded); in the last block proj / fc1 / fc2 run on the CLS row only
             gemm_flops += n_local * ((model.depth - 1) * 24.0 * 101 * d * d + 6.0 * 101 * d * d + 18.0 * d * d)
-        g_ms = sum(prof[k][0] for k in ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2"))
-        g_n = sum(prof[k][1] for k in ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2"))
+            if fused_attn and d <= 384:
+                gemm_flops += n_local * (model.depth - 1) * 4.0 * 101 * 101 * d
+        g_ms = sum(prof[k][0] for k in GEMM_OPS if k in prof)
+        g_n = sum(prof[k][1] for k in GEMM_OPS if k in prof)
         achieved = gemm_flops / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
         # committed rocprofv3 evidence for the same kernels (tools/collect_profiles.sh, tools/collect_pmc_sq.sh): HBM/fabric bytes per
         # launch from the FETCH_SIZE / WRITE_SIZE passes, MFMA-busy and LDS-active fractions from the SQ counter passes.  Both files
@@ -357,7 +364,7 @@ def main():
         if os.path.exists(spath):
             sq = json.load(open(spath))
             if sq.get("kernel_source_sha256") == sha:
-                gem = [v for k, v in sq.items() if k.startswith("gemm_ps_split_kernel") or k.startswith("gemm_ps_duo_kernel")]
+                gem = [v for k, v in sq.items() if k.startswith(("gemm_ps_split_kernel", "gemm_ps_duo_kernel", "cell_qkv_attention_kernel"))]
                 cyc = sum(v["kernel_cycles"] for v in gem)
                 if cyc > 0:
                     busy = round(sum(v["mfma_busy_frac"] * v["kernel_cycles"] for v in gem) / cyc, 4)
@@ -365,7 +372,8 @@ def main():
         alg_bytes = 0.0
         for name, model in models.items():      # algorithmic bytes per pass of the four GEMMs: A read once, output written once, z RMW
             d = model.D
-            per_row = 4.0 * d * (1 + 3) + 4.0 * d * (1 + 2) + 4.0 * d * (1 + 4) + 4.0 * d * (4 + 2)      # qkv, proj, fc1, fc2
+            qkv_io = (1 + 1) if (fused_attn and d <= 384) else (1 + 3)      # fused with attention: z in, attention output out; else z in, q / k / v out
+            per_row = 4.0 * d * qkv_io + 4.0 * d * (1 + 2) + 4.0 * d * (1 + 4) + 4.0 * d * (4 + 2)      # qkv, proj, fc1, fc2
             alg_bytes += n_local * 101 * (model.depth - 1) * per_row + 12.0 * d * d * 4.0 * model.depth * ((n_local + args.chunk - 1) // args.chunk)
         # the bound that binds most of the GEMM time: every classifier's GEMMs are priced against their own roofline (per_model_*),
         # the family's label is the time-weighted majority
@@ -382,7 +390,7 @@ def main():
         out["hbm_frac_of_8tbs_pass"] = round(pass_bytes / (ms_per_step * 1e-3) / 8.0e12, 4) if pass_bytes else None
         out["roofline"] = {"bound": "mfma" if t_mfma >= t_hbm else "hbm",
                            "bound_note": f"time-weighted over the classifiers: {t_mfma:.0f} ms of GEMMs MFMA-bound (D >= 384), {t_hbm:.0f} ms HBM-bound (D <= 288)",
-                           "kernel": "gemm_ps_split_kernel (qkv/proj/fc2) + gemm_ps_duo_kernel (fc1), fp16x3", "achieved": round(achieved, 2),
+                           "kernel": "gemm_ps_split_kernel (proj/fc2) + gemm_ps_duo_kernel (fc1, qkv at D = 576) + cell_qkv_attention_kernel (norm1 + qkv + attention, D <= 384), fp16x3", "achieved": round(achieved, 2),
                            "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 5),
                            "traffic": traffic, "traffic_unit": f"bytes/launch (2*FETCH_SIZE + WRITE_SIZE, {traffic_src})",
                            "algorithmic_bytes_per_launch": round(alg_bytes / max(g_n, 1)),

@@ -163,7 +163,8 @@ int ribca_vote(const float* p_a, int32_t k_a, const int8_t* map_a, const float* 
 /* ---- profiling + kernel-level test hooks --------------------------------------------------------------------- */
 /* When enabled, every kernel launch of the ViT forward is bracketed by HIP events on its stream; ribca_prof_read
  * synchronises and returns, per kernel class, total milliseconds and launch count since the last reset.
- * classes: 0 gemm_qkv 1 gemm_proj 2 gemm_fc1 3 gemm_fc2 4 gemm_embed 5 attention 6 layernorm 7 im2col 8 head 9 other */
+ * classes: 0 gemm_qkv 1 gemm_proj 2 gemm_fc1 3 gemm_fc2 4 gemm_embed 5 attention 6 layernorm (row statistics) 7 cell_qkv_attention
+ * (the per-cell fused norm1 -> qkv -> attention kernel of D <= 384) 8 head 9 other */
 int ribca_prof_enable(int32_t on);
 int ribca_prof_read(double* ms_out10, int64_t* count_out10);
 const char* ribca_prof_name(int32_t cls);

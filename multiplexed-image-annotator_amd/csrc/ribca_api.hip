@@ -34,8 +34,8 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // ----------------------------------------------------------------------------------------------- profiling
-enum ProfClass { P_QKV = 0, P_PROJ, P_FC1, P_FC2, P_EMBED, P_ATTN, P_LN, P_IM2COL, P_HEAD, P_OTHER, P_COUNT };
-const char* kProfNames[P_COUNT] = {"gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2", "gemm_embed", "attention", "layernorm", "im2col",
+enum ProfClass { P_QKV = 0, P_PROJ, P_FC1, P_FC2, P_EMBED, P_ATTN, P_LN, P_CELL, P_HEAD, P_OTHER, P_COUNT };
+const char* kProfNames[P_COUNT] = {"gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2", "gemm_embed", "attention", "layernorm", "cell_qkv_attention",
                                    "head", "other"};
 struct ProfRec { hipEvent_t a, b; int cls; };
 bool g_prof_on = false;
@@ -330,7 +330,7 @@ void run_block_fold(const BlockW& L, const BlockWs& w, int cells, const AttnGeom
   const int D = a.D, Dp = round_up(D, 32), ld_x = 2 * Dp, ld_h = 2 * 4 * D, Mc = cells * a.T;
   const float scale = 1.0f / sqrtf((float)a.hd);
   if (cell_attn_on(a)) {
-    ProfScope ps(P_QKV, s);
+    ProfScope ps(P_CELL, s);
     launch_cell_qkv_attention(w.zps, ld_x, L.qkvw, ld_x, L.qkvb2, L.qkvc, w.rs, w.xa, ld_x, cells, D, scale, s);
   } else {
     {
