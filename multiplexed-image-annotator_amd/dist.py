@@ -25,12 +25,13 @@ def shard_bounds(n: int, rank: int, world_size: int) -> Tuple[int, int]:
     return (n * rank) // world_size, (n * (rank + 1)) // world_size
 
 
-def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+def all_gather_rows(local: torch.Tensor, n_total: int, group=None, force_collective: bool = False) -> torch.Tensor:
     """Reassemble a (n_total, K) tensor from each rank's contiguous (n_local, K) shard (``shard_bounds`` layout).
-    Shards are padded to the largest shard so a single fixed-size all_gather (one RCCL call) is enough."""
+    Shards are padded to the largest shard so a single fixed-size all_gather (one RCCL call) is enough.
+    ``force_collective`` issues the collective even in a group of one rank (the single-GPU RCCL test: same call, same buffers)."""
     import torch.distributed as dist
     rank, ws = world()
-    if ws == 1:
+    if ws == 1 and not (force_collective and dist.is_initialized()):
         assert local.shape[0] == n_total
         return local
     if local.is_cuda and dist.get_backend(group) == "gloo":     # rehearsal / CPU-collective runs: stage through host memory

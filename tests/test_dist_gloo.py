@@ -56,3 +56,24 @@ def test_all_gather_rows_gloo_world2(golden_dir):
     out = mgr.dict()
     mp.spawn(_worker, args=(2, port, golden_dir, out), nprocs=2, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def _worker_single(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multiplexed_image_annotator_amd import dist as rd
+    x = torch.arange(11 * 4, dtype=torch.float32).reshape(11, 4)
+    same = rd.all_gather_rows(x, 11)                               # one rank: no collective, the shard itself
+    forced = rd.all_gather_rows(x, 11, force_collective=True)      # the collective's buffers and call with a group of one
+    out[rank] = bool(same is x and torch.equal(forced, x) and forced.data_ptr() != x.data_ptr())
+    dist.destroy_process_group()
+
+
+def test_all_gather_rows_group_of_one_forced_collective():
+    """the path tests/test_gpu_rccl_single_rank.py drives through RCCL, here through gloo"""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_single, args=(1, _free_port(), out), nprocs=1, join=True)
+    assert dict(out) == {0: True}

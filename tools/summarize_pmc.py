@@ -37,6 +37,22 @@ def counter_sums(sub, counter):
     return per_kernel
 
 
+def counter_by_shape(sub, counter):
+    """KiB and launches per (kernel, grid size): one kernel instantiation serves several GEMM shapes"""
+    path = find(sub, "counter_collection.csv")
+    acc = defaultdict(lambda: [0.0, set()])
+    if path is None:
+        return acc
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if row.get("Counter_Name") != counter:
+                continue
+            key = (row["Kernel_Name"], int(row.get("Grid_Size", 0) or 0))
+            acc[key][0] += float(row["Counter_Value"])
+            acc[key][1].add(row.get("Dispatch_Id"))
+    return acc
+
+
 fetch = counter_sums("fetch", "FETCH_SIZE")
 write = counter_sums("write", "WRITE_SIZE")
 gemm = [k for k in fetch if "gemm_ps_split_kernel" in k or "gemm_ps_duo_kernel" in k or "cell_qkv_attention_kernel" in k]
@@ -63,6 +79,12 @@ if launches:
         other[k.split("(")[0].replace("void ribca::", "")[:90]] = {
             "launches": fetch[k][1], "bytes_per_launch": (2.0 * fetch[k][0] + write.get(k, [0.0, 0])[0]) * 1024.0 / fetch[k][1]}
     res["other_kernels"] = other
+fs, ws = counter_by_shape("fetch", "FETCH_SIZE"), counter_by_shape("write", "WRITE_SIZE")
+res["per_shape"] = [
+    {"kernel": k.split("(")[0].replace("void ribca::", "")[:90], "grid_threads": grid, "launches": len(v[1]),
+     "fetch_bytes_per_launch": 2.0 * v[0] * 1024.0 / max(len(v[1]), 1),
+     "write_bytes_per_launch": ws[(k, grid)][0] * 1024.0 / max(len(ws[(k, grid)][1]), 1) if (k, grid) in ws else None}
+    for (k, grid), v in sorted(fs.items(), key=lambda kv: -kv[1][0]) if k in gemm][:40]
 import hashlib
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
