@@ -129,9 +129,35 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
   const int nblk = mtiles * ntiles;
   int bid = blockIdx.x;
   {
+    // blocks b, b + 8, ... run on one XCD (one L2): XCD x walks the contiguous tile range [first, first + cnt) with n fastest, so
+    // the n-tiles of an m-tile run together and its A rows are fetched once.  When the weight is larger than the L2 can keep
+    // beside the A / output streams (panel > 0: n-tiles per panel, chosen by the launcher), the whole m-tile rows of the range are
+    // walked panel by panel -- every m-tile's n-tiles of panel 0, then of panel 1, ... -- so a panel of W stays resident while the
+    // A rows stream past it (A is then fetched once per panel); the partial rows at the two ends of the range keep the plain order.
     const int xcd = bid & 7, loc = bid >> 3;
     const int q = nblk >> 3, r = nblk & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int cnt = xcd < r ? q + 1 : q;
+    bid = first + loc;
+    const int panel = mode >> 8;
+    if (panel > 0 && panel < ntiles) {
+      const int r0 = (first + ntiles - 1) / ntiles, r1 = (first + cnt) / ntiles;     // whole m-tile rows [r0, r1)
+      const int head = r0 * ntiles - first;
+      if (r1 > r0 && loc >= head) {
+        int l = loc - head;
+        const int rows = r1 - r0;
+        if (l < rows * ntiles) {
+          int p0 = 0, w = panel;
+          while (l >= rows * w) {          // at most ntiles / panel iterations, uniform over the workgroup
+            l -= rows * w;
+            p0 += w;
+            w = ntiles - p0 < panel ? ntiles - p0 : panel;
+          }
+          const int rr = l / w;
+          bid = (r0 + rr) * ntiles + p0 + (l - rr * w);
+        }
+      }
+    }
   }
   const int mt = bid / ntiles, nt = bid - mt * ntiles;
   const int m0 = mt * BM, n0 = nt * BN;
@@ -378,6 +404,21 @@ static bool launch_duo_impl(const GemmArgs& g, const Epi& epi, hipStream_t s, in
   if (wf == nullptr) return false;
   const dim3 grid(mtiles * ntiles), block(64 * NW);
   const int delay = delay_per_step * (g.Kp / BK);
+  // W panel order (see the kernel's tile map): only where the weight (Np x Kp packed-split = 4 bytes per element) would not stay in an
+  // XCD's 4 MB L2 beside the streams; panels of at most RIBCA_DUO_PANEL_KB (default 2816) of W, equal widths
+  static const int panel_kb = getenv("RIBCA_DUO_PANEL_KB") ? atoi(getenv("RIBCA_DUO_PANEL_KB")) : 2816;
+  int panel = 0;
+  {
+    const size_t tile_bytes = (size_t)BN * g.Kp * 4, w_bytes = tile_bytes * ntiles;
+    if (panel_kb > 0 && w_bytes > (size_t)panel_kb * 1024) {
+      const int fit = (int)((size_t)panel_kb * 1024 / tile_bytes);
+      if (fit >= 1) {
+        const int np = (ntiles + fit - 1) / fit;
+        panel = (ntiles + np - 1) / np;
+      }
+    }
+  }
+  const int mode_p = (mode & 0xff) | (panel << 8);
   auto go = [&](auto abl_c) {
     constexpr int ABL = decltype(abl_c)::value;
     static bool attr_set = false;
@@ -386,7 +427,7 @@ static bool launch_duo_impl(const GemmArgs& g, const Epi& epi, hipStream_t s, in
                                 (int)(100 * 1024));
       attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_ps_duo_kernel<BM, NW, WM, TN, NWS, Epi, ABL>), grid, block, lds, s, g.A, g.lda, wf, g.M, g.Kp, mtiles, ntiles, epi, mode, delay);
+    hipLaunchKernelGGL((gemm_ps_duo_kernel<BM, NW, WM, TN, NWS, Epi, ABL>), grid, block, lds, s, g.A, g.lda, wf, g.M, g.Kp, mtiles, ntiles, epi, mode_p, delay);
   };
   // the diagnostic forms (no epilogue / stamps) exist for the epilogues tools/bench_gemm.py and tools/stamp_duo.py drive
 #ifdef RIBCA_DIAG

@@ -1,10 +1,16 @@
 #!/bin/bash
-# same-box A/B of one environment switch on the working tree, interleaved: tools/ab_env.sh VAR A_VALUE B_VALUE [rounds]
-cd ${GRAFT_REPO_ROOT:-.}
-VAR=$1; A=$2; B=$3; N=${4:-3}
-for rep in $(seq 1 $N); do
-for v in $A $B; do
-  echo -n "== $VAR=$v (rep $rep): "
-  env $VAR=$v timeout -k 10 300 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-dropin 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
-done
+# Runs ON THE GPU BOX: interleaved same-box A/B of one environment switch on the default bench workload.
+#   tools/ab_env.sh VAR A_VALUE B_VALUE [repeats]   -> gpurun_out/ab/ab_<VAR>.txt
+set -eo pipefail
+VAR=$1; A=$2; B=$3; REP=${4:-2}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/ab
+mkdir -p "$OUT"
+F=$OUT/ab_$VAR.txt
+: > "$F"
+for i in $(seq "$REP"); do
+  for v in "$A" "$B"; do
+    line=$(env "$VAR=$v" python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-dropin 2>/dev/null | tail -1)
+    echo "$VAR=$v: $(echo "$line" | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); k=d.get("per_kernel_ms") or {}; print(d["value"], "cells/s", d["ms_per_step"], "ms", {x: k[x] for x in ("gemm_qkv","gemm_fc1","gemm_fc2","gemm_proj","cell_qkv_attention") if x in k})')" | tee -a "$F"
+  done
 done

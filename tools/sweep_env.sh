@@ -1,0 +1,14 @@
+#!/bin/bash
+# Runs ON THE GPU BOX: default bench workload over the values of one environment variable, one box.
+#   tools/sweep_env.sh VAR v1 v2 ...   -> gpurun_out/ab/sweep_<VAR>.txt
+set -eo pipefail
+VAR=$1; shift
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/ab
+mkdir -p "$OUT"
+F=$OUT/sweep_$VAR.txt
+: > "$F"
+for v in "$@"; do
+  line=$(env "$VAR=$v" python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-dropin 2>/dev/null | tail -1)
+  echo "$VAR=$v: $(echo "$line" | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); k=d.get("per_kernel_ms") or {}; print(d["value"], "cells/s", d["ms_per_step"], "ms", {x: k[x] for x in ("gemm_qkv","gemm_fc1","gemm_fc2","gemm_proj","cell_qkv_attention") if x in k})')" | tee -a "$F"
+done
