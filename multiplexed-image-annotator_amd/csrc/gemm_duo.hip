@@ -404,9 +404,12 @@ static bool launch_duo_impl(const GemmArgs& g, const Epi& epi, hipStream_t s, in
   if (wf == nullptr) return false;
   const dim3 grid(mtiles * ntiles), block(64 * NW);
   const int delay = delay_per_step * (g.Kp / BK);
-  // W panel order (see the kernel's tile map): only where the weight (Np x Kp packed-split = 4 bytes per element) would not stay in an
-  // XCD's 4 MB L2 beside the streams; panels of at most RIBCA_DUO_PANEL_KB (default 2816) of W, equal widths
-  static const int panel_kb = getenv("RIBCA_DUO_PANEL_KB") ? atoi(getenv("RIBCA_DUO_PANEL_KB")) : 2816;
+  // W panel order (see the kernel's tile map), OFF by default: RIBCA_DUO_PANEL_KB = the most W (KB) a panel may hold, applied only where
+  // the whole weight is larger.  Measured at D = 576 (W = 4.0 / 5.3 MB against the XCD's 4 MB L2; profiles/r3/duo_w_panel_experiment.txt):
+  // 2816 KB halves the counter traffic of those launches (fc1 3.7 -> 2.5 GB, qkv 2.7 -> 1.7 GB; whole pass 21.7 -> 19.4 TB) and costs
+  // 0.4-0.9 % of throughput, more with smaller panels -- the misses it removes are served by the Infinity Cache at no cost in time,
+  // while every panel re-reads the A rows.
+  static const int panel_kb = getenv("RIBCA_DUO_PANEL_KB") ? atoi(getenv("RIBCA_DUO_PANEL_KB")) : 0;
   int panel = 0;
   {
     const size_t tile_bytes = (size_t)BN * g.Kp * 4, w_bytes = tile_bytes * ntiles;
