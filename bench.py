@@ -396,6 +396,10 @@ def main():
                            "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 5),
                            "traffic": traffic, "traffic_unit": f"bytes/launch (2*FETCH_SIZE + WRITE_SIZE, {traffic_src})",
                            "algorithmic_bytes_per_launch": round(alg_bytes / max(g_n, 1)),
+                           # not the peak the fraction is priced against: what register-resident MFMA loops sustain on this chip under its
+                           # power management (tools/mfma_sustain_probe.hip, profiles/r3/mfma_sustain_probe.txt: 1.88 PF at 1.89 GHz)
+                           "mfma_sustained_tflops_probe": 1880.0,
+                           "frac_of_sustained_3_pass_cap": round(achieved / (1880.0 / 3.0), 4),
                            "mfma_busy_frac": busy, "lds_active_frac": lds,
                            "counters": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), SQ_LDS_IDX_ACTIVE / (256 CUs x ...): "
                                        "profiles/r3/sq_summary.json; null = the committed counters belong to another build of the library",

@@ -98,8 +98,9 @@ static void run(const char* name, int waves_per_simd, int iters) {
   // FLOP per MFMA: 2 * 16*16*32 = 16384 (MODE 0) and 2 * 32*32*16 = 32768 (MODE 1); per iteration 32 (MODE 0) / 16 (MODE 1) of them
   const double flop = (double)waves * (double)iters * (MODE == 0 ? 32.0 * 16384.0 : 16.0 * 32768.0);
   const double tf = flop / (ms * 1e-3) / 1e12;
-  // cycles per MFMA per SIMD: the SIMD's waves share its matrix core
-  const double per_mfma = (cyc / waves) / ((double)iters * (MODE == 0 ? 32.0 : 16.0)) / waves_per_simd;
+  // cycles per MFMA per SIMD from the wall time (the SIMD's waves share its matrix core, and the issue arbiter serves the oldest wave
+  // first: per-wave stamps of co-resident waves end at 1/w, 2/w, ... of the kernel, so they cannot be averaged into a rate)
+  const double per_mfma = (ms * 1e-3 * ghz * 1e9) / ((double)iters * (MODE == 0 ? 32.0 : 16.0) * waves_per_simd);
   printf("%-22s %d wave(s)/SIMD: %7.2f ms  %7.1f TFLOP/s dense  clock %.2f GHz  %.1f cycles per MFMA per SIMD  (%.0f%% of 2.5 PF)\n", name,
          waves_per_simd, ms, tf, ghz, per_mfma, tf / 2500.0 * 100.0);
   free(h);
