@@ -64,7 +64,14 @@ template <int D, int HD>
 __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t* __restrict__ z, int ldz, const uint16_t* __restrict__ W, int ldw,
                                                                  const float* __restrict__ bias2, const float* __restrict__ csum,
                                                                  const float2* __restrict__ rowstat, uint16_t* __restrict__ out, int ldo, int T,
-                                                                 float scale, int dbg) {
+                                                                 float scale, int dbg_arg) {
+  // timing ablations exist in the diagnostic library only (RIBCA_CELL_DBG, tools/bench_cell_attention.py); the product kernel has none
+#ifdef RIBCA_DIAG
+  const int dbg = dbg_arg;
+#else
+  constexpr int dbg = 0;
+  (void)dbg_arg;
+#endif
   using G = CellGeom<D, HD>;
   constexpr int NK = G::NK, GROUPS = G::GROUPS, HPG = G::HPG, kRing = G::RING, kGroupDims = G::GD, NTP = G::NTP, kWStage = G::WSTAGE;
   constexpr int NTILES = 3 * NTP;              // accumulator tiles per wave and group: q | k | v
@@ -325,7 +332,11 @@ void launch_cell_qkv_attention(const uint16_t* z, int ldz, const uint16_t* W, in
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       attr_set[slot] = true;
     }
+#ifdef RIBCA_DIAG
     static const int dbg = getenv("RIBCA_CELL_DBG") ? atoi(getenv("RIBCA_CELL_DBG")) : 0;      // timing ablations of tools/bench_cell_attention.py
+#else
+    const int dbg = 0;
+#endif
     hipLaunchKernelGGL(kern, dim3(cells), dim3(512), lds, s, z, ldz, W, ldw, bias2, csum, rowstat, out, ldo, (int)kTokens, scale, dbg);
   };
   if (D == 288) go(cell_qkv_attention_kernel<288, 24>, CellGeom<288, 24>::LDS);

@@ -169,23 +169,29 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
   const int nk = Kp / BK;
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tc1 = 0, tc2 = 0;      // tc: shader-clock stamps around the K loop (in-kernel clock)
   if (ABL & 8) ts0 = __builtin_amdgcn_s_memrealtime();
+  // the scheduling A/B switches below (RIBCA_DUO_MODE) exist in the diagnostic library only; none of them paid
+#ifdef RIBCA_DIAG
+  const int lab = mode & 0xff;
+#else
+  constexpr int lab = 0;
+#endif
   // mode bit 0: static wave priority by the CU's workgroup slot (TG_ID of HW_ID, bits 19:16); bit 1: the first round's odd-slot
   // workgroups start `delay` x 10 ns late; bit 2: epilogue at raised priority (A/B switches: none paid)
-  if (mode & 3) {
+  if (lab & 3) {
     unsigned int hwid;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     const bool odd_slot = ((hwid >> 16) & 1u) != 0;
-    if (mode & 1) {
+    if (lab & 1) {
       if (odd_slot) __builtin_amdgcn_s_setprio(0);
       else __builtin_amdgcn_s_setprio(2);
     }
-    if ((mode & 2) && odd_slot && (int)blockIdx.x < 1024) {
+    if ((lab & 2) && odd_slot && (int)blockIdx.x < 1024) {
       const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)delay;
       while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(16);
     }
   }
 
-  if (mode & 8) __builtin_amdgcn_s_setprio(3);
+  if (lab & 8) __builtin_amdgcn_s_setprio(3);
   // ---- A ring: wave w loads the 8-row groups w, w + NW, ... of every stage (1 KB per instruction) through a buffer descriptor
   // over the tile's rows: ONE per-lane offset register, everything that varies (group, K step) in the scalar offset, and rows beyond
   // M read as zeros by the descriptor's range check (their outputs are dropped by the epilogue guards).
@@ -339,8 +345,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
     }
     return;
   }
-  if (mode & 4) __builtin_amdgcn_s_setprio(3);
-  if (mode & 8) __builtin_amdgcn_s_setprio(0);     // bit 3: K loop at priority 3 (set below the prologue), epilogue back at 0
+  if (lab & 4) __builtin_amdgcn_s_setprio(3);
+  if (lab & 8) __builtin_amdgcn_s_setprio(0);     // bit 3: K loop at priority 3 (set below the prologue), epilogue back at 0
   const int mbase = m0 + wm * (16 * MT) + r16, nbase = n0 + wn * (16 * TN) + 4 * g;
 #pragma unroll
   for (int b = 0; b < NB; ++b) run_epilogue<TN, Epi, RB>(epi, mbase + 16 * RB * b, nbase, acc[b]);
