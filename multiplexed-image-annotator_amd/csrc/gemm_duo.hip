@@ -348,8 +348,15 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
   if (lab & 4) __builtin_amdgcn_s_setprio(3);
   if (lab & 8) __builtin_amdgcn_s_setprio(0);     // bit 3: K loop at priority 3 (set below the prologue), epilogue back at 0
   const int mbase = m0 + wm * (16 * MT) + r16, nbase = n0 + wn * (16 * TN) + 4 * g;
+  // a tile wholly inside the product (all but the last row of m-tiles, every n-tile when N is a multiple of BN) takes the unguarded
+  // form of the epilogue: workgroup-uniform branch
+  if (m0 + BM <= M && n0 + BN <= epi.N && !(mode & 0x10)) {      // mode bit 4 (RIBCA_DUO_GUARDED=1): A/B switch, always the guarded form
 #pragma unroll
-  for (int b = 0; b < NB; ++b) run_epilogue<TN, Epi, RB>(epi, mbase + 16 * RB * b, nbase, acc[b]);
+    for (int b = 0; b < NB; ++b) run_epilogue<TN, Epi, RB, true>(epi, mbase + 16 * RB * b, nbase, acc[b]);
+  } else {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) run_epilogue<TN, Epi, RB>(epi, mbase + 16 * RB * b, nbase, acc[b]);
+  }
   if constexpr (NT > 0) {
 #pragma unroll
     for (int i = 0; i < NT; ++i) asm volatile("" ::"v"(touched[i]));
@@ -427,7 +434,8 @@ static bool launch_duo_impl(const GemmArgs& g, const Epi& epi, hipStream_t s, in
       }
     }
   }
-  const int mode_p = (mode & 0xff) | (panel << 8);
+  static const int guarded = (getenv("RIBCA_DUO_GUARDED") && atoi(getenv("RIBCA_DUO_GUARDED")) != 0) ? 0x10 : 0;
+  const int mode_p = (mode & 0xef) | guarded | (panel << 8);
   auto go = [&](auto abl_c) {
     constexpr int ABL = decltype(abl_c)::value;
     static bool attr_set = false;

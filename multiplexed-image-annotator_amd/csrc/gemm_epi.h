@@ -116,24 +116,30 @@ struct EpiGeluT {
   int rs_stride = 1;                                                 // rowstat[m * rs_stride] belongs to GEMM row m
   struct Ctx {};
   typedef std::conditional_t<FOLD, LnRow, NoRow> RowS;
+  // IN = the caller's whole tile lies inside M x N (gemm_duo.hip tests it once per workgroup): no per-access guards, so the register
+  // epilogue is one basic block the scheduler can interleave across its 4-value groups instead of 24 exec-masked islands
+  static constexpr bool kInside = true;
+  template <bool IN = false>
   __device__ __forceinline__ RowS fetch_row(int m) const {
-    if constexpr (FOLD) { const float2 r = this->rowstat[(size_t)(m < M ? m : M - 1) * rs_stride]; return RowS{r.x, -r.y * r.x}; }
+    if constexpr (FOLD) { const float2 r = this->rowstat[(size_t)(IN || m < M ? m : M - 1) * rs_stride]; return RowS{r.x, -r.y * r.x}; }
     else return RowS{};
   }
+  template <bool IN = false>
   __device__ __forceinline__ float4 fetch_csum(int n) const {
-    if constexpr (FOLD) return n < N ? *reinterpret_cast<const float4*>(this->csum + n) : float4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (FOLD) return (IN || n < N) ? *reinterpret_cast<const float4*>(this->csum + n) : float4{0.f, 0.f, 0.f, 0.f};
     else return float4{0.f, 0.f, 0.f, 0.f};
   }
+  template <bool IN = false>
   __device__ __forceinline__ float4 fetch_bias(int n) const {      // bias == nullptr: already added (plain())
-    return (bias != nullptr && n < N) ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+    return (bias != nullptr && (IN || n < N)) ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
   }
   // the same epilogue for a tile whose fold (and bias) has already been applied to the accumulators (gemm_split16.hip does it before
   // parking the tile: the drain then needs neither row statistics nor column sums)
   __device__ __forceinline__ EpiGeluT<false> plain() const { return EpiGeluT<false>{out, ldo, nullptr, M, N, nt}; }
   __device__ __forceinline__ void fetch(int, int, Ctx&) const {}
-  template <int PX = 16>
+  template <int PX = 16, bool IN = false>
   __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const float4& c, const RowS& r, const Ctx&) const {
-    if (m >= M || n >= N) return;
+    if (!IN && (m >= M || n >= N)) return;
     const float4 x = ln_fold4<FOLD>(v, b, c, r);
     const f32x2v u0 = gelu_erf2(f32x2v{x.x, x.y}), u1 = gelu_erf2(f32x2v{x.z, x.w});
     float t[4] = {u0.x, u0.y, u1.x, u1.y};
@@ -147,12 +153,15 @@ template <bool FOLD>
 struct EpiQKVT {
   static constexpr bool kTouch = false, kFold = FOLD;
   typedef std::conditional_t<FOLD, LnRow, NoRow> RowS;
+  static constexpr bool kInside = true;      // see EpiGeluT
+  template <bool IN = false>
   __device__ __forceinline__ RowS fetch_row(int m) const {
-    if constexpr (FOLD) { const float2 r = this->rowstat[(size_t)(m < M ? m : M - 1) * rs_stride]; return RowS{r.x, -r.y * r.x}; }
+    if constexpr (FOLD) { const float2 r = this->rowstat[(size_t)(IN || m < M ? m : M - 1) * rs_stride]; return RowS{r.x, -r.y * r.x}; }
     else return RowS{};
   }
+  template <bool IN = false>
   __device__ __forceinline__ float4 fetch_csum(int n) const {
-    if constexpr (FOLD) return n < N ? *reinterpret_cast<const float4*>(this->csum + n) : float4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (FOLD) return (IN || n < N) ? *reinterpret_cast<const float4*>(this->csum + n) : float4{0.f, 0.f, 0.f, 0.f};
     else return float4{0.f, 0.f, 0.f, 0.f};
   }
   uint16_t* q; uint16_t* k; uint16_t* vt; const float* bias; int D, hd, hdp /* stored dims per Q/K row = AttnGeom::hdq */, hdv; float scale; int M, N;
@@ -194,17 +203,18 @@ struct EpiQKVT {
     c.d = f - c.head * hd;   // multiple of 4, d+3 < hd (hd % 4 == 0)
     return c;
   }
+  template <bool IN = false>
   __device__ __forceinline__ float4 fetch_bias(int n) const {      // bias == nullptr: already added (plain())
-    return (bias != nullptr && n < N) ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+    return (bias != nullptr && (IN || n < N)) ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
   }
   __device__ __forceinline__ EpiQKVT<false> plain() const {
     return EpiQKVT<false>{q, k, vt, nullptr, D, hd, hdp, hdv, scale, M, N, T, TP, H, KP, nt, magicT, nullptr, nullptr, vrow, n_off, cls_rows, 1};
   }
   __device__ __forceinline__ void fetch(int, int, Ctx&) const {}
-  template <int PX = 16>
+  template <int PX = 16, bool IN = false>
   __device__ __forceinline__ void apply(int m, int n, const f32x4& v, const float4& b, const float4& cs, const RowS& rs, const Ctx&, const Row& r,
                                         const Col& c) const {
-    if (m >= M || n >= N) return;
+    if (!IN && (m >= M || n >= N)) return;
     const float4 xf = ln_fold4<FOLD>(v, b, cs, rs);
     float x[4] = {xf.x, xf.y, xf.z, xf.w};
     const size_t ch = (size_t)r.cell * H + c.head;
@@ -272,15 +282,26 @@ template <> __device__ __forceinline__ void settle_ctx<EpiRowMap::Ctx>(EpiRowMap
 template <class Epi, class = void> struct has_rowcol : std::false_type {};
 template <class Epi> struct has_rowcol<Epi, std::void_t<typename Epi::Row>> : std::true_type {};
 
-template <int TN, class Epi, int R = 4>
+template <class Epi, class = void> struct has_inside : std::false_type {};
+template <class Epi> struct has_inside<Epi, std::enable_if_t<Epi::kInside>> : std::true_type {};
+
+// IN: the whole workgroup tile is inside M x N (only honoured by the epilogues that have unguarded forms: kInside)
+template <int TN, class Epi, int R = 4, bool IN = false>
 __device__ __forceinline__ void run_epilogue(const Epi& epi, int mbase, int nbase, f32x4 (&acc)[R][TN]) {
+  constexpr bool INF = IN && has_inside<Epi>::value;
   float4 b4[TN], c4[TN];
   typename Epi::Ctx ctx[R][TN];
   typename Epi::RowS rs[R];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) { b4[j] = epi.fetch_bias(nbase + 16 * j); c4[j] = epi.fetch_csum(nbase + 16 * j); }
+  for (int j = 0; j < TN; ++j) {
+    if constexpr (INF) { b4[j] = epi.template fetch_bias<true>(nbase + 16 * j); c4[j] = epi.template fetch_csum<true>(nbase + 16 * j); }
+    else { b4[j] = epi.fetch_bias(nbase + 16 * j); c4[j] = epi.fetch_csum(nbase + 16 * j); }
+  }
 #pragma unroll
-  for (int i = 0; i < R; ++i) rs[i] = epi.fetch_row(mbase + 16 * i);
+  for (int i = 0; i < R; ++i) {
+    if constexpr (INF) rs[i] = epi.template fetch_row<true>(mbase + 16 * i);
+    else rs[i] = epi.fetch_row(mbase + 16 * i);
+  }
 #pragma unroll
   for (int i = 0; i < R; ++i)
 #pragma unroll
@@ -307,12 +328,18 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, int mbase, int nbas
 #pragma unroll
     for (int i = 0; i < R; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) epi.apply(mbase + 16 * i, nbase + 16 * j, acc[i][j], b4[j], c4[j], rs[i], ctx[i][j], rows[i], cols[j]);
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (INF) epi.template apply<16, true>(mbase + 16 * i, nbase + 16 * j, acc[i][j], b4[j], c4[j], rs[i], ctx[i][j], rows[i], cols[j]);
+        else epi.apply(mbase + 16 * i, nbase + 16 * j, acc[i][j], b4[j], c4[j], rs[i], ctx[i][j], rows[i], cols[j]);
+      }
   } else {
 #pragma unroll
     for (int i = 0; i < R; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) epi.apply(mbase + 16 * i, nbase + 16 * j, acc[i][j], b4[j], c4[j], rs[i], ctx[i][j]);
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (INF) epi.template apply<16, true>(mbase + 16 * i, nbase + 16 * j, acc[i][j], b4[j], c4[j], rs[i], ctx[i][j]);
+        else epi.apply(mbase + 16 * i, nbase + 16 * j, acc[i][j], b4[j], c4[j], rs[i], ctx[i][j]);
+      }
   }
 }
 
