@@ -12,6 +12,9 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_uin
 HERE = os.path.dirname(os.path.abspath(__file__))
 # RIBCA_DIAG=1 selects the diagnostic library (same ABI + the A/B and timing-ablation kernel forms; `build --diag`): tools/ only
 LIB_PATH = os.path.join(HERE, "libribca_hip_diag.so" if os.environ.get("RIBCA_DIAG") == "1" else "libribca_hip.so")
+# RIBCA_LIB=<file name next to this module, or a path>: another build of the same library (same-box A/B of two builds, tools/ab_env.sh)
+if os.environ.get("RIBCA_LIB"):
+    LIB_PATH = os.environ["RIBCA_LIB"] if os.path.isabs(os.environ["RIBCA_LIB"]) else os.path.join(HERE, os.environ["RIBCA_LIB"])
 
 _lib = None
 

@@ -93,15 +93,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
       for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
+    // exp(s - mx) = exp2(s log2e - mx log2e): one packed fma per two scores in front of v_exp_f32 (cell_attention.hip does the same)
+    const f32x2v l2 = {1.44269504089f, 1.44269504089f}, moff = {-mx * 1.44269504089f, -mx * 1.44269504089f};
+    f32x2v sum2 = {0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = __expf(s[kt][r] - mx);
-        s[kt][r] = e;
-        sum += e;
-      }
+    for (int kt = 0; kt < NT; ++kt) {
+      const f32x2v a0 = __builtin_elementwise_fma(f32x2v{s[kt][0], s[kt][1]}, l2, moff);
+      const f32x2v a1 = __builtin_elementwise_fma(f32x2v{s[kt][2], s[kt][3]}, l2, moff);
+      const f32x2v e0 = {__builtin_amdgcn_exp2f(a0.x), __builtin_amdgcn_exp2f(a0.y)}, e1 = {__builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y)};
+      s[kt] = f32x4{e0.x, e0.y, e1.x, e1.y};
+      sum2 += e0;
+      sum2 += e1;
+    }
+    float sum = sum2.x + sum2.y;
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
@@ -110,12 +114,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     f16x8 phi[KST], plo[KST];
 #pragma unroll
     for (int t = 0; t < KST; ++t) {
-      float pa[4], pb[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { pa[r] = s[2 * t][r] * inv; pb[r] = s[2 * t + 1][r] * inv; }
+      const f32x2v inv2 = {inv, inv};
+      const f32x2v pa0 = f32x2v{s[2 * t][0], s[2 * t][1]} * inv2, pa1 = f32x2v{s[2 * t][2], s[2 * t][3]} * inv2;
+      const f32x2v pb0 = f32x2v{s[2 * t + 1][0], s[2 * t + 1][1]} * inv2, pb1 = f32x2v{s[2 * t + 1][2], s[2 * t + 1][3]} * inv2;
+      const float pa[4] = {pa0.x, pa0.y, pa1.x, pa1.y}, pb[4] = {pb0.x, pb0.y, pb1.x, pb1.y};
       uint2 ha, la, hb, lb;
-      split4(pa, ha, la);
-      split4(pb, hb, lb);
+      split4_unit(pa, ha, la);      // probabilities: inside the fp16 range by construction
+      split4_unit(pb, hb, lb);
       phi[t] = __builtin_bit_cast(f16x8, uint4{ha.x, ha.y, hb.x, hb.y});
       plo[t] = __builtin_bit_cast(f16x8, uint4{la.x, la.y, lb.x, lb.y});
     }
@@ -265,15 +270,19 @@ __global__ __launch_bounds__(64 * WPP) void attention_lds_kernel(const uint16_t*
       for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
+    // exp(s - mx) = exp2(s log2e - mx log2e): one packed fma per two scores in front of v_exp_f32 (cell_attention.hip does the same)
+    const f32x2v l2 = {1.44269504089f, 1.44269504089f}, moff = {-mx * 1.44269504089f, -mx * 1.44269504089f};
+    f32x2v sum2 = {0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = __expf(s[kt][r] - mx);
-        s[kt][r] = e;
-        sum += e;
-      }
+    for (int kt = 0; kt < NT; ++kt) {
+      const f32x2v a0 = __builtin_elementwise_fma(f32x2v{s[kt][0], s[kt][1]}, l2, moff);
+      const f32x2v a1 = __builtin_elementwise_fma(f32x2v{s[kt][2], s[kt][3]}, l2, moff);
+      const f32x2v e0 = {__builtin_amdgcn_exp2f(a0.x), __builtin_amdgcn_exp2f(a0.y)}, e1 = {__builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y)};
+      s[kt] = f32x4{e0.x, e0.y, e1.x, e1.y};
+      sum2 += e0;
+      sum2 += e1;
+    }
+    float sum = sum2.x + sum2.y;
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
@@ -281,12 +290,13 @@ __global__ __launch_bounds__(64 * WPP) void attention_lds_kernel(const uint16_t*
     f16x8 phi[KST], plo[KST];
 #pragma unroll
     for (int t = 0; t < KST; ++t) {
-      float pa[4], pb[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { pa[r] = s[2 * t][r] * inv; pb[r] = s[2 * t + 1][r] * inv; }
+      const f32x2v inv2 = {inv, inv};
+      const f32x2v pa0 = f32x2v{s[2 * t][0], s[2 * t][1]} * inv2, pa1 = f32x2v{s[2 * t][2], s[2 * t][3]} * inv2;
+      const f32x2v pb0 = f32x2v{s[2 * t + 1][0], s[2 * t + 1][1]} * inv2, pb1 = f32x2v{s[2 * t + 1][2], s[2 * t + 1][3]} * inv2;
+      const float pa[4] = {pa0.x, pa0.y, pa1.x, pa1.y}, pb[4] = {pb0.x, pb0.y, pb1.x, pb1.y};
       uint2 ha, la, hb, lb;
-      split4(pa, ha, la);
-      split4(pb, hb, lb);
+      split4_unit(pa, ha, la);      // probabilities: inside the fp16 range by construction
+      split4_unit(pb, hb, lb);
       phi[t] = __builtin_bit_cast(f16x8, uint4{ha.x, ha.y, hb.x, hb.y});
       plo[t] = __builtin_bit_cast(f16x8, uint4{la.x, la.y, lb.x, lb.y});
     }

@@ -177,10 +177,11 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
     for (int j = 0; j < NTILES; ++j) {
       const int n = (j / NTP) * D + hg * kGroupDims + 16 * (j % NTP) + 4 * g;
       const float4 c4 = *reinterpret_cast<const float4*>(cb + n * 4), b4 = *reinterpret_cast<const float4*>(cb + 3 * D * 4 + n * 4);
-      acc[j][0] = fmaf(rstd, acc[j][0], fmaf(nm, c4.x, b4.x));
-      acc[j][1] = fmaf(rstd, acc[j][1], fmaf(nm, c4.y, b4.y));
-      acc[j][2] = fmaf(rstd, acc[j][2], fmaf(nm, c4.z, b4.z));
-      acc[j][3] = fmaf(rstd, acc[j][3], fmaf(nm, c4.w, b4.w));
+      // two columns per instruction (v_pk_fma_f32); the same two fused multiply-adds per value as ln_fold4 (gemm_epi.h)
+      const f32x2v r2 = {rstd, rstd}, n2 = {nm, nm};
+      const f32x2v lo2 = __builtin_elementwise_fma(r2, f32x2v{acc[j][0], acc[j][1]}, __builtin_elementwise_fma(n2, f32x2v{c4.x, c4.y}, f32x2v{b4.x, b4.y}));
+      const f32x2v hi2 = __builtin_elementwise_fma(r2, f32x2v{acc[j][2], acc[j][3]}, __builtin_elementwise_fma(n2, f32x2v{c4.z, c4.w}, f32x2v{b4.z, b4.w}));
+      acc[j] = f32x4{lo2.x, lo2.y, hi2.x, hi2.y};
     }
     // ---- publish k (fragment order, one image per head) and v (row-major packed-split rows of 48 dims)
     f16x8 qhi[HPG], qlo[HPG];
@@ -262,27 +263,33 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
           for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[e][kt][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
+        // exp(s - mx) = exp2(s log2e - mx log2e): ONE packed fma per two scores in front of v_exp_f32 (a subtract and a multiply per
+        // score before); probabilities are normalised two at a time and split without the fp16 range clamp (they lie in [0, 1])
+        const f32x2v l2 = {1.44269504089f, 1.44269504089f}, moff = {-mx * 1.44269504089f, -mx * 1.44269504089f};
+        f32x2v sum2 = {0.f, 0.f};
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float ex = __expf(s[e][kt][r] - mx);
-            s[e][kt][r] = ex;
-            sum += ex;
-          }
+        for (int kt = 0; kt < NT; ++kt) {
+          const f32x2v a0 = __builtin_elementwise_fma(f32x2v{s[e][kt][0], s[e][kt][1]}, l2, moff);
+          const f32x2v a1 = __builtin_elementwise_fma(f32x2v{s[e][kt][2], s[e][kt][3]}, l2, moff);
+          const f32x2v e0 = {__builtin_amdgcn_exp2f(a0.x), __builtin_amdgcn_exp2f(a0.y)}, e1 = {__builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y)};
+          s[e][kt] = f32x4{e0.x, e0.y, e1.x, e1.y};
+          sum2 += e0;
+          sum2 += e1;
+        }
+        float sum = sum2.x + sum2.y;
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
+        const f32x2v inv2 = {inv, inv};
         s[e][NT] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < KST; ++t) {
-          float pa[4], pb[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { pa[r] = s[e][2 * t][r] * inv; pb[r] = s[e][2 * t + 1][r] * inv; }
+          const f32x2v pa0 = f32x2v{s[e][2 * t][0], s[e][2 * t][1]} * inv2, pa1 = f32x2v{s[e][2 * t][2], s[e][2 * t][3]} * inv2;
+          const f32x2v pb0 = f32x2v{s[e][2 * t + 1][0], s[e][2 * t + 1][1]} * inv2, pb1 = f32x2v{s[e][2 * t + 1][2], s[e][2 * t + 1][3]} * inv2;
+          const float pa[4] = {pa0.x, pa0.y, pa1.x, pa1.y}, pb[4] = {pb0.x, pb0.y, pb1.x, pb1.y};
           uint2 ha, la, hb, lb;
-          split4(pa, ha, la);
-          split4(pb, hb, lb);
+          split4_unit(pa, ha, la);
+          split4_unit(pb, hb, lb);
           phi[e][t] = __builtin_bit_cast(f16x8, uint4{ha.x, ha.y, hb.x, hb.y});
           plo[e][t] = __builtin_bit_cast(f16x8, uint4{la.x, la.y, lb.x, lb.y});
         }
