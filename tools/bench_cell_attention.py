@@ -5,6 +5,8 @@ RIBCA_CELL_DBG=1: no attention phase, 2: no MFMAs / fragment reads in the qkv ph
 import os
 import sys
 
+os.environ.setdefault("RIBCA_DIAG", "1")      # the RIBCA_CELL_DBG ablations exist in libribca_hip_diag.so only (build --diag)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
