@@ -97,29 +97,22 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
     // D = 288 with neither MFMAs nor attention, tools/bench_cell_attention.py.  A deeper ring does not help -- issue-bound, not
     // latency-bound -- and a register-staged loader (global_load_dwordx4 + ds_write_b128, one or two stages in flight) was 2.4-5x
     // slower: profiles/r3/cell_attention_loader_experiments.txt.  The GEMMs use four loader waves for this reason.)
-    // One buffer descriptor over the weight, TWO per-lane offset registers (the swizzled chunk of a lane's row repeats every second
-    // 8-row group), everything else -- part, head group, K step, row group -- in the scalar offset: a DMA instruction costs two
-    // scalar adds.  (With 64-bit per-lane addresses every instruction waited for a dependent multiply-add chain on one register
-    // pair: 67 cycles each.)
-    constexpr int kLdwB = 2 * G::Dp * 2;                         // bytes per packed-split weight row (the launcher checks ldw == 2 Dp)
-    (void)ldw;
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(W), 0, 3 * D * kLdwB, 0x00020000);
-    int voff2[2];
-#pragma unroll
-    for (int par = 0; par < 2; ++par) {
-      const int row = par * 8 + (lane >> 3);                   // swz_f(row + 16 i) == swz_f(row)
-      voff2[par] = (lane >> 3) * kLdwB + (((lane & 7) ^ swz_f(row)) << 4);
-    }
+    // Later experiment, NOT kept: the same stream through one buffer descriptor with scalar / precomputed offsets (4 instructions per DMA
+    // instead of a dependent 64-bit address chain, 40 GB/s from this one wave) bought 0.15 % end to end and was NOT deterministic at
+    // 18 DMAs per stage (D = 144, 288): a few rows per thousand cells differed by up to 5e-4 between identical launches
+    // (tools/check_determinism.py; tests/test_gpu_e2e.py::test_config3_full_size_properties caught it).  Cause not established.
     auto issue = [&](int step) {
       const int hg = step / NK, s = step - hg * NK;
       char* st = smem + (step % kRing) * kWStage;
-      const int sbase = hg * kGroupDims * kLdwB + s * (2 * BK * 2);      // bytes: the group's first row of part q, K step s
 #pragma unroll
       for (int i = 0; i < GPL; ++i) {
-        constexpr int kRowsPerDma = 8;
-        const int which = (i * kRowsPerDma) / kGroupDims, c0 = i * kRowsPerDma - which * kGroupDims;      // [q GD | k GD | v GD] rows of this group
-        const int soff = sbase + (which * D + c0) * kLdwB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(st + i * 1024), 16, voff2[i & 1], soff, 0, 0);
+        const int row = i * 8 + (lane >> 3);                   // [q GD | k GD | v GD] rows of this group
+        const int which = row / kGroupDims, c = row - which * kGroupDims;
+        const int n = which * D + hg * kGroupDims + c;
+        const int ch = (lane & 7) ^ swz_f(row);
+        const uint16_t* src = W + (size_t)n * ldw + s * (2 * BK) + ch * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(st + i * 1024), 16,
+                                         0, 0);
       }
     };
     issue(0);
@@ -343,7 +336,6 @@ bool cell_attention_supported(int D, int H, int T) { return H == kHeads && T == 
 void launch_cell_qkv_attention(const uint16_t* z, int ldz, const uint16_t* W, int ldw, const float* bias2, const float* csum, const float2* rowstat,
                                uint16_t* out, int ldo, int cells, int D, float scale, hipStream_t s) {
   if (cells <= 0) return;
-  if (ldw != 2 * ((D + 31) / 32 * 32)) abort();                 // the loader's scalar offsets assume the packed weight's own row pitch
   auto go = [&](auto kern, int lds) {
     static bool attr_set[3] = {false, false, false};
     const int slot = D == 288 ? 1 : D == 384 ? 2 : 0;

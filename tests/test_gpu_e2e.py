@@ -405,6 +405,26 @@ def test_edge_inputs_run_end_to_end(tmp_path, case):
         assert os.path.exists(tmp_path / "results" / "e_integrated_neighborhood.csv")
 
 
+@pytest.mark.parametrize("name", list(synth.VIT_CONFIGS))
+def test_classifier_bitwise_repeatable(name):
+    """The same patches through one classifier three times -- twice with the same chunking and three concurrent segment streams, once in
+    small chunks on one stream: identical bits.  Targets races inside a kernel (a loader rewrite of the fused per-cell kernel once passed
+    every numerical bound and differed by up to 5e-4 on a few rows per thousand between identical launches), which tolerance tests do
+    not see; the config-3 properties test below checks the same at full size for one chunking pair."""
+    from multiplexed_image_annotator_amd import _lib, ops
+    dev = _lib.require_gpu()
+    d, c, k = synth.VIT_CONFIGS[name]
+    g = torch.Generator().manual_seed(17)
+    patches = (torch.rand((5000, c, 40, 40), generator=g) * 2 - 1).to(dev)
+    model = ops.VitModel(synth.make_vit_state_dict(name, synth.SEED_BASE + 3), dev)
+    src = list(range(c))
+    ref = model.predict_proba(patches, src, chunk_cells=1024, streams=3)
+    for chunk, streams in ((1024, 3), (300, 1), (777, 2)):
+        p = model.predict_proba(patches, src, chunk_cells=chunk, streams=streams)
+        bad = (p != ref).any(dim=1).nonzero().flatten()
+        assert len(bad) == 0, (name, chunk, streams, bad[:8].tolist(), (p - ref).abs().max().item())
+
+
 def test_config3_full_size_properties():
     """BASELINE config 3 at its real size (15-ch 4096 x 4096, ~100 k cells, five classifiers, the bench's own inputs): properties that do
     not need the CPU oracle -- every labelled pixel counted once, patches of a shard == rows of the full run, probability rows sum to
