@@ -59,6 +59,89 @@ __device__ __forceinline__ void gload16(f16x8& dst, unsigned voff, const void* s
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(u), "n"(OFF) : "memory");
 }
 
+// ---- EpiResidZK (gemm_epi.h): descriptor over the residual tile's rows, the four-lane sum and the load-free epilogue
+template <class Epi>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t zk_rsrc(const Epi& epi, int m0, int rows_here, __amdgpu_buffer_rsrc_t other) {
+  if constexpr (is_zk<Epi>::value) {
+    // the last row ends with its own 2 * Dp values, not with the row pitch (ldz can be a multiple of it): reads behind it return zeros
+    const int row_bytes = ((epi.N + 31) / 32 * 32) * 4;
+    return __builtin_amdgcn_make_buffer_rsrc(epi.z + (size_t)m0 * epi.ldz, 0, (rows_here - 1) * epi.ldz * 2 + row_bytes, 0x00020000);
+  } else {
+    return other;
+  }
+}
+// sum over the four lanes (r16, g = 0 .. 3) that share an output row: two lane-half swaps (gfx950), the same bits in all four, fixed order
+// (Written as inline asm: handed the same value twice, hipcc folds the two results of the swap builtins into one -- the ISA then adds a
+// register to itself; tools/swap_probe.hip shows it.  s_nop: the swaps read VALU results of the instruction just before.)
+__device__ __forceinline__ float g4_sum(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  float c = a + b, d;
+  asm volatile("v_mov_b32 %0, %1\n\ts_nop 1\n\tv_permlane32_swap_b32 %1, %0\n\ts_nop 1" : "=&v"(d), "+v"(c));
+  return c + d;
+}
+// acc holds z + A W^T of the wave's MT x TN tiles (lane: row r16 of every row tile, columns 4 g .. 4 g + 3 of every column tile);
+// b4 / pm were read before the K loop.  IN: the whole workgroup tile lies inside M x N.
+template <int TN, int MT, int RB, bool IN>
+__device__ __forceinline__ void resid_zk_epilogue(const EpiResidZK& epi, int mbase, int nbase, int blk, int g, f32x4 (&acc)[MT / RB][RB][TN],
+                                                  const float4 (&b4)[TN], const float (&pm)[MT]) {
+  float sum[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    f32x4(&a)[TN] = acc[i / RB][i % RB];
+    const int m = mbase + 16 * i;
+    const bool ok = IN || m < epi.M;
+    uint16_t* zr = epi.z + (size_t)(ok ? m : 0) * epi.ldz;
+    const f32x2v pm2 = {pm[i], pm[i]};
+    f32x2v tot = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      f32x2v x0 = (f32x2v{a[j][0], a[j][1]} - pm2) + f32x2v{b4[j].x, b4[j].y};
+      f32x2v x1 = (f32x2v{a[j][2], a[j][3]} - pm2) + f32x2v{b4[j].z, b4[j].w};
+      x0.x = clamp_f16_range(x0.x); x0.y = clamp_f16_range(x0.y); x1.x = clamp_f16_range(x1.x); x1.y = clamp_f16_range(x1.y);
+      a[j] = f32x4{x0.x, x0.y, x1.x, x1.y};
+      tot += x0; tot += x1;
+      // split (values already inside the fp16 range) and pair store: the partner lane (g ^ 1) holds the other 4 columns of the PS group
+      uint2 hi, lo;
+      hi.x = cvt_pk_f16(x0.x, x0.y); hi.y = cvt_pk_f16(x1.x, x1.y);
+      lo.x = cvt_pk_f16(f32_minus_f16lo(x0.x, hi.x), f32_minus_f16hi(x0.y, hi.x));
+      lo.y = cvt_pk_f16(f32_minus_f16lo(x1.x, hi.y), f32_minus_f16hi(x1.y, hi.y));
+      const auto rx = __builtin_amdgcn_permlane16_swap(hi.x, lo.x, false, false);
+      const auto ry = __builtin_amdgcn_permlane16_swap(hi.y, lo.y, false, false);
+      const u32x4 o = {rx[0], ry[0], rx[1], ry[1]};      // even g: 8 x hi, odd g: 8 x lo
+      const int k = nbase + 16 * j;
+      if (ok) *reinterpret_cast<u32x4*>(zr + ps_off(k & ~7) + ((k & 4) ? 8 : 0)) = o;
+    }
+    sum[i] = tot.x + tot.y;
+  }
+  if (epi.part == nullptr) return;
+  constexpr float inv = 1.0f / (float)(16 * TN);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) sum[i] = g4_sum(sum[i]) * inv;      // block mean of the row
+  float q[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    f32x4(&a)[TN] = acc[i / RB][i % RB];
+    const f32x2v mu = {sum[i], sum[i]};
+    f32x2v qq = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const f32x2v d0 = f32x2v{a[j][0], a[j][1]} - mu, d1 = f32x2v{a[j][2], a[j][3]} - mu;
+      qq += d0 * d0; qq += d1 * d1;
+    }
+    q[i] = qq.x + qq.y;
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) q[i] = g4_sum(q[i]);
+  if (g == 0) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = mbase + 16 * i;
+      if (IN || m < epi.M) epi.part[(size_t)blk * epi.M + m] = float2{sum[i], q[i]};
+    }
+  }
+}
+
 }  // namespace
 
 // weight [Np][2*Kp] packed-split  ->  fragment order (see the header comment); one thread per 16-byte vector
@@ -167,6 +250,11 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
   const int wm = wave / WN, wn = wave - wm * WN;
   const int r16 = lane & 15, g = lane >> 4;
   const int nk = Kp / BK;
+  // EpiResidZK: the residual tile's BN / 32 K steps follow the product's own through the same ring
+  constexpr bool ZK = is_zk<Epi>::value;
+  constexpr int ZS = ZK ? BN / 32 : 0;
+  static_assert(!ZK || (NST == 3 && NWS == 3 && ABL == 0), "the residual-through-the-ring form exists for the production tile only");
+  const int nkz = nk + ZS;
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tc1 = 0, tc2 = 0;      // tc: shader-clock stamps around the K loop (in-kernel clock)
   if (ABL & 8) ts0 = __builtin_amdgcn_s_memrealtime();
   // the scheduling A/B switches below (RIBCA_DUO_MODE) exist in the diagnostic library only; none of them paid
@@ -205,9 +293,25 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
     a_voff = drow * lda * 2 + dch * 16;
   }
   const int a_gstride = 8 * NW * lda * 2;       // bytes between the groups of one wave
+  // the residual tile (ZK): rows of the packed-split stream, 128 bytes = 32 columns per K step, same swizzle
+  const __amdgpu_buffer_rsrc_t z_rsrc = zk_rsrc(epi, m0, rows_here, a_rsrc);
+  int z_voff = 0, z_gstride = 0;
+  if constexpr (ZK) {
+    const int drow = wave * 8 + (lane >> 3);
+    z_voff = drow * epi.ldz * 2 + (((lane & 7) ^ swz_f(drow)) * 16);
+    z_gstride = 8 * NW * epi.ldz * 2;
+  }
   auto issue_a = [&](int kk, int slot) {
     if (ABL & 2) return;
     char* st = smem + slot * STAGE + wave * 1024;
+    if (ZK && kk >= nk) {
+      const int ko = n0 * 4 + (kk - nk) * (4 * BK);
+#pragma unroll
+      for (int i = 0; i < GPW; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(z_rsrc, (__attribute__((address_space(3))) void*)(st + i * (1024 * NW)), 16, z_voff, i * z_gstride + ko,
+                                                 0, 0);
+      return;
+    }
     const int ko = kk * (4 * BK);
 #pragma unroll
     for (int i = 0; i < GPW; ++i)
@@ -229,6 +333,22 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
     }
   };
 
+  // ZK: everything the epilogue needs from memory is requested here, in front of the first ring stage (vmcnt retires in order: the
+  // first operand wait covers these) -- bias of the lane's 4 TN columns, mean of the stored row for each of its MT rows
+  float4 zb4[ZK ? TN : 1];
+  float zpm[ZK ? MT : 1];
+  if constexpr (ZK) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (16 * TN) + 16 * j + 4 * g;
+      zb4[j] = n < epi.N ? *reinterpret_cast<const float4*>(epi.bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * (16 * MT) + 16 * i + r16;
+      zpm[i] = (epi.prev != nullptr && m < M) ? epi.prev[(size_t)m * epi.prev_stride].y : 0.f;
+    }
+  }
   f32x4 acc[NB][RB][TN];
 #pragma unroll
   for (int b = 0; b < NB; ++b)
@@ -263,7 +383,10 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
   auto step = [&](auto sa_c, auto sw_c, int kk) {
     constexpr int SA = decltype(sa_c)::value, SW = decltype(sw_c)::value;
     // the operands of step kk have landed; younger ones (FLY operations: issued one step ago) may stay in flight
-    if (NT > 0 && kk > last_issue) {            // the touches sit behind every operand batch
+    if constexpr (ZK) {                         // behind the last W batch only the next stage's A (or z) rows stay in flight
+      if (kk + 1 < nk) wait_vmcnt<FLY>();
+      else wait_vmcnt<NA>();
+    } else if (NT > 0 && kk > last_issue) {     // the touches sit behind every operand batch
       if (FLY > 0 && kk + 1 < nk) wait_vmcnt<FLY + NT>();
       else wait_vmcnt<NT>();
     } else {
@@ -279,7 +402,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
       constexpr int SN = (SW + NWS - 1) % NWS;
       issue_w(kk + NWS - 1, whi[SN], wlo[SN]);
     }
-    if (kk + NST - 1 < nk) issue_a(kk + NST - 1, (SA + NST - 1) % NST);
+    if (kk + NST - 1 < nkz) issue_a(kk + NST - 1, (SA + NST - 1) % NST);
     if (NT > 0 && kk == last_issue) touch();
     __builtin_amdgcn_sched_barrier(0);
     f16x8 ah[2], al[2];
@@ -310,7 +433,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
   static_for<NST - 1>([&](auto s_c) {
     constexpr int S = decltype(s_c)::value;
     if (S < NWS - 1 && S < nk) issue_w(S, whi[S], wlo[S]);
-    if (S < nk) issue_a(S, S);
+    if (S < nkz) issue_a(S, S);
   });
   if (NT > 0 && last_issue < 0) touch();
   int kk = 0;
@@ -323,6 +446,64 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
     constexpr int P = decltype(p_c)::value;
     if (kk + P < nk) step(std::integral_constant<int, P % NST>{}, std::integral_constant<int, P % NWS>{}, kk + P);
   });
+
+  if constexpr (ZK) {
+    // ---- the residual tile: K step t holds columns n0 + 32 t .. + 31 of the stored rows; against the identity, the column tile whose
+    // 16 columns sit at offset 0 or 16 of that step receives z_lo and z_hi (exact products, fp32 accumulate)
+    const int p8 = r16 & 7;
+    const unsigned one = (p8 & 1) ? 0x3C000000u : 0x00003C00u;       // 1.0 in the lane's element r16 % 8
+    const u32x4 pat = {(p8 >> 1) == 0 ? one : 0u, (p8 >> 1) == 1 ? one : 0u, (p8 >> 1) == 2 ? one : 0u, (p8 >> 1) == 3 ? one : 0u};
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    const f16x8 id0 = __builtin_bit_cast(f16x8, g == (r16 >> 3) ? pat : zero4), id16 = __builtin_bit_cast(f16x8, g == 2 + (r16 >> 3) ? pat : zero4);
+    int zsel[TN];
+    f16x8 idj[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int c0 = wn * (16 * TN) + 16 * j;
+      zsel[j] = n0 + c0 < epi.N ? (c0 >> 5) : -1;       // column tiles beyond N take nothing (their K step may lie behind the row)
+      idj[j] = (c0 & 16) ? id16 : id0;
+    }
+    const int nk3 = nk % NST;
+    static_for<ZS>([&](auto t_c) {
+      constexpr int t = decltype(t_c)::value;
+      if constexpr (t + 1 < ZS) wait_vmcnt<NA>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if constexpr (t + NST - 1 < ZS) issue_a(nk + t + NST - 1, (nk3 + t + NST - 1) % NST);
+      __builtin_amdgcn_sched_barrier(0);
+      bool mine = false;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) mine = mine || zsel[j] == t;
+      if (mine) {      // wave-uniform
+        const int slot = (nk3 + t) % NST;
+        f16x8 ah[2], al[2];
+        const unsigned a_hi_s = a_hi + (unsigned)(slot * STAGE), a_lo_s = a_lo + (unsigned)(slot * STAGE);
+        lds_read16<0>(ah[0], a_hi_s);
+        lds_read16<0>(al[0], a_lo_s);
+        static_for<MT>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          constexpr int cur = i & 1, nxt = cur ^ 1;
+          if constexpr (i + 1 < MT) {
+            lds_read16<(i + 1) * 2048>(ah[nxt], a_hi_s);
+            lds_read16<(i + 1) * 2048>(al[nxt], a_lo_s);
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[cur]), "+v"(al[cur])::"memory");
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[cur]), "+v"(al[cur])::"memory");
+          }
+          f32x4(&a)[TN] = acc[i / RB][i % RB];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            if (zsel[j] == t) {
+              a[j] = mfma_f16(idj[j], al[cur], a[j]);
+              a[j] = mfma_f16(idj[j], ah[cur], a[j]);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+    });
+  }
 
   if (ABL & 8) { ts2 = __builtin_amdgcn_s_memrealtime(); tc2 = __builtin_amdgcn_s_memtime(); }
   if (ABL & 1) {
@@ -350,7 +531,12 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
   const int mbase = m0 + wm * (16 * MT) + r16, nbase = n0 + wn * (16 * TN) + 4 * g;
   // a tile wholly inside the product (all but the last row of m-tiles, every n-tile when N is a multiple of BN) takes the unguarded
   // form of the epilogue: workgroup-uniform branch
-  if (m0 + BM <= M && n0 + BN <= epi.N && !(mode & 0x10)) {      // mode bit 4 (RIBCA_DUO_GUARDED=1): A/B switch, always the guarded form
+  if constexpr (ZK) {
+    if (n0 + wn * (16 * TN) >= epi.N) return;      // a wave column block wholly beyond N (N is a multiple of the block): nothing to write
+    const int blk = nt * WN + wn;
+    if (m0 + BM <= M) resid_zk_epilogue<TN, MT, RB, true>(epi, mbase, nbase, blk, g, acc, zb4, zpm);
+    else resid_zk_epilogue<TN, MT, RB, false>(epi, mbase, nbase, blk, g, acc, zb4, zpm);
+  } else if (m0 + BM <= M && n0 + BN <= epi.N && !(mode & 0x10)) {      // mode bit 4 (RIBCA_DUO_GUARDED=1): A/B switch, always the guarded form
 #pragma unroll
     for (int b = 0; b < NB; ++b) run_epilogue<TN, Epi, RB, true>(epi, mbase + 16 * RB * b, nbase, acc[b]);
   } else {
@@ -489,6 +675,7 @@ bool launch_duo(const GemmArgs& g, const Epi& epi, hipStream_t s, int abl) {
 RIBCA_DUO_INST(128, EpiGelu) RIBCA_DUO_INST(96, EpiGelu) RIBCA_DUO_INST(64, EpiGelu)
 RIBCA_DUO_INST(128, EpiGeluLn) RIBCA_DUO_INST(96, EpiGeluLn) RIBCA_DUO_INST(64, EpiGeluLn)
 RIBCA_DUO_INST(128, EpiQKVLn) RIBCA_DUO_INST(96, EpiQKVLn) RIBCA_DUO_INST(64, EpiQKVLn)
+RIBCA_DUO_INST(128, EpiResidZK) RIBCA_DUO_INST(96, EpiResidZK) RIBCA_DUO_INST(64, EpiResidZK)
 #ifdef RIBCA_DIAG
 RIBCA_DUO_INST(128, EpiResid) RIBCA_DUO_INST(96, EpiResid) RIBCA_DUO_INST(64, EpiResid)
 RIBCA_DUO_INST(128, EpiQKV) RIBCA_DUO_INST(96, EpiQKV) RIBCA_DUO_INST(64, EpiQKV)

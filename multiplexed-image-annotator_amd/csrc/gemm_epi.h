@@ -94,6 +94,26 @@ struct EpiResidPS {
   __device__ __forceinline__ void apply(int, int, const f32x4&, const float4&, const float4&, const RowS&, const Ctx&) const {}
 };
 
+// The same residual update for the two-workgroups-per-CU kernel (gemm_duo.hip), with NO load in the epilogue.  Round 2 measured what
+// sinks that kernel on proj / fc2: beside a neighbour workgroup that keeps two ring stages of LDS-DMA in flight
+// even L2-hit loads of an epilogue take ~6 us, the residual tile's z loads 13 of a tile's 17 us -- without them the kernel was 26 % under
+// the one-workgroup kernel.  The stored residual stream IS an A operand (packed-split rows), so the z tile rides the A ring as BN / 32
+// extra K steps behind the product's own:  z + A W^T = [A | z] [W | I]^T, the identity as a constant register fragment (one 1.0 per
+// lane, no weight traffic), two MFMAs per (row tile, column tile) -- lo then hi, both exact products -- on the K step that holds the
+// tile's columns.  The asynchronous loader that hides the operands' latency now hides the residual's; bias and the stored rows' means
+// are read before the first ring stage.  What is left behind the K loop is VALU and stores: x = (acc - previous mean) + bias, split,
+// 16-byte pair stores, and the statistics of the new row segment per (row, WAVE column block of 16 TN columns) -- a lane sums its own
+// 4 TN values, two lane-half swaps add the four lanes of a row in a fixed order; no LDS, no barrier, nothing shared between waves.
+// ln_finalize_kernel combines the blocks exactly as it combines the one-workgroup kernel's column tiles (more of them, same update).
+struct EpiResidZK {
+  static constexpr bool kTouch = false, kFold = false, kZK = true;
+  uint16_t* z; int ldz; const float* bias; int M, N;
+  float2* part = nullptr;      // [N / (16 TN)][M] (mean, M2) per wave column block, or nullptr: no statistics wanted
+  const float2* prev = nullptr; int prev_stride = 1;     // (rstd, mean) of the stored rows, or nullptr: no re-centring
+  struct Ctx {};
+  typedef NoRow RowS;
+};
+
 // LayerNorm folded into the GEMM that follows it (timm Block.norm1 -> attn.qkv, norm2 -> mlp.fc1):
 //   LN(z) W^T + b = rstd (z (gamma o W)^T) - rstd mean c + b',   c[n] = sum_k (gamma o W)[n][k],  b' = b + W beta
 // The GEMM reads the residual stream z itself (packed-split), its weight is gamma o W (ribca_vit_create folds it), and the
@@ -284,6 +304,10 @@ template <class Epi> struct has_rowcol<Epi, std::void_t<typename Epi::Row>> : st
 
 template <class Epi, class = void> struct has_inside : std::false_type {};
 template <class Epi> struct has_inside<Epi, std::enable_if_t<Epi::kInside>> : std::true_type {};
+
+// the residual tile rides the A ring as extra K steps (EpiResidZK, gemm_duo.hip)
+template <class Epi, class = void> struct is_zk : std::false_type {};
+template <class Epi> struct is_zk<Epi, std::enable_if_t<Epi::kZK>> : std::true_type {};
 
 // IN: the whole workgroup tile is inside M x N (only honoured by the epilogues that have unguarded forms: kInside)
 template <int TN, class Epi, int R = 4, bool IN = false>

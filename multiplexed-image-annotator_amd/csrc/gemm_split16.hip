@@ -916,9 +916,47 @@ void launch_gemm_resid(const GemmArgs& g, float* z, int ldz, hipStream_t s) {
 void launch_gemm_gelu(const GemmArgs& g, uint16_t* out, int ldo, hipStream_t s) {
   launch_any(g, EpiGelu{out, ldo, g.bias, g.M, g.N, nt_mask() & 1}, s);
 }
-void launch_gemm_resid_ps(const GemmArgs& g, uint16_t* z, int ldz, float2* part, const float2* prev, int prev_stride, hipStream_t s) {
+// columns of a wave's block in the two-workgroups-per-CU kernel (gemm_duo.hip launch_duo: 4 waves as 1 x 4 for 64- / 128-wide tiles,
+// 2 x 2 for 96-wide ones)
+static int resid_duo_block(int N) {
+  const int bn = gemm_pick_bn(N);
+  return bn == 96 ? 48 : bn / 4;
+}
+// Where the two-workgroups-per-CU form pays (profiles/r3/resid_through_ring_bench.txt, M = 103 424, cache-cold operands, row statistics
+// included on both sides): the narrow classifier (N = 144: proj -15 %, fc2 -10 %) and the short-K products of the 96-wide tiles (proj at
+// D = 288 / 576: -2 % with the test hook's weight repack inside the figure).  Long K loops lose (fc2 at D = 288 +11 %, D = 576 +4 %):
+// with 4 waves as 2 x 2 every W fragment is requested by two waves, 2.7 bytes from L2 per (row, column, K step) against 1.8 for the
+// 256 x 96 tile of the one-workgroup kernel, and the K loop runs into the CU's L2 fetch rate (61-70 GB/s) before
+// the load-free epilogue can matter; the 128-wide form (1 x 4 waves: each reads the whole A stage from LDS) ties (+1 ... +5 %).
+static bool resid_duo_pays(int N, int Kp) {
+  if (N <= 192) return true;
+  return gemm_pick_bn(N) == 96 && Kp <= (N + 31) / 32 * 32;
+}
+ResidStatGeom launch_gemm_resid_ps(const GemmArgs& g, uint16_t* z, int ldz, float2* part, const float2* prev, int prev_stride, hipStream_t s,
+                                   bool force_duo) {
   static const int no_touch = (getenv("RIBCA_GEMM_TOUCH") && atoi(getenv("RIBCA_GEMM_TOUCH")) == 0) ? 2 : 0;
+  // proj / fc2 of the classifiers' full blocks: two workgroups per CU, residual through the ring, load-free epilogue (EpiResidZK).
+  // RIBCA_RESID_DUO = 0: never, 1 (default): the shapes where it measured faster, 2: every shape it supports (A/B)
+  static const int duo_mode = getenv("RIBCA_RESID_DUO") ? atoi(getenv("RIBCA_RESID_DUO")) : 1;
+  const int blk = resid_duo_block(g.N);
+  const bool want = force_duo || duo_mode == 2 || (duo_mode == 1 && resid_duo_pays(g.N, g.Kp));
+  if (want && g_variant == 0 && g.WF != nullptr && g.M >= 4096 && g.N % blk == 0 && g.N % 8 == 0) {
+    const EpiResidZK epi{z, ldz, g.bias, g.M, g.N, part, prev, prev_stride};
+    bool done = false;
+    switch (gemm_pick_bn(g.N)) {
+      case 128: done = launch_duo<128, EpiResidZK>(g, epi, s, 0); break;
+      case 64: done = launch_duo<64, EpiResidZK>(g, epi, s, 0); break;
+      default: done = launch_duo<96, EpiResidZK>(g, epi, s, 0); break;
+    }
+    if (done) return ResidStatGeom{g.N / blk, blk};
+  }
   launch_any(g, EpiResidPS{z, ldz, g.bias, g.M, g.N, no_touch, part, prev, prev_stride}, s);
+  return ResidStatGeom{gemm_resid_tiles(g.N), gemm_resid_bn(g.N)};
+}
+int gemm_resid_part_rows(int N) {
+  const int blk = resid_duo_block(N);
+  const int fine = (N + blk - 1) / blk, coarse = gemm_padded_n(N) / gemm_pick_bn(N);
+  return fine > coarse ? fine : coarse;
 }
 void launch_gemm_gelu_ln(const GemmArgs& g, const float2* rowstat, const float* csum, uint16_t* out, int ldo, hipStream_t s) {
   launch_any(g, EpiGeluLn{out, ldo, g.bias, g.M, g.N, nt_mask() & 1, rowstat, csum}, s);

@@ -79,6 +79,7 @@ struct BlockW {
   const uint16_t *qkvw, *projw, *fc1w, *fc2w;
   const uint16_t* qkvwf = nullptr;   // folded qkv weight in fragment order: the qkv product runs on the duo kernel as well
   const uint16_t* fc1wf;   // fc1 weight again, in MFMA fragment order (gemm_duo.hip): the GELU GEMMs run on the two-workgroups-per-CU kernel
+  const uint16_t *projwf = nullptr, *fc2wf = nullptr;   // classifiers: proj / fc2 in fragment order too (residual through the ring, EpiResidZK)
   // LayerNorm folded into qkv / fc1 (classifiers): qkvw / fc1w then hold gamma o W, and per output column the sum of the packed row
   // and the bias with beta folded in (vit_misc.hip pack_weight_fold_kernel)
   const float *qkvc = nullptr, *qkvb2 = nullptr, *fc1c = nullptr, *fc1b2 = nullptr;
@@ -131,9 +132,11 @@ void layout_block(Carver& c, BlockW& L, int D, bool fold = false) {
   L.qkvw = c.take<uint16_t>((size_t)gemm_padded_n(3 * D) * 2 * Dp);
   if (fold) L.qkvwf = c.take<uint16_t>((size_t)gemm_padded_n(3 * D) * 2 * Dp);
   L.projw = c.take<uint16_t>((size_t)gemm_padded_n(D) * 2 * Dp);
+  if (fold) L.projwf = c.take<uint16_t>((size_t)gemm_padded_n(D) * 2 * Dp);
   L.fc1w = c.take<uint16_t>((size_t)gemm_padded_n(4 * D) * 2 * Dp);
   L.fc1wf = c.take<uint16_t>((size_t)gemm_padded_n(4 * D) * 2 * Dp);
   L.fc2w = c.take<uint16_t>((size_t)gemm_padded_n(D) * 2 * H4);
+  if (fold) L.fc2wf = c.take<uint16_t>((size_t)gemm_padded_n(D) * 2 * H4);
 }
 
 // lays the arena out; with base == nullptr only measures
@@ -199,12 +202,14 @@ struct BlobReader {
     } else pack(L.qkvw, 3 * D, D, Dp);
     copy(L.qkvb, 3 * D);
     pack(L.projw, D, D, Dp); copy(L.projb, D);
+    if (fold) launch_pack_wf(L.projw, 2 * Dp, gemm_padded_n(D), Dp, const_cast<uint16_t*>(L.projwf), s);
     copy(L.ln2w, D); copy(L.ln2b, D);
     if (fold) pack_fold(L.fc1w, 4 * D, D, Dp, L.ln2w, L.ln2b, L.fc1c, L.fc1b2);
     else pack(L.fc1w, 4 * D, D, Dp);
     copy(L.fc1b, 4 * D);
     launch_pack_wf(L.fc1w, 2 * Dp, gemm_padded_n(4 * D), Dp, const_cast<uint16_t*>(L.fc1wf), s);
     pack(L.fc2w, D, 4 * D, 4 * D); copy(L.fc2b, D);
+    if (fold) launch_pack_wf(L.fc2w, 2 * 4 * D, gemm_padded_n(D), 4 * D, const_cast<uint16_t*>(L.fc2wf), s);
   }
 };
 int64_t block_params(int64_t d) { return 2 * d + 3 * d * d + 3 * d + d * d + d + 2 * d + 4 * d * d + 4 * d + 4 * d * d + d; }
@@ -224,7 +229,7 @@ BlockWs carve_blocks(Carver& c, int cells, const AttnGeom& a, bool fold = false)
   if (fold) {
     w.z = nullptr;
     w.zps = c.take<uint16_t>(Mc * 2 * Dp);
-    w.part = c.take<float2>(Mc * gemm_resid_tiles(a.D));
+    w.part = c.take<float2>(Mc * gemm_resid_part_rows(a.D));
     w.rs = c.take<float2>(Mc);
   } else {
     w.z = c.take<float>(Mc * a.D);
@@ -317,8 +322,8 @@ void run_last_block_cls(const BlockW& L, const BlockWs& w, int cells, const Attn
 // Precondition: w.rs holds the statistics of z for norm1 (row_stats after the embedding, or the previous block's fc2).
 // prev_stride: w.rs[m * prev_stride] = (rstd, mean) of the stored row that GEMM row m updates (re-centring, EpiResidPS)
 void resid_ps_and_stats(const GemmArgs& g, const BlockWs& w, int ldz_rows, int D, bool want_stats, int prev_stride, hipStream_t s) {
-  launch_gemm_resid_ps(g, w.zps, ldz_rows, want_stats ? w.part : nullptr, w.rs, prev_stride, s);
-  if (want_stats) launch_ln_finalize(w.part, gemm_resid_tiles(D), g.M, gemm_resid_bn(D), D, w.rs, s);
+  const ResidStatGeom sg = launch_gemm_resid_ps(g, w.zps, ldz_rows, want_stats ? w.part : nullptr, w.rs, prev_stride, s);
+  if (want_stats) launch_ln_finalize(w.part, sg.tiles, g.M, sg.bn, D, w.rs, s);
 }
 // norm1 -> qkv -> attention of a whole block in ONE per-cell kernel (cell_attention.hip) where the geometry allows (D = 144, 288):
 // 13.9 -> 14.4 k cells/s in a same-box A/B (profiles/r3/ab_cell_attention.txt).  RIBCA_CELL_ATTN=0: the unfused pair, for A/B.
@@ -342,7 +347,7 @@ void run_block_fold(const BlockW& L, const BlockWs& w, int cells, const AttnGeom
   }
   {
     ProfScope ps(P_PROJ, s);
-    GemmArgs g{w.xa, ld_x, L.projw, ld_x, Mc, D, Dp, L.projb};
+    GemmArgs g{w.xa, ld_x, L.projw, ld_x, Mc, D, Dp, L.projb, L.projwf};
     resid_ps_and_stats(g, w, ld_x, D, true, 1, s);
   }
   {
@@ -352,7 +357,7 @@ void run_block_fold(const BlockW& L, const BlockWs& w, int cells, const AttnGeom
   }
   {
     ProfScope ps(P_FC2, s);
-    GemmArgs g{w.h, ld_h, L.fc2w, ld_h, Mc, D, 4 * D, L.fc2b};
+    GemmArgs g{w.h, ld_h, L.fc2w, ld_h, Mc, D, 4 * D, L.fc2b, L.fc2wf};
     resid_ps_and_stats(g, w, ld_x, D, true, 1, s);
   }
 }
@@ -850,9 +855,28 @@ int ribca_test_gemm_resid_ps(const uint16_t* A, int32_t lda, const uint16_t* W, 
   if (N % 8 != 0) return fail("ribca_test_gemm_resid_ps: N must be a multiple of 8");
   if ((rowstat != nullptr) != (part != nullptr)) return fail("ribca_test_gemm_resid_ps: part and rowstat go together");
   GemmArgs g{A, lda, W, ldw, M, N, Kp, bias};
-  launch_gemm_resid_ps(g, z_ps, ldz, reinterpret_cast<float2*>(part), reinterpret_cast<const float2*>(prev), 1, (hipStream_t)stream);
-  if (rowstat) launch_ln_finalize(reinterpret_cast<const float2*>(part), gemm_resid_tiles(N), M, gemm_resid_bn(N), N, reinterpret_cast<float2*>(rowstat),
-                                  (hipStream_t)stream);
+  const ResidStatGeom sg = launch_gemm_resid_ps(g, z_ps, ldz, reinterpret_cast<float2*>(part), reinterpret_cast<const float2*>(prev), 1, (hipStream_t)stream);
+  if (rowstat) launch_ln_finalize(reinterpret_cast<const float2*>(part), sg.tiles, M, sg.bn, N, reinterpret_cast<float2*>(rowstat), (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int32_t ribca_test_resid_part_rows(int32_t N) { return gemm_resid_part_rows(N); }
+// the same update on the two-workgroups-per-CU kernel with the residual tile riding the A ring (EpiResidZK): what the classifiers' full
+// blocks run for proj / fc2.  part needs ribca_test_resid_part_rows(N) x M pairs; wf_scratch the size of the packed weight.
+int ribca_test_gemm_resid_ps_duo(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
+                                 const float* bias, uint16_t* wf_scratch, uint16_t* z_ps, int32_t ldz, float* part, float* rowstat,
+                                 const float* prev, void* stream) {
+  if (M < 4096) return fail("ribca_test_gemm_resid_ps_duo: the forward uses this kernel for M >= 4096 only");
+  if (!wf_scratch) return fail("ribca_test_gemm_resid_ps_duo: wf_scratch is NULL");
+  if (N % 8 != 0) return fail("ribca_test_gemm_resid_ps_duo: N must be a multiple of 8");
+  if ((rowstat != nullptr) != (part != nullptr)) return fail("ribca_test_gemm_resid_ps_duo: part and rowstat go together");
+  launch_pack_wf(W, ldw, gemm_padded_n(N), Kp, wf_scratch, (hipStream_t)stream);
+  GemmArgs g{A, lda, W, ldw, M, N, Kp, bias, wf_scratch};
+  const ResidStatGeom sg = launch_gemm_resid_ps(g, z_ps, ldz, reinterpret_cast<float2*>(part), reinterpret_cast<const float2*>(prev), 1, (hipStream_t)stream,
+                                                true);
+  if (sg.bn == gemm_resid_bn(N))      // the duo kernel's wave blocks are 16 / 32 / 48 columns wide, never a tile width
+    return fail("ribca_test_gemm_resid_ps_duo: the two-workgroups-per-CU kernel did not take this shape");
+  if (rowstat) launch_ln_finalize(reinterpret_cast<const float2*>(part), sg.tiles, M, sg.bn, N, reinterpret_cast<float2*>(rowstat), (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return 0;
 }

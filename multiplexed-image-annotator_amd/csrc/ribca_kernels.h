@@ -29,9 +29,16 @@ void launch_gemm_gelu(const GemmArgs& g, uint16_t* out, int ldo, hipStream_t s);
 // z_ps[m][n] = (z_ps[m][n] - prev[m * prev_stride].y) + acc + bias on the packed-split residual stream (prev = (rstd, mean) of the
 // stored rows: re-centring, see EpiResidPS; nullptr = none); part [gemm_resid_tiles(N)][M] receives (mean, centred sum of squares)
 // of every (row, column tile) of the NEW z, or nullptr
-void launch_gemm_resid_ps(const GemmArgs& g, uint16_t* z, int ldz, float2* part, const float2* prev, int prev_stride, hipStream_t s);
-int gemm_resid_tiles(int N);        // column tiles of an N-wide residual GEMM (= rows of `part`)
+// Returns the geometry of `part` it used: with a fragment-order weight (g.WF) and M >= 4096 the GEMM runs on the two-workgroups-per-CU
+// kernel with the residual tile riding the A ring (EpiResidZK, gemm_duo.hip) -- for the shapes where that measured faster, or for
+// every shape it supports with force_duo -- and the statistics come per WAVE column block (16 / 32 / 48 columns) instead of per column
+// tile; ln_finalize takes either.  RIBCA_RESID_DUO = 0 / 1 / 2: never / where it pays (default) / wherever supported.
+struct ResidStatGeom { int tiles, bn; };
+ResidStatGeom launch_gemm_resid_ps(const GemmArgs& g, uint16_t* z, int ldz, float2* part, const float2* prev, int prev_stride, hipStream_t s,
+                                   bool force_duo = false);
+int gemm_resid_tiles(int N);        // column tiles of an N-wide residual GEMM on the one-workgroup kernel
 int gemm_resid_bn(int N);           // their width
+int gemm_resid_part_rows(int N);    // rows `part` must have for either kernel (the finer of the two geometries)
 // the same as launch_gemm_gelu / launch_gemm_qkv with rowstat[m] = (rstd, mean):  x = rstd * acc + (-mean * rstd * csum[n] + bias[n])
 void launch_gemm_gelu_ln(const GemmArgs& g, const float2* rowstat, const float* csum, uint16_t* out, int ldo, hipStream_t s);
 // geometry of one attention problem: D = H*hd features, T tokens per cell; Q/K rows padded to TP = 16*NT tokens and STORED with

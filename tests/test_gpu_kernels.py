@@ -252,13 +252,17 @@ def test_row_stats(dev, d, mean, std):
 
 RESID_PS_SHAPES = [(1, 288, 288), (300, 288, 1152), (257, 144, 144), (130, 144, 576), (77, 576, 2304), (129, 384, 384), (515, 768, 768),
                    (11100, 576, 576), (22100, 288, 288), (16500, 384, 1536), (40000, 144, 144)]
+# the two-workgroups-per-CU form with the residual tile riding the A ring (what the full blocks run for M >= 4096): every tile width
+# (96 / 128 / 64), ragged last row tiles, a last column tile half behind N (144, 240), short and long K, one K step
+RESID_ZK_SHAPES = [(11100, 576, 576), (22100, 288, 288), (16500, 384, 1536), (40000, 144, 144), (4100, 144, 576), (5000, 768, 768),
+                   (4097, 64, 64), (4200, 192, 96), (4300, 240, 32), (6000, 576, 2304), (4096, 288, 1152)]
 
 
-@pytest.mark.parametrize("m,n,k", RESID_PS_SHAPES)
+@pytest.mark.parametrize("m,n,k,duo", [s + (False,) for s in RESID_PS_SHAPES] + [s + (True,) for s in RESID_ZK_SHAPES])
 @pytest.mark.parametrize("mean,recentre", [(0.3, False), (40.0, False), (40.0, True)])
-def test_gemm_resid_ps(dev, m, n, k, mean, recentre):
+def test_gemm_resid_ps(dev, m, n, k, duo, mean, recentre):
     """proj / fc2 of the classifiers: z (packed-split) += A W^T + b in place, plus (rstd, -mean rstd) of the NEW rows out of the
-    epilogue's per-tile pairs (2 ... 6 column tiles), also for rows whose mean dwarfs their spread"""
+    epilogue's per-tile pairs (2 ... 6 column tiles; duo: 3 ... 24 wave column blocks), also for rows whose mean dwarfs their spread"""
     from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
     kp = (k + 31) // 32 * 32
     a = rnd((m, k), 5, dev)
@@ -271,19 +275,24 @@ def test_gemm_resid_ps(dev, m, n, k, mean, recentre):
     z_ps = ps_encode(z0, npd)
     z0q = ps_decode(z_ps, n)
     aq, wq = ps_decode(a_ps, k), ps_decode(w_ps, k)[:n]
-    tiles = lib().ribca_test_resid_tiles(n)
+    tiles = lib().ribca_test_resid_part_rows(n) if duo else lib().ribca_test_resid_tiles(n)
     part = torch.zeros((tiles, m, 2), dtype=torch.float32, device=dev)
     rs = torch.zeros((m, 2), dtype=torch.float32, device=dev)
     # the forward hands the epilogue the (rstd, mean) the stored rows had: it subtracts that mean (re-centring)
     prev = _row_stats(z_ps, npd, m, n, dev) if recentre else None
-    check(lib().ribca_test_gemm_resid_ps(ptr(a_ps), 2 * kp, ptr(w_ps), 2 * kp, m, n, kp, ptr(bias), ptr(z_ps), 2 * npd, ptr(part), ptr(rs),
-                                         ptr(prev) if recentre else None, stream_ptr()), "resid_ps")
+    if duo:
+        wf = torch.zeros_like(w_ps)
+        check(lib().ribca_test_gemm_resid_ps_duo(ptr(a_ps), 2 * kp, ptr(w_ps), 2 * kp, m, n, kp, ptr(bias), ptr(wf), ptr(z_ps), 2 * npd, ptr(part),
+                                                 ptr(rs), ptr(prev) if recentre else None, stream_ptr()), "resid_ps duo")
+    else:
+        check(lib().ribca_test_gemm_resid_ps(ptr(a_ps), 2 * kp, ptr(w_ps), 2 * kp, m, n, kp, ptr(bias), ptr(z_ps), 2 * npd, ptr(part), ptr(rs),
+                                             ptr(prev) if recentre else None, stream_ptr()), "resid_ps")
     ref = z0q + aq @ wq.t() + bias.double()
     if recentre:
         ref = ref - prev[:, 1:2].double()
     got = ps_decode(z_ps, n)
     err = ((got - ref).abs() / (1.0 + ref.abs())).max().item()
-    note_err(f"gemm_resid_ps {m}x{n}x{k} mean {mean} recentre {recentre}", err)
+    note_err(f"gemm_resid_ps {m}x{n}x{k} mean {mean} recentre {recentre} duo {duo}", err)
     # as test_gemm_residual, plus the re-split of the new row (2^-23 relative); re-centred rows: z - mean is one more fp32 rounding
     # at |z| <= 45 (2^-24 x 45 = 2.7e-6 absolute)
     assert err < 2e-5, err
