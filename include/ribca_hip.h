@@ -196,7 +196,7 @@ int ribca_test_row_stats(uint16_t* z_ps, int32_t ldz, int32_t M, int32_t D, floa
 int32_t ribca_test_resid_tiles(int32_t N);
 int ribca_test_gemm_resid_ps(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
                              const float* bias, uint16_t* z_ps, int32_t ldz, float* part, float* rowstat, const float* prev, void* stream);
-/* gemm_resid_ps as the classifiers' full blocks run it for M >= 4096 (proj, fc2): two workgroups per CU (gemm_duo.hip), the weight in
+/* gemm_resid_ps as the classifiers' full blocks run it for the weight shapes where it measured faster (any M): two workgroups per CU (gemm_duo.hip), the weight in
  * MFMA fragment order (wf_scratch: Np * 2 * Kp uint16, filled here from W), the residual tile through the A ring as extra K steps against
  * an identity fragment, a load-free epilogue; statistics per wave column block (part: ribca_test_resid_part_rows(N) * M float2). */
 int32_t ribca_test_resid_part_rows(int32_t N);

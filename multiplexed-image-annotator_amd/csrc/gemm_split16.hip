@@ -940,7 +940,9 @@ ResidStatGeom launch_gemm_resid_ps(const GemmArgs& g, uint16_t* z, int ldz, floa
   static const int duo_mode = getenv("RIBCA_RESID_DUO") ? atoi(getenv("RIBCA_RESID_DUO")) : 1;
   const int blk = resid_duo_block(g.N);
   const bool want = force_duo || duo_mode == 2 || (duo_mode == 1 && resid_duo_pays(g.N, g.Kp));
-  if (want && g_variant == 0 && g.WF != nullptr && g.M >= 4096 && g.N % blk == 0 && g.N % 8 == 0) {
+  // (No threshold on M: this form is not bit-identical to the one-workgroup kernel -- the residual is added inside the accumulation,
+  // the statistics are combined per wave block -- and a cell's result must not depend on the size of the chunk it was computed in.)
+  if (want && g_variant == 0 && g.WF != nullptr && g.N % blk == 0 && g.N % 8 == 0) {
     const EpiResidZK epi{z, ldz, g.bias, g.M, g.N, part, prev, prev_stride};
     bool done = false;
     switch (gemm_pick_bn(g.N)) {

@@ -862,11 +862,10 @@ int ribca_test_gemm_resid_ps(const uint16_t* A, int32_t lda, const uint16_t* W, 
 }
 int32_t ribca_test_resid_part_rows(int32_t N) { return gemm_resid_part_rows(N); }
 // the same update on the two-workgroups-per-CU kernel with the residual tile riding the A ring (EpiResidZK): what the classifiers' full
-// blocks run for proj / fc2.  part needs ribca_test_resid_part_rows(N) x M pairs; wf_scratch the size of the packed weight.
+// blocks run for proj / fc2 where it measured faster (any M: the choice depends on the shape of the weight alone).  part needs ribca_test_resid_part_rows(N) x M pairs; wf_scratch the size of the packed weight.
 int ribca_test_gemm_resid_ps_duo(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
                                  const float* bias, uint16_t* wf_scratch, uint16_t* z_ps, int32_t ldz, float* part, float* rowstat,
                                  const float* prev, void* stream) {
-  if (M < 4096) return fail("ribca_test_gemm_resid_ps_duo: the forward uses this kernel for M >= 4096 only");
   if (!wf_scratch) return fail("ribca_test_gemm_resid_ps_duo: wf_scratch is NULL");
   if (N % 8 != 0) return fail("ribca_test_gemm_resid_ps_duo: N must be a multiple of 8");
   if ((rowstat != nullptr) != (part != nullptr)) return fail("ribca_test_gemm_resid_ps_duo: part and rowstat go together");

@@ -29,7 +29,7 @@ void launch_gemm_gelu(const GemmArgs& g, uint16_t* out, int ldo, hipStream_t s);
 // z_ps[m][n] = (z_ps[m][n] - prev[m * prev_stride].y) + acc + bias on the packed-split residual stream (prev = (rstd, mean) of the
 // stored rows: re-centring, see EpiResidPS; nullptr = none); part [gemm_resid_tiles(N)][M] receives (mean, centred sum of squares)
 // of every (row, column tile) of the NEW z, or nullptr
-// Returns the geometry of `part` it used: with a fragment-order weight (g.WF) and M >= 4096 the GEMM runs on the two-workgroups-per-CU
+// Returns the geometry of `part` it used: with a fragment-order weight (g.WF) the GEMM runs on the two-workgroups-per-CU
 // kernel with the residual tile riding the A ring (EpiResidZK, gemm_duo.hip) -- for the shapes where that measured faster, or for
 // every shape it supports with force_duo -- and the statistics come per WAVE column block (16 / 32 / 48 columns) instead of per column
 // tile; ln_finalize takes either.  RIBCA_RESID_DUO = 0 / 1 / 2: never / where it pays (default) / wherever supported.
