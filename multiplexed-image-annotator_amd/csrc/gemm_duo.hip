@@ -188,7 +188,7 @@ int duo_set_stamp_buffer(void* dev_ptr, unsigned int capacity_blocks) {
 template <int BM, int NW, int WM, int TN, int NWS, class Epi, int ABL>
 __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ WF, int M,
                                                                        int Kp, int mtiles, int ntiles, Epi epi, int mode, int delay) {
-  static_assert(BM == 256 || BM == 192, "tile rows");
+  static_assert(BM == 256 || BM == 192 || BM == 128, "tile rows");
   constexpr int NST = BM == 256 ? 2 : 3;      // ring stages
   static_assert(NWS == NST || (NST == 3 && NWS == 2), "W register sets");
   constexpr int WN = NW / WM, BN = 16 * TN * WN;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
   // EpiResidZK: the residual tile's BN / 32 K steps follow the product's own through the same ring
   constexpr bool ZK = is_zk<Epi>::value;
   constexpr int ZS = ZK ? BN / 32 : 0;
-  static_assert(!ZK || (NST == 3 && NWS == 3 && ABL == 0), "the residual-through-the-ring form exists for the production tile only");
+  static_assert(!ZK || (NST == 3 && ABL == 0), "the residual-through-the-ring form exists for the production tile only");
   const int nkz = nk + ZS;
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tc1 = 0, tc2 = 0;      // tc: shader-clock stamps around the K loop (in-kernel clock)
   if (ABL & 8) ts0 = __builtin_amdgcn_s_memrealtime();
@@ -656,7 +656,14 @@ bool launch_duo(const GemmArgs& g, const Epi& epi, hipStream_t s, int abl) {
   // 1 = the same tile with 8 waves as 2 x 4 (4 x 2), 2 W sets; 2 = 256 rows, 2-stage ring, 4 waves
   static const int form = getenv("RIBCA_DUO_FORM") ? atoi(getenv("RIBCA_DUO_FORM")) : 0;
   (void)form;
-  if constexpr (BN % 64 == 0) {
+  if constexpr (BN == 192) {
+    // 128 x 192 tiles, 4 waves as 1 x 4: a wave owns all 128 rows x 48 columns (96 accumulator registers) and every W fragment is
+    // requested by ONE wave.  (192 rows x 192 columns needs 144 + 48 + 16 registers beside the addresses: hipcc spills fragment
+    // registers inside the K loop, and a spilled register that an inline-asm load is still filling holds garbage.)
+    // (Not instantiated for EpiResidZK: with its second buffer descriptor and the epilogue's prefetched vectors hipcc parks scalars in
+    // scratch and reloads them every K step -- vector-memory operations the counted waits do not know about.)
+    return launch_duo_impl<128, 4, 1, 3, BN, Epi>(g, epi, s, abl);
+  } else if constexpr (BN % 64 == 0) {
 #ifdef RIBCA_DIAG
     if (form == 2) return launch_duo_impl<256, 4, 1, 2, BN, Epi>(g, epi, s, abl);
     if (form == 1) return launch_duo_impl<192, 8, 2, 2, BN, Epi>(g, epi, s, abl);
@@ -676,6 +683,7 @@ RIBCA_DUO_INST(128, EpiGelu) RIBCA_DUO_INST(96, EpiGelu) RIBCA_DUO_INST(64, EpiG
 RIBCA_DUO_INST(128, EpiGeluLn) RIBCA_DUO_INST(96, EpiGeluLn) RIBCA_DUO_INST(64, EpiGeluLn)
 RIBCA_DUO_INST(128, EpiQKVLn) RIBCA_DUO_INST(96, EpiQKVLn) RIBCA_DUO_INST(64, EpiQKVLn)
 RIBCA_DUO_INST(128, EpiResidZK) RIBCA_DUO_INST(96, EpiResidZK) RIBCA_DUO_INST(64, EpiResidZK)
+RIBCA_DUO_INST(192, EpiQKVLn) RIBCA_DUO_INST(192, EpiGeluLn)
 #ifdef RIBCA_DIAG
 RIBCA_DUO_INST(128, EpiResid) RIBCA_DUO_INST(96, EpiResid) RIBCA_DUO_INST(64, EpiResid)
 RIBCA_DUO_INST(128, EpiQKV) RIBCA_DUO_INST(96, EpiQKV) RIBCA_DUO_INST(64, EpiQKV)

@@ -838,6 +838,15 @@ static void launch_persist(const GemmArgs& g, const Epi& epi, hipStream_t s) {
 // two-workgroups-per-CU kernel for mlp.fc1.  The A/B and timing-ablation forms of DESIGN.md section 6 (no stagger, no loads, no
 // epilogue, fewer MFMA passes, stamps, persistent workgroups, duo variants 40-49) exist only in the diagnostic library
 // (-DRIBCA_DIAG: `python -m multiplexed_image_annotator_amd.build --diag` -> libribca_hip_diag.so, used by tools/).
+// RIBCA_DUO_BN192 (bit 0: qkv, bit 1: fc1; default 3, 0 for A/B): 128 x 192 tiles with 4 waves as 1 x 4 on the two-workgroups-per-CU
+// kernel where N % 192 == 0 -- every W fragment is requested by ONE wave: 1.67 bytes from L2 per (row, column, K step) against 2.67 for
+// the 2 x 2 waves of the 192 x 96 tile (qkv at D = 576, fc1 at D = 144) and the same 1.67 as the 192 x 128 tile.  Same bits (the
+// accumulation order per element does not change); qkv launches 840 -> 785 ms per pass, fc1 1950 -> 1928, +0.2-0.3 % end to end in an
+// interleaved same-box A/B (profiles/r3/ab_duo_128x192.txt).
+static int duo_bn192() {
+  static const int v = getenv("RIBCA_DUO_BN192") ? atoi(getenv("RIBCA_DUO_BN192")) : 3;
+  return v;
+}
 template <int BN, class Epi>
 static void launch_bn(const GemmArgs& g, const Epi& epi, hipStream_t s) {
   // GELU GEMMs whose weight carries a fragment-order copy (GemmArgs::WF, set by the block runner for mlp.fc1) run on the
@@ -846,6 +855,9 @@ static void launch_bn(const GemmArgs& g, const Epi& epi, hipStream_t s) {
   // 5-25 % slower.  RIBCA_GEMM_DUO=0: off.
   if constexpr (std::is_same<Epi, EpiGelu>::value || std::is_same<Epi, EpiGeluLn>::value) {
     static const bool duo_on = !(getenv("RIBCA_GEMM_DUO") && atoi(getenv("RIBCA_GEMM_DUO")) == 0);
+    if constexpr (std::is_same<Epi, EpiGeluLn>::value) {
+      if (g_variant == 0 && duo_on && (duo_bn192() & 2) && g.N % 192 == 0 && g.WF != nullptr && g.M >= 4096 && launch_duo<192, Epi>(g, epi, s, 0)) return;
+    }
     if (g_variant == 0 && duo_on && g.WF != nullptr && g.M >= 4096 && launch_duo<BN, Epi>(g, epi, s, 0)) return;
   }
   // The folded qkv product too, now that V is stored row-major (round 2 measured this epilogue 5-25 % slower on the duo kernel because
@@ -853,6 +865,9 @@ static void launch_bn(const GemmArgs& g, const Epi& epi, hipStream_t s) {
   // 1939 -> 1808 ms per pass, +0.65 % end to end in an interleaved same-box A/B (profiles/r3/ab_qkv_on_duo.txt).  RIBCA_QKV_DUO=0: off.
   if constexpr (std::is_same<Epi, EpiQKVLn>::value) {
     static const bool qkv_duo = !(getenv("RIBCA_QKV_DUO") && atoi(getenv("RIBCA_QKV_DUO")) == 0);
+    if (g_variant == 0 && qkv_duo && (duo_bn192() & 1) && g.N % 192 == 0 && g.WF != nullptr && g.M >= 4096 && epi.vrow &&
+        launch_duo<192, Epi>(g, epi, s, 0))
+      return;
     if (g_variant == 0 && qkv_duo && g.WF != nullptr && g.M >= 4096 && epi.vrow && launch_duo<BN, Epi>(g, epi, s, 0)) return;
   }
 #ifdef RIBCA_DIAG
