@@ -349,21 +349,6 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
       zpm[i] = (epi.prev != nullptr && m < M) ? epi.prev[(size_t)m * epi.prev_stride].y : 0.f;
     }
   }
-  // RIBCA_DUO_PREFETCH (build-time A/B): the folded epilogues' row statistics -- one 8-byte load per output row of the lane, the most
-  // numerous loads of those epilogues -- are requested here as well instead of behind the K loop
-#ifdef RIBCA_DUO_PREFETCH
-  constexpr bool PRS = Epi::kFold && !ZK;
-#else
-  constexpr bool PRS = false;
-#endif
-  float2 prs[PRS ? NB : 1][PRS ? RB : 1];
-  if constexpr (PRS) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int m = m0 + wm * (16 * MT) + 16 * i + r16;
-      prs[i / RB][i % RB] = epi.rowstat[(size_t)(m < M ? m : M - 1) * epi.rs_stride];
-    }
-  }
   f32x4 acc[NB][RB][TN];
 #pragma unroll
   for (int b = 0; b < NB; ++b)
@@ -553,16 +538,10 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
     else resid_zk_epilogue<TN, MT, RB, false>(epi, mbase, nbase, blk, g, acc, zb4, zpm);
   } else if (m0 + BM <= M && n0 + BN <= epi.N && !(mode & 0x10)) {      // mode bit 4 (RIBCA_DUO_GUARDED=1): A/B switch, always the guarded form
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      if constexpr (PRS) run_epilogue<TN, Epi, RB, true, true>(epi, mbase + 16 * RB * b, nbase, acc[b], prs[b]);
-      else run_epilogue<TN, Epi, RB, true>(epi, mbase + 16 * RB * b, nbase, acc[b]);
-    }
+    for (int b = 0; b < NB; ++b) run_epilogue<TN, Epi, RB, true>(epi, mbase + 16 * RB * b, nbase, acc[b]);
   } else {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      if constexpr (PRS) run_epilogue<TN, Epi, RB, false, true>(epi, mbase + 16 * RB * b, nbase, acc[b], prs[b]);
-      else run_epilogue<TN, Epi, RB>(epi, mbase + 16 * RB * b, nbase, acc[b]);
-    }
+    for (int b = 0; b < NB; ++b) run_epilogue<TN, Epi, RB>(epi, mbase + 16 * RB * b, nbase, acc[b]);
   }
   if constexpr (NT > 0) {
 #pragma unroll

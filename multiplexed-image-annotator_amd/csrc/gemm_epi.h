@@ -310,10 +310,8 @@ template <class Epi, class = void> struct is_zk : std::false_type {};
 template <class Epi> struct is_zk<Epi, std::enable_if_t<Epi::kZK>> : std::true_type {};
 
 // IN: the whole workgroup tile is inside M x N (only honoured by the epilogues that have unguarded forms: kInside)
-// PRE: prs holds (rstd, mean) of the lane's R rows, read by the caller in front of its K loop (folded epilogues of gemm_duo.hip)
-struct NoPre {};
-template <int TN, class Epi, int R = 4, bool IN = false, bool PRE = false, class PreT = NoPre>
-__device__ __forceinline__ void run_epilogue(const Epi& epi, int mbase, int nbase, f32x4 (&acc)[R][TN], const PreT& prs = PreT{}) {
+template <int TN, class Epi, int R = 4, bool IN = false>
+__device__ __forceinline__ void run_epilogue(const Epi& epi, int mbase, int nbase, f32x4 (&acc)[R][TN]) {
   constexpr bool INF = IN && has_inside<Epi>::value;
   float4 b4[TN], c4[TN];
   typename Epi::Ctx ctx[R][TN];
@@ -325,7 +323,6 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, int mbase, int nbas
   }
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    if constexpr (PRE) { rs[i] = typename Epi::RowS{prs[i].x, -prs[i].y * prs[i].x}; continue; }
     if constexpr (INF) rs[i] = epi.template fetch_row<true>(mbase + 16 * i);
     else rs[i] = epi.fetch_row(mbase + 16 * i);
   }
