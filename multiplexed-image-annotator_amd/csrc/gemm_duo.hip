@@ -665,14 +665,18 @@ bool launch_duo(const GemmArgs& g, const Epi& epi, hipStream_t s, int abl) {
     return launch_duo_impl<128, 4, 1, 3, BN, Epi>(g, epi, s, abl);
   } else if constexpr (BN % 64 == 0) {
 #ifdef RIBCA_DIAG
-    if (form == 2) return launch_duo_impl<256, 4, 1, 2, BN, Epi>(g, epi, s, abl);
-    if (form == 1) return launch_duo_impl<192, 8, 2, 2, BN, Epi>(g, epi, s, abl);
+    if constexpr (!is_zk<Epi>::value) {      // the A/B tile forms do not exist for the residual-through-the-ring epilogue
+      if (form == 2) return launch_duo_impl<256, 4, 1, 2, BN, Epi>(g, epi, s, abl);
+      if (form == 1) return launch_duo_impl<192, 8, 2, 2, BN, Epi>(g, epi, s, abl);
+    }
 #endif
     return launch_duo_impl<192, 4, 1, 3, BN, Epi>(g, epi, s, abl);
   } else {   // BN = 96
 #ifdef RIBCA_DIAG
-    if (form == 2) return launch_duo_impl<256, 4, 2, 2, BN, Epi>(g, epi, s, abl);
-    if (form == 1) return launch_duo_impl<192, 8, 4, 2, BN, Epi>(g, epi, s, abl);
+    if constexpr (!is_zk<Epi>::value) {
+      if (form == 2) return launch_duo_impl<256, 4, 2, 2, BN, Epi>(g, epi, s, abl);
+      if (form == 1) return launch_duo_impl<192, 8, 4, 2, BN, Epi>(g, epi, s, abl);
+    }
 #endif
     return launch_duo_impl<192, 4, 2, 3, BN, Epi>(g, epi, s, abl);
   }
