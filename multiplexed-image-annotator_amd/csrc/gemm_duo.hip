@@ -306,10 +306,14 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
     char* st = smem + slot * STAGE + wave * 1024;
     if (ZK && kk >= nk) {
       const int ko = n0 * 4 + (kk - nk) * (4 * BK);
+      // 128 x 192 form: the residual rows are read ONCE, by this workgroup alone -- a non-temporal request.  (It also keeps the two
+      // DMA paths apart for hipcc: with identical instructions behind the branch it merges them into one load whose DESCRIPTOR is
+      // picked from a table in scratch and re-read every K step -- vector-memory operations the counted waits know nothing of.)
+      constexpr int ZAUX = BN == 192 ? 2 : 0;
 #pragma unroll
       for (int i = 0; i < GPW; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(z_rsrc, (__attribute__((address_space(3))) void*)(st + i * (1024 * NW)), 16, z_voff, i * z_gstride + ko,
-                                                 0, 0);
+                                                 0, ZAUX);
       return;
     }
     const int ko = kk * (4 * BK);
@@ -660,8 +664,6 @@ bool launch_duo(const GemmArgs& g, const Epi& epi, hipStream_t s, int abl) {
     // 128 x 192 tiles, 4 waves as 1 x 4: a wave owns all 128 rows x 48 columns (96 accumulator registers) and every W fragment is
     // requested by ONE wave.  (192 rows x 192 columns needs 144 + 48 + 16 registers beside the addresses: hipcc spills fragment
     // registers inside the K loop, and a spilled register that an inline-asm load is still filling holds garbage.)
-    // (Not instantiated for EpiResidZK: with its second buffer descriptor and the epilogue's prefetched vectors hipcc parks scalars in
-    // scratch and reloads them every K step -- vector-memory operations the counted waits do not know about.)
     return launch_duo_impl<128, 4, 1, 3, BN, Epi>(g, epi, s, abl);
   } else if constexpr (BN % 64 == 0) {
 #ifdef RIBCA_DIAG
@@ -687,7 +689,7 @@ RIBCA_DUO_INST(128, EpiGelu) RIBCA_DUO_INST(96, EpiGelu) RIBCA_DUO_INST(64, EpiG
 RIBCA_DUO_INST(128, EpiGeluLn) RIBCA_DUO_INST(96, EpiGeluLn) RIBCA_DUO_INST(64, EpiGeluLn)
 RIBCA_DUO_INST(128, EpiQKVLn) RIBCA_DUO_INST(96, EpiQKVLn) RIBCA_DUO_INST(64, EpiQKVLn)
 RIBCA_DUO_INST(128, EpiResidZK) RIBCA_DUO_INST(96, EpiResidZK) RIBCA_DUO_INST(64, EpiResidZK)
-RIBCA_DUO_INST(192, EpiQKVLn) RIBCA_DUO_INST(192, EpiGeluLn)
+RIBCA_DUO_INST(192, EpiQKVLn) RIBCA_DUO_INST(192, EpiGeluLn) RIBCA_DUO_INST(192, EpiResidZK)
 #ifdef RIBCA_DIAG
 RIBCA_DUO_INST(128, EpiResid) RIBCA_DUO_INST(96, EpiResid) RIBCA_DUO_INST(64, EpiResid)
 RIBCA_DUO_INST(128, EpiQKV) RIBCA_DUO_INST(96, EpiQKV) RIBCA_DUO_INST(64, EpiQKV)

@@ -931,20 +931,31 @@ void launch_gemm_resid(const GemmArgs& g, float* z, int ldz, hipStream_t s) {
 void launch_gemm_gelu(const GemmArgs& g, uint16_t* out, int ldo, hipStream_t s) {
   launch_any(g, EpiGelu{out, ldo, g.bias, g.M, g.N, nt_mask() & 1}, s);
 }
-// columns of a wave's block in the two-workgroups-per-CU kernel (gemm_duo.hip launch_duo: 4 waves as 1 x 4 for 64- / 128-wide tiles,
-// 2 x 2 for 96-wide ones)
+// Tile width of the two-workgroups-per-CU form a residual GEMM would take (gemm_duo.hip launch_duo), and the columns of a wave's block
+// in it: 4 waves as 1 x 4 for 64- / 128- / 192-wide tiles, 2 x 2 for 96-wide ones.
+// RIBCA_RESID_DUO192 (default 1; 0 for A/B): where N % 192 == 0 the 128 x 192 tile (every W fragment requested once: 1.67 bytes from L2
+// per unit instead of 2.67) replaces the 192 x 96 one, and with it the long K loops pay too (fc2 at D = 384 / 576).
+static bool resid_duo192() {
+  static const bool on = !(getenv("RIBCA_RESID_DUO192") && atoi(getenv("RIBCA_RESID_DUO192")) == 0);
+  return on;
+}
+static int resid_duo_bn(int N) { return (resid_duo192() && N % 192 == 0) ? 192 : gemm_pick_bn(N); }
 static int resid_duo_block(int N) {
-  const int bn = gemm_pick_bn(N);
-  return bn == 96 ? 48 : bn / 4;
+  const int bn = resid_duo_bn(N);
+  return (bn == 96 || bn == 192) ? 48 : bn / 4;
 }
 // Where the two-workgroups-per-CU form pays (profiles/r3/resid_through_ring_bench.txt, M = 103 424, cache-cold operands, row statistics
 // included on both sides): the narrow classifier (N = 144: proj -15 %, fc2 -10 %) and the short-K products of the 96-wide tiles (proj at
-// D = 288 / 576: -2 % with the test hook's weight repack inside the figure).  Long K loops lose (fc2 at D = 288 +11 %, D = 576 +4 %):
-// with 4 waves as 2 x 2 every W fragment is requested by two waves, 2.7 bytes from L2 per (row, column, K step) against 1.8 for the
-// 256 x 96 tile of the one-workgroup kernel, and the K loop runs into the CU's L2 fetch rate (61-70 GB/s) before
-// the load-free epilogue can matter; the 128-wide form (1 x 4 waves: each reads the whole A stage from LDS) ties (+1 ... +5 %).
+// D = 288 / 576: -2 % with the test hook's weight repack inside the figure).  Long K loops lose on the 192 x 96 tile (fc2 at D = 288
+// +11 %, D = 576 +4 %): with 4 waves as 2 x 2 every W fragment is requested by two waves, 2.7 bytes from L2 per (row, column, K step)
+// against 1.8 for the 256 x 96 tile of the one-workgroup kernel, and the K loop runs into the CU's L2 fetch rate (61-70 GB/s, DESIGN.md
+// section 6.2) before the load-free epilogue can matter; the 192 x 128 form (1 x 4 waves) ties (+1 ... +5 %).
+// The 128 x 192 tile (1.67 bytes per unit) pays wherever the one-workgroup kernel would run its 96-wide tile (1.83), long K loops
+// included -- proj at D = 576 -12 %, fc2 at D = 576 -7 % -- and loses against the 128-wide tile (1.50): D = 384 +1 ... +10 %
+// (profiles/r3/resid_through_ring_bench_128x192.txt).
 static bool resid_duo_pays(int N, int Kp) {
   if (N <= 192) return true;
+  if (resid_duo_bn(N) == 192) return gemm_pick_bn(N) == 96;
   return gemm_pick_bn(N) == 96 && Kp <= (N + 31) / 32 * 32;
 }
 ResidStatGeom launch_gemm_resid_ps(const GemmArgs& g, uint16_t* z, int ldz, float2* part, const float2* prev, int prev_stride, hipStream_t s,
@@ -960,7 +971,8 @@ ResidStatGeom launch_gemm_resid_ps(const GemmArgs& g, uint16_t* z, int ldz, floa
   if (want && g_variant == 0 && g.WF != nullptr && g.N % blk == 0 && g.N % 8 == 0) {
     const EpiResidZK epi{z, ldz, g.bias, g.M, g.N, part, prev, prev_stride};
     bool done = false;
-    switch (gemm_pick_bn(g.N)) {
+    switch (resid_duo_bn(g.N)) {
+      case 192: done = launch_duo<192, EpiResidZK>(g, epi, s, 0); break;
       case 128: done = launch_duo<128, EpiResidZK>(g, epi, s, 0); break;
       case 64: done = launch_duo<64, EpiResidZK>(g, epi, s, 0); break;
       default: done = launch_duo<96, EpiResidZK>(g, epi, s, 0); break;

@@ -253,8 +253,8 @@ def test_row_stats(dev, d, mean, std):
 RESID_PS_SHAPES = [(1, 288, 288), (300, 288, 1152), (257, 144, 144), (130, 144, 576), (77, 576, 2304), (129, 384, 384), (515, 768, 768),
                    (11100, 576, 576), (22100, 288, 288), (16500, 384, 1536), (40000, 144, 144)]
 # the two-workgroups-per-CU form with the residual tile riding the A ring (what the full blocks run where it is faster): every tile width
-# (96 / 128 / 64), a single row, ragged last row tiles, a last column tile half behind N (144, 240), short and long K, one K step
-RESID_ZK_SHAPES = [(1, 288, 288), (300, 144, 576), (909, 576, 576), (193, 384, 384), (11100, 576, 576), (22100, 288, 288), (16500, 384, 1536), (40000, 144, 144), (4100, 144, 576), (5000, 768, 768),
+# (96 / 128 / 64, and 128 x 192 tiles where N % 192 == 0), a single row, ragged last row tiles, a last column tile half behind N (144, 240), short and long K, one K step
+RESID_ZK_SHAPES = [(1, 288, 288), (300, 144, 576), (909, 576, 576), (193, 384, 384), (4100, 256, 512), (129, 192, 64), (11100, 576, 576), (22100, 288, 288), (16500, 384, 1536), (40000, 144, 144), (4100, 144, 576), (5000, 768, 768),
                    (4097, 64, 64), (4200, 192, 96), (4300, 240, 32), (6000, 576, 2304), (4096, 288, 1152)]
 
 
