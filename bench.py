@@ -392,7 +392,7 @@ def main():
                            "bound_note": f"time-weighted over the classifiers: {t_mfma:.0f} ms of GEMMs MFMA-bound ({', '.join(m['model'] for m in per_model if m['bound'] == 'mfma')}), "
                                          f"{t_hbm:.0f} ms HBM-bound ({', '.join(m['model'] for m in per_model if m['bound'] == 'hbm')}); "
                                          "a classifier's side of the ridge follows its algorithmic FLOP per byte (per_model_flop_per_byte; 104 at the ridge of the issued work)",
-                           "kernel": "gemm_ps_split_kernel (fc2, proj at D = 384) + gemm_ps_duo_kernel (fc1, qkv at D = 576; proj at D = 144 / 288 / 576 and fc2 at D = 144 with the residual tile through the operand ring) + cell_qkv_attention_kernel (norm1 + qkv + attention, D <= 384), fp16x3", "achieved": round(achieved, 2),
+                           "kernel": "gemm_ps_split_kernel (fc2 at D = 288 / 384, proj at D = 384) + gemm_ps_duo_kernel (fc1, qkv at D = 576; proj at D = 144 / 288 / 576 and fc2 at D = 144 / 576 with the residual tile through the operand ring) + cell_qkv_attention_kernel (norm1 + qkv + attention, D <= 384), fp16x3", "achieved": round(achieved, 2),
                            "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 5),
                            "traffic": traffic, "traffic_unit": f"bytes/launch (2*FETCH_SIZE + WRITE_SIZE, {traffic_src})",
                            "algorithmic_bytes_per_launch": round(alg_bytes / max(g_n, 1)),
