@@ -57,6 +57,24 @@ class _LazyPredictions:
         return iter(self._get())
 
 
+
+def _load_state_dict(path: str) -> Dict[str, torch.Tensor]:
+    """``{"model": state_dict}`` checkpoint as the reference stores it (model.py:189-231, markerImputer.py:260-271).
+
+    The reference unpickles with ``weights_only=False``; a state dict is plain tensors, so the drop-in uses the loader that executes
+    nothing from the file and says so when a checkpoint holds anything else.
+    """
+    try:
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:  # pickle.UnpicklingError and friends: name the file and the remedy
+        raise RuntimeError(
+            "{}: not a plain tensor checkpoint (torch.load(weights_only=True) refused it: {}). Re-save it as "
+            "torch.save({{'model': model.state_dict()}}, path).".format(path, e)) from e
+    if not isinstance(ckpt, dict) or "model" not in ckpt:
+        raise RuntimeError("{}: expected a dict with a 'model' state dict".format(path))
+    return ckpt["model"]
+
+
 class Annotator(object):
     def __init__(self, marker_list_path, image_path, device, main_dir='./', batch_id='', strict=True, infer=True, min_cells=-1,
                  normalize=True, blur=False, amax=1, confidence=0.25, cell_size=30, cell_type_confidence=None, n_jobs=0):
@@ -123,7 +141,7 @@ class Annotator(object):
             sd = self._weights.get(name)
             path = os.path.join(MODEL_DIR, name + ".pth")
             if sd is None and os.path.exists(path):
-                sd = torch.load(path, map_location="cpu", weights_only=False)["model"]
+                sd = _load_state_dict(path)
             if sd is None:
                 msg = {"immune_base": "Immune base", "immune_extended": "Immune extended", "immune_full": "Immune full",
                        "struct": "Tissue structure", "nerve": "Nerve cell"}[name] + " model not found"
@@ -139,7 +157,7 @@ class Annotator(object):
             sd = self._weights.get(panel + "_impute")
             path = os.path.join(MODEL_DIR, panel + "_impute.pth")
             if sd is None and panel in ("immune_full", "immune_extended", "immune_base") and os.path.exists(path):
-                sd = torch.load(path, map_location="cpu", weights_only=False)["model"]
+                sd = _load_state_dict(path)
             if sd is None:
                 raise ValueError("Panel not found")
             self.imputers[panel] = ops.MaeModel(sd, _lib.require_gpu())

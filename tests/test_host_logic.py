@@ -77,3 +77,27 @@ def test_palette_and_confidence_colours_match_reference(golden_dir):
     exp = g["viridis_rgb"].copy()
     exp[~(v > 0)] = (192, 192, 192)                     # colorize paints non-positive confidences silver (model.py:831)
     assert np.array_equal(got.astype(np.int64), exp)
+
+
+class _NotATensor:      # module-level so that pickle can name it (what an arbitrary-code checkpoint looks like to the loader)
+    pass
+
+
+def test_checkpoint_loader_executes_nothing_from_the_file(tmp_path):
+    """annotator._load_state_dict: the reference's ``{"model": state_dict}`` layout (model.py:189-231) through torch's weights_only
+    loader; a checkpoint holding anything but tensors is refused with a message naming the file, not unpickled."""
+    import torch
+    from multiplexed_image_annotator_amd.annotator import _load_state_dict
+    good = tmp_path / "immune_base.pth"
+    sd = {"cls_token": torch.arange(6, dtype=torch.float32).reshape(1, 1, 6), "head.bias": torch.zeros(3)}
+    torch.save({"model": sd}, str(good))
+    got = _load_state_dict(str(good))
+    assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    bad = tmp_path / "evil.pth"
+    torch.save({"model": {"w": torch.zeros(1)}, "extra": _NotATensor()}, str(bad))
+    with pytest.raises(RuntimeError, match="evil.pth"):
+        _load_state_dict(str(bad))
+    nokey = tmp_path / "nokey.pth"
+    torch.save({"state": sd}, str(nokey))
+    with pytest.raises(RuntimeError, match="'model'"):
+        _load_state_dict(str(nokey))
