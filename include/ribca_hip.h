@@ -203,6 +203,16 @@ int32_t ribca_test_resid_part_rows(int32_t N);
 int ribca_test_gemm_resid_ps_duo(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
                                  const float* bias, uint16_t* wf_scratch, uint16_t* z_ps, int32_t ldz, float* part, float* rowstat,
                                  const float* prev, void* stream);
+/* The MX form of the residual GEMM (csrc/gemm_mx.hip; replaces timm Mlp.fc2 reached from reference model.py:54-55): A given as
+ * packed-split rows is first converted to the three-plane MX3 format (hi_out [M][Kp128] fp16, l8_out [M][Kp128] bytes, sc_out
+ * [M][Kp128 / 32] bytes, Kp128 = Kp rounded up to 128; all three are outputs the tests inspect), W to the MX weight image
+ * (wh_scratch / wx_scratch: ribca_test_mx_weight_bytes), then z_ps = (z_ps - prev mean) + A W^T + bias with statistics per 48-column
+ * block (part: (N / 48) * M float2).  N % 48 == 0. */
+int64_t ribca_test_mx_weight_bytes(int32_t N, int32_t Kp, int32_t which);
+int ribca_test_mx_pack_act(const uint16_t* A, int32_t lda, int32_t M, int32_t Kp, uint16_t* hi_out, uint8_t* l8_out, uint8_t* sc_out, void* stream);
+int ribca_test_gemm_mx_resid(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp, const float* bias,
+                             uint16_t* hi_out, uint8_t* l8_out, uint8_t* sc_out, uint16_t* wh_scratch, uint8_t* wx_scratch, uint16_t* z_ps,
+                             int32_t ldz, float* part, float* rowstat, const float* prev, void* stream);
 int ribca_test_gemm_fold(int32_t kind, const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
                          const float* bias2, const float* csum, const float* rowstat, void* out, int32_t ldo, void* stream);
 int ribca_test_qkv_attention_fold(const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t cells, int32_t D, int32_t Kp,

@@ -69,6 +69,10 @@ SIGNATURES = {
     "ribca_test_resid_part_rows": (c_int32, [c_int32]),
     "ribca_test_gemm_resid_ps_duo": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                                c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ribca_test_mx_weight_bytes": (c_int64, [c_int32, c_int32, c_int32]),
+    "ribca_test_mx_pack_act": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ribca_test_gemm_mx_resid": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ribca_test_gemm_fold": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_int32, c_void_p]),
     "ribca_test_qkv_attention_fold": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libribca_hip.so")
 LIB_DIAG = os.path.join(HERE, "libribca_hip_diag.so")
-SOURCES = ["gemm_split16.hip", "gemm_duo.hip", "attention.hip", "cell_attention.hip", "vit_misc.hip", "preprocess.hip", "preprocess_scaled.hip", "vote.hip", "colorize.hip", "knn.hip", "normalize.hip", "ribca_api.hip"]
+SOURCES = ["gemm_split16.hip", "gemm_duo.hip", "gemm_mx.hip", "attention.hip", "cell_attention.hip", "vit_misc.hip", "preprocess.hip", "preprocess_scaled.hip", "vote.hip", "colorize.hip", "knn.hip", "normalize.hip", "ribca_api.hip"]
 HEADERS = ["ribca_common.h", "ribca_kernels.h", "gemm_epi.h", os.path.join("..", "..", "include", "ribca_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

@@ -367,6 +367,91 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, int mbase, int nbas
   }
 }
 
+// ---------------------------------------------------------------------------------------------- EpiResidZK pieces shared by gemm_duo.hip and gemm_mx.hip
+// ---- EpiResidZK (gemm_epi.h): descriptor over the residual tile's rows, the four-lane sum and the load-free epilogue
+template <class Epi>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t zk_rsrc(const Epi& epi, int m0, int rows_here, __amdgpu_buffer_rsrc_t other) {
+  if constexpr (is_zk<Epi>::value) {
+    // the last row ends with its own 2 * Dp values, not with the row pitch (ldz can be a multiple of it): reads behind it return zeros
+    const int row_bytes = ((epi.N + 31) / 32 * 32) * 4;
+    return __builtin_amdgcn_make_buffer_rsrc(epi.z + (size_t)m0 * epi.ldz, 0, (rows_here - 1) * epi.ldz * 2 + row_bytes, 0x00020000);
+  } else {
+    return other;
+  }
+}
+// sum over the four lanes (r16, g = 0 .. 3) that share an output row: two lane-half swaps (gfx950), the same bits in all four, fixed order
+// (Written as inline asm: handed the same value twice, hipcc folds the two results of the swap builtins into one -- the ISA then adds a
+// register to itself; tools/swap_probe.hip shows it.  s_nop: the swaps read VALU results of the instruction just before.)
+__device__ __forceinline__ float g4_sum(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  float c = a + b, d;
+  asm volatile("v_mov_b32 %0, %1\n\ts_nop 1\n\tv_permlane32_swap_b32 %1, %0\n\ts_nop 1" : "=&v"(d), "+v"(c));
+  return c + d;
+}
+// acc holds z + A W^T of the wave's MT x TN tiles (lane: row r16 of every row tile, columns 4 g .. 4 g + 3 of every column tile);
+// b4 / pm were read before the K loop.  IN: the whole workgroup tile lies inside M x N.
+template <int TN, int MT, int RB, bool IN>
+__device__ __forceinline__ void resid_zk_epilogue(const EpiResidZK& epi, int mbase, int nbase, int blk, int g, f32x4 (&acc)[MT / RB][RB][TN],
+                                                  const float4 (&b4)[TN], const float (&pm)[MT]) {
+  float sum[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    f32x4(&a)[TN] = acc[i / RB][i % RB];
+    const int m = mbase + 16 * i;
+    const bool ok = IN || m < epi.M;
+    uint16_t* zr = epi.z + (size_t)(ok ? m : 0) * epi.ldz;
+    const f32x2v pm2 = {pm[i], pm[i]};
+    f32x2v tot = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      f32x2v x0 = (f32x2v{a[j][0], a[j][1]} - pm2) + f32x2v{b4[j].x, b4[j].y};
+      f32x2v x1 = (f32x2v{a[j][2], a[j][3]} - pm2) + f32x2v{b4[j].z, b4[j].w};
+      x0.x = clamp_f16_range(x0.x); x0.y = clamp_f16_range(x0.y); x1.x = clamp_f16_range(x1.x); x1.y = clamp_f16_range(x1.y);
+      a[j] = f32x4{x0.x, x0.y, x1.x, x1.y};
+      tot += x0; tot += x1;
+      // split (values already inside the fp16 range) and pair store: the partner lane (g ^ 1) holds the other 4 columns of the PS group
+      uint2 hi, lo;
+      hi.x = cvt_pk_f16(x0.x, x0.y); hi.y = cvt_pk_f16(x1.x, x1.y);
+      lo.x = cvt_pk_f16(f32_minus_f16lo(x0.x, hi.x), f32_minus_f16hi(x0.y, hi.x));
+      lo.y = cvt_pk_f16(f32_minus_f16lo(x1.x, hi.y), f32_minus_f16hi(x1.y, hi.y));
+      const auto rx = __builtin_amdgcn_permlane16_swap(hi.x, lo.x, false, false);
+      const auto ry = __builtin_amdgcn_permlane16_swap(hi.y, lo.y, false, false);
+      const u32x4 o = {rx[0], ry[0], rx[1], ry[1]};      // even g: 8 x hi, odd g: 8 x lo
+      const int k = nbase + 16 * j;
+      if (ok) *reinterpret_cast<u32x4*>(zr + ps_off(k & ~7) + ((k & 4) ? 8 : 0)) = o;
+    }
+    sum[i] = tot.x + tot.y;
+  }
+  if (epi.part == nullptr) return;
+  constexpr float inv = 1.0f / (float)(16 * TN);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) sum[i] = g4_sum(sum[i]) * inv;      // block mean of the row
+  float q[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    f32x4(&a)[TN] = acc[i / RB][i % RB];
+    const f32x2v mu = {sum[i], sum[i]};
+    f32x2v qq = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const f32x2v d0 = f32x2v{a[j][0], a[j][1]} - mu, d1 = f32x2v{a[j][2], a[j][3]} - mu;
+      qq += d0 * d0; qq += d1 * d1;
+    }
+    q[i] = qq.x + qq.y;
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) q[i] = g4_sum(q[i]);
+  if (g == 0) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = mbase + 16 * i;
+      if (IN || m < epi.M) epi.part[(size_t)blk * epi.M + m] = float2{sum[i], q[i]};
+    }
+  }
+}
+
+
 // ---------------------------------------------------------------------------------------------- kernel
 __device__ __forceinline__ int swz_f(int row) { return ((row >> 1) & 7) ^ ((((row + 12) & 15) < 8) ? 2 : 0); }
 

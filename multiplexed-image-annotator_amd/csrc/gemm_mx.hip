@@ -1,0 +1,622 @@
+// "MX" form of the split-operand GEMM: fp16 hi * hi on v_mfma_f32_16x16x32_f16 plus TWO block-scaled correction products on
+// v_mfma_scale_f32_16x16x128_f8f6f4 -- 1.75 matrix units per product instead of the three fp16 passes of gemm_split16.hip /
+// gemm_duo.hip, and 3 bytes per activation element instead of 4 (timm Mlp.fc2 of every full Block reached from reference
+// cell_type_annotation/model.py:54-55 ``for blk in self.blocks: x = blk(x)``; tolerance: north_star's 1e-3 on
+// softmax(model(x), dim=1), model.py:401-404).
+//
+//   x = hi + lo,  hi = fp16(x),  lo = x - hi                      (as everywhere on this path: ribca_common.h)
+//   A W^T  ~=  Ah Wh^T  +  Al' Wh'^T  +  Ah' Wl'^T                Ah Wh^T : 4 x v_mfma_f32_16x16x32_f16 per 128 k   (64 cycles)
+//                                                                 Al' Wh'^T: A lo as fp8 e4m3 x W hi as fp6 e2m3    (32 cycles)
+//                                                                 Ah' Wl'^T: A hi as fp6 e2m3 x W lo as fp6 e2m3    (16 cycles)
+//   every primed operand block-scaled (E8M0 per 32 k).  The corrections are 2^-11 of the product and need 4 bits each: the scheme's
+//   error is 2^-16 class (tools/mx_mix_probe.hip: 7.8e-6 of max |C| on hardware, the roundings emulated bit for bit;
+//   tests/precision_study.py: 4-9e-5 on softmax outputs after 12 blocks).  What it buys (profiles/r4/mx_mix_probe.txt): one wave's 128-deep
+//   step over 8 x 3 tiles takes 1.5 us instead of 2.5 us of matrix time at two waves per SIMD (the chip is power-managed: fewer matrix
+//   passes also run at a higher clock), and the A stream through L2 -> LDS shrinks by a quarter.
+//
+// Operand formats ("MX3" activations; written by mx_pack_act_kernel here and by the GELU epilogue of gemm_duo.hip):
+//   * 32 consecutive columns form a block; E = max(exponent field of the block's largest |hi|, 1) - 15;
+//     the block's scale byte is  sl = E - 19 + 127  (lo / 2^(E-19) <= 256 < 448, the e4m3 maximum: v_cvt_scalef32_pk_fp8_f32 does NOT
+//     saturate, it returns the NaN code); the fp6 image of hi uses sh = sl + 17 (hi / 2^(E-2) < 8, saturating at 7.5);
+//   * hi plane  [M][Kp] fp16, PERMUTED inside every 128 columns: column c = 32 g + 8 s + j sits at position 32 s + 8 g + j, so that the
+//     f16 MFMA of sub-step s reads one contiguous 64-byte piece per row AND lane (row, g) holds 32 CONSECUTIVE columns over the four
+//     sub-steps -- exactly the block the scaled MFMA wants in one lane, so the fp6 image of hi is ONE v_cvt_scalef32_pk32_fp6_f16 of
+//     registers the kernel has anyway (never stored);
+//   * lo plane  [M][Kp] bytes (e4m3, natural column order: a 128-deep step of a row is one 128-byte line);
+//   * scale plane [M][Kp / 32] bytes.
+//   Weights (mx_pack_w_kernel, once per model): fragment order as in gemm_duo.hip, grouped by the 48 output columns (3 column tiles) one
+//   wave owns -- per group and 128 k: twelve 1 KB hi fragments [sub-step][tile], then the fp6 images of lo and hi (24 bytes per lane and
+//   tile, as 8 + 16) and 8 bytes of scale bytes per lane -- so that ONE scalar base per stream reaches a step's operands.
+//
+// Kernel: two 256-thread workgroups per CU (77 KB of LDS each), tile 128 x 192, 4 waves as 1 x 4 (a wave owns all 128 rows x 48 columns
+// = 8 x 3 accumulator tiles), W straight from L2 into registers, A through LDS by buffer_load ... lds.  One 128-deep step:
+//     [B1: the step's four hi units have landed]  f16 phase: 4 sub-steps x 8 row tiles x 3 MFMAs, W hi fragments streamed two sub-steps
+//     ahead  ->  conversion: every wave turns the hi rows of TWO row tiles into fp6 (2 v_cvt_scalef32_pk32_fp6_f16 per wave instead of 8)
+//     and leaves them in LDS  ->  [B2]  the next step's hi units are requested into the slots just freed  ->  MX phase: 8 row tiles x
+//     (lo, fp6 hi, scale from LDS) x 3 x 2 scaled MFMAs.
+// Two barriers per 128 k (the fp16x3 kernels: four).  The residual tile rides the ring behind the product's own steps exactly as in
+// gemm_duo.hip (EpiResidZK: identity fragments, exact), and the epilogue is that kernel's.
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+#include "gemm_epi.h"
+
+namespace ribca {
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+typedef unsigned u32v4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32v2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h32 __attribute__((ext_vector_type(32)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+template <int... Is, class F>
+__device__ __forceinline__ void sfor_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+  sfor_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+// exponent byte shared by the producers: ef = exponent field of the block's largest |hi| (fp16 bits)
+__device__ __host__ __forceinline__ int mx_sl_byte(int ef) { return (ef < 1 ? 1 : ef) + 93; }     // E - 19 + 127, E = max(ef, 1) - 15
+constexpr int kMxShDelta = 17;                                                                       // sh = sl + 17  (E - 2 + 127)
+__device__ __forceinline__ float e8m0_float(int byte) { return __builtin_bit_cast(float, (unsigned)byte << 23); }
+
+// position of logical column c in the permuted hi plane
+__device__ __host__ __forceinline__ int mx_hi_pos(int c) { return (c & ~127) | (((c >> 3) & 3) << 5) | (((c >> 5) & 3) << 3) | (c & 7); }
+
+template <int OFF>
+__device__ __forceinline__ void lds_rd128(u32v4& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_rd128h(f16x8& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_rd64(u32v2& dst, unsigned addr) {
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_rd8(unsigned& dst, unsigned addr) {
+  asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_wr128(unsigned addr, const u32v4& v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_wr64(unsigned addr, const u32v2& v) {
+  asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ unsigned long long uniform_ptr(const void* p) {
+  const unsigned long long b = (unsigned long long)(uintptr_t)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+template <int OFF>
+__device__ __forceinline__ void gld16h(f16x8& dst, unsigned voff, unsigned long long sbase) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void gld16(u32v4& dst, unsigned voff, unsigned long long sbase) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void gld8(u32v2& dst, unsigned voff, unsigned long long sbase) {
+  asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void gld4(unsigned& dst, unsigned voff, unsigned long long sbase) {
+  asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+// fp6 operands occupy 6 dwords of the 8 the builtin takes: the upper two are never read by the instruction
+__device__ __forceinline__ i32x8 op6(const u32v4& a, const u32v2& b) {
+  const u32v4 bx = __builtin_shufflevector(b, b, 0, 1, -1, -1);
+  return __builtin_bit_cast(i32x8, __builtin_shufflevector(a, bx, 0, 1, 2, 3, 4, 5, -1, -1));
+}
+__device__ __forceinline__ i32x8 op8(const u32v4& a, const u32v4& b) {
+  return __builtin_bit_cast(i32x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// Pins every MFMA issued so far in front of this point (no instruction): the products are pure values to the compiler, which otherwise
+// sinks them below the conditional operand requests that follow a phase -- keeping COPIES of the fragments those requests overwrite
+// (measured: 400 registers instead of 230).
+template <int MT, int TN>
+__device__ __forceinline__ void pin_acc(f32x4 (&acc)[1][MT][TN]) {
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[0][i][j]));
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------------------------- operand packers
+// bytes of the weight image per (48 output columns, 128 k): WH 12 x 1 KB of fp16 hi fragments [sub-step][tile];
+// WX: l6b [tile][64 x 8] | l6a [tile][64 x 16] | scale bytes 64 x 8 (sl0 sh0 sl1 sh1 | sl2 sh2 0 0) | h6b [tile][64 x 8] | h6a [tile][64 x 16]
+// (every piece within the 13-bit signed instruction offset of one of two scalar bases: the block's start and the start of h6a)
+constexpr int kMxWhBytes = 12288, kMxWxBytes = 9728;
+constexpr int kWxL6b = 0, kWxL6a = 1536, kWxSc = 4608, kWxH6b = 5120, kWxH6a = 6656;
+// (sized for whole 192-column tiles: the waves of a last tile that lie beyond N still stream their -- zero -- fragments)
+size_t mx_wh_bytes(int Np, int Kp) { return (size_t)((Np + 191) / 192 * 4) * (Kp / 128) * kMxWhBytes; }
+size_t mx_wx_bytes(int Np, int Kp) { return (size_t)((Np + 191) / 192 * 4) * (Kp / 128) * kMxWxBytes; }
+
+// packed-split weight [Np][2 Kp] (Kp % 128 == 0, rows n >= N read as zeros by the caller's padding) -> WH / WX; one thread per
+// (output column, 32-k block); N48 = columns rounded up to whole 192-column tiles: columns beyond Np are written as zeros
+__global__ void mx_pack_w_kernel(const uint16_t* __restrict__ W, int ldw, int Np, int N48, int Kp, uint16_t* __restrict__ WH, unsigned char* __restrict__ WX) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nq = Kp / 32;
+  if (idx >= (long long)N48 * nq) return;
+  const int n = (int)(idx / nq), q = (int)(idx - (long long)n * nq);
+  const int jb = n / 48, j = (n - 48 * jb) >> 4, r16 = n & 15, b = q >> 2, g = q & 3, lane = g * 16 + r16, nb = Kp / 128;
+  h32 hv, lv;
+  unsigned mh = 0, ml = 0;
+  uint4 hraw[4] = {};
+  if (n < Np) {
+    const uint16_t* src = W + (size_t)n * ldw + (size_t)q * 64;      // 4 PS groups of [hi 8 | lo 8]
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      hraw[t] = *reinterpret_cast<const uint4*>(src + 16 * t);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint16_t hb = src[16 * t + e], lb = src[16 * t + 8 + e];
+        hv[8 * t + e] = __builtin_bit_cast(_Float16, hb);
+        lv[8 * t + e] = __builtin_bit_cast(_Float16, lb);
+        mh = max(mh, (unsigned)(hb & 0x7fff)); ml = max(ml, (unsigned)(lb & 0x7fff));
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 32; ++e) { hv[e] = (_Float16)0.f; lv[e] = (_Float16)0.f; }
+  }
+  // both images scaled so that the block's largest magnitude lands in [4, 8): the weights are packed once, so lo gets its own exponent
+  int eh = (int)(mh >> 10), el = (int)(ml >> 10);
+  eh = eh < 1 ? 1 : eh; el = el < 1 ? 1 : el;
+  const int sh = eh + 110, sl = el + 110;      // E - 2 + 127, E = ef - 15
+  const u32x6 h6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(hv, e8m0_float(sh));
+  const u32x6 l6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(lv, e8m0_float(sl));
+  const size_t blk = (size_t)jb * nb + b;
+  unsigned char* wh = reinterpret_cast<unsigned char*>(WH) + blk * kMxWhBytes + j * 1024 + lane * 16;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) *reinterpret_cast<uint4*>(wh + t * 3072) = hraw[t];
+  unsigned char* wx = WX + blk * kMxWxBytes;
+  *reinterpret_cast<uint2*>(wx + kWxL6b + j * 512 + lane * 8) = uint2{l6[4], l6[5]};
+  *reinterpret_cast<uint4*>(wx + kWxL6a + j * 1024 + lane * 16) = uint4{l6[0], l6[1], l6[2], l6[3]};
+  *reinterpret_cast<uint2*>(wx + kWxH6b + j * 512 + lane * 8) = uint2{h6[4], h6[5]};
+  *reinterpret_cast<uint4*>(wx + kWxH6a + j * 1024 + lane * 16) = uint4{h6[0], h6[1], h6[2], h6[3]};
+  *reinterpret_cast<uint16_t*>(wx + kWxSc + lane * 8 + j * 2) = (uint16_t)((unsigned)sl | ((unsigned)sh << 8));
+  if (j == 2) *reinterpret_cast<uint16_t*>(wx + kWxSc + lane * 8 + 6) = 0;
+}
+void launch_mx_pack_w(const uint16_t* W, int ldw, int Np, int Kp, uint16_t* WH, unsigned char* WX, hipStream_t s) {
+  const int N48 = (Np + 191) / 192 * 192;
+  const long long total = (long long)N48 * (Kp / 32);
+  hipLaunchKernelGGL(mx_pack_w_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W, ldw, Np, N48, Kp, WH, WX);
+}
+
+// packed-split activation rows [M][2 Kp] -> the three MX3 planes (Kp128 = Kp rounded up to 128: the pad reads as zeros).  The reference
+// producer of the format: tests compare the fused producers with it, and operands no kernel emits in MX3 yet go through it.
+__global__ void mx_pack_act_kernel(const uint16_t* __restrict__ ps, int ldps, int M, int Kp, int Kp128, uint16_t* __restrict__ hi,
+                                   unsigned char* __restrict__ l8, unsigned char* __restrict__ sc) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nq = Kp128 / 32;
+  if (idx >= (long long)M * nq) return;
+  const int m = (int)(idx / nq), q = (int)(idx - (long long)m * nq);
+  uint4 hv[4] = {}, lv[4] = {};
+  if (32 * q < Kp) {
+    const uint4* src = reinterpret_cast<const uint4*>(ps + (size_t)m * ldps + (size_t)q * 64);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { hv[t] = src[2 * t]; lv[t] = src[2 * t + 1]; }
+  }
+  unsigned mh = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const unsigned w[4] = {hv[t].x, hv[t].y, hv[t].z, hv[t].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mh = max(mh, max(w[e] & 0x7fffu, (w[e] >> 16) & 0x7fffu));
+  }
+  const int sl = mx_sl_byte((int)(mh >> 10));
+  const float scale = e8m0_float(sl);
+  uint16_t* hrow = hi + (size_t)m * Kp128 + (q >> 2) * 128 + (q & 3) * 8;      // + 32 t: mx_hi_pos of column 32 q + 8 t
+  unsigned out8[8];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    *reinterpret_cast<uint4*>(hrow + 32 * t) = hv[t];
+    const unsigned w[4] = {lv[t].x, lv[t].y, lv[t].z, lv[t].w};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const f32x2 a = unpack_f16(w[2 * e]), b = unpack_f16(w[2 * e + 1]);
+      s16x2 r = {0, 0};
+      r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, a[0], a[1], scale, false);
+      r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, b[0], b[1], scale, true);
+      out8[2 * t + e] = __builtin_bit_cast(unsigned, r);
+    }
+  }
+  uint4* lrow = reinterpret_cast<uint4*>(l8 + (size_t)m * Kp128 + 32 * q);
+  lrow[0] = uint4{out8[0], out8[1], out8[2], out8[3]};
+  lrow[1] = uint4{out8[4], out8[5], out8[6], out8[7]};
+  sc[(size_t)m * nq + q] = (unsigned char)sl;
+}
+void launch_mx_pack_act(const uint16_t* ps, int ldps, int M, int Kp, const MxAct& a, hipStream_t s) {
+  const long long total = (long long)M * (a.Kp / 32);
+  hipLaunchKernelGGL(mx_pack_act_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ps, ldps, M, Kp, a.Kp, a.hi, a.l8, a.sc);
+}
+
+// ----------------------------------------------------------------------------------------------------------- kernel
+namespace {
+constexpr int MX_BM = 128, MX_BN = 192, MX_MT = 8, MX_TN = 3;
+// LDS map: the fp6 rows sit right behind the hi slots so that one per-lane address register (plus instruction offsets < 64 KB) reaches both
+constexpr int L_HI = 0, L_H6A = 32768, L_H6B = 40960, L_SC = 45056, L_SC_SLOT = 640, L_L8 = L_SC + 2 * L_SC_SLOT, L_TOTAL = L_L8 + 32768;
+static_assert(L_L8 % 16 == 0, "LDS-DMA destination alignment");
+__device__ __forceinline__ int mx_f4(int row) { return (4 - ((row >> 2) & 3)) & 3; }      // chunk swizzle of the 64-byte hi rows
+// chunk swizzle of the 128-byte lo rows: an fp8 operand's lane (row, g) holds k = 16 g .. + 15 and 64 + 16 g .. + 15 (tools/mx_kmap_probe.hip:
+// NOT the 32 consecutive k of the fp6 formats; the block scales follow the logical k), i.e. chunks g and g + 4 of the row -- with this
+// swizzle every ds_read_b128 lane group touches 16 distinct 16-byte slots for both
+__device__ __forceinline__ int mx_f8(int row) { return (row >> 1) & 7; }
+}  // namespace
+
+// ABL (diagnostic library only): 1 = no epilogue (results dropped)
+template <class Epi, int ABL>
+__global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint16_t* __restrict__ WH, const unsigned char* __restrict__ WX, int M, int nb,
+                                                              int mtiles, int ntiles, Epi epi) {
+  static_assert(is_zk<Epi>::value, "the residual-through-the-ring epilogue");
+  constexpr int MT = MX_MT, TN = MX_TN, BM = MX_BM, BN = MX_BN, ZS = BN / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nblk = mtiles * ntiles;
+  int bid = blockIdx.x;
+  {
+    // blocks b, b + 8, ... run on one XCD (one L2): XCD x walks a contiguous tile range with n fastest (as gemm_duo.hip)
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    bid = first + loc;
+  }
+  const int mt = bid / ntiles, nt = bid - mt * ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int rows_here = (M - m0) < BM ? (M - m0) : BM;
+  const int Kp = A.Kp;
+
+  // ---- descriptors over the tile's rows of the three planes (rows beyond M read as zeros) and of the residual stream
+  const __amdgpu_buffer_rsrc_t hi_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.hi + (size_t)m0 * Kp, 0, rows_here * Kp * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t l8_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.l8 + (size_t)m0 * Kp, 0, rows_here * Kp, 0x00020000);
+  const __amdgpu_buffer_rsrc_t sc_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.sc + (size_t)m0 * (Kp >> 5), 0, rows_here * (Kp >> 5), 0x00020000);
+  // (a copy: naming epi inside a lambda that a generic lambda calls makes hipcc drop the kernel's HOST stub without a diagnostic -- the library
+  // then fails to load with an undefined symbol)
+  const int ldz_ = epi.ldz;
+  int hi_voff, l8_voff, sc_voff;
+  {
+    const int hrow = wave * 32 + (lane >> 2);                      // + 16 for the wave's second instruction (same swizzle)
+    hi_voff = hrow * Kp * 2 + (((lane & 3) ^ mx_f4(hrow)) << 4);
+    const int drow = wave * 8 + (lane >> 3);                       // + 32 i for the wave's other groups (same swizzle)
+    l8_voff = drow * Kp + (((lane & 7) ^ mx_f8(drow)) << 4);
+    sc_voff = (wave * 32 + lane) * (Kp >> 5);
+  }
+  auto issue_hi = [&](int b) {      // the four hi units of step b: 8 operations per wave
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(hi_rsrc, (__attribute__((address_space(3))) void*)(smem + L_HI + s * 8192 + wave * 2048 + u * 1024), 16,
+                                                 hi_voff, u * 16 * Kp * 2 + b * 256 + s * 64, 0, 0);
+  };
+  auto issue_l8 = [&](int b) {      // lo unit + scale unit of step b: 5 operations per wave
+    char* st = smem + L_L8 + (b & 1) * 16384 + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(l8_rsrc, (__attribute__((address_space(3))) void*)(st + i * 4096), 16, l8_voff, i * 32 * Kp + b * 128, 0, 0);
+    // 64 rows per wave from row 32 w: the upper half repeats what the next wave writes (the same bytes) and the last wave's spills into the slot's pad
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(sc_rsrc, (__attribute__((address_space(3))) void*)(smem + L_SC + (b & 1) * L_SC_SLOT + wave * 128), 4, sc_voff,
+                                             b * 4, 0, 0);
+  };
+  auto issue_z = [&](int t, int slot_off) {      // 32 columns of the residual tile (packed-split: 128 bytes per row): 4 operations per wave
+    char* st = smem + slot_off + wave * 1024;
+    const int ko = n0 * 4 + t * 128;
+    const __amdgpu_buffer_rsrc_t z_rsrc = zk_rsrc(epi, m0, rows_here, hi_rsrc);
+    const int drow = wave * 8 + (lane >> 3);
+    const int z_voff = drow * ldz_ * 2 + (((lane & 7) ^ swz_f(drow)) << 4);      // (recomputed: not worth a register across the K loop)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(z_rsrc, (__attribute__((address_space(3))) void*)(st + i * 4096), 16, z_voff, i * 32 * ldz_ * 2 + ko, 0, 2);
+  };
+
+  // ---- W: the wave's three column tiles; hi fragments stream through three register sets, the fp6 images are single-buffered
+  const int wn = wave;
+  const unsigned wvoff16 = (unsigned)lane * 16u, wvoff8 = (unsigned)lane * 8u;
+  const size_t jb = (size_t)(n0 / 48) + (size_t)wn;
+  const char* whb = reinterpret_cast<const char*>(WH) + jb * (size_t)nb * kMxWhBytes;
+  const char* wxb = reinterpret_cast<const char*>(WX) + jb * (size_t)nb * kMxWxBytes;
+  f16x8 whi[3][TN];
+  u32v4 wl6a[TN], wh6a[TN];
+  u32v2 wl6b[TN], wh6b[TN];
+  u32v2 wsc;      // bytes: sl0 sh0 sl1 sh1 | sl2 sh2 - -
+  auto issue_whi = [&](int t, f16x8 (&dst)[TN]) {      // sub-step t = 4 b + s of the K loop: 3 operations
+    const unsigned long long p = uniform_ptr(whb + (size_t)t * 3072);
+    gld16h<0>(dst[0], wvoff16, p);
+    gld16h<1024>(dst[1], wvoff16, p);
+    gld16h<2048>(dst[2], wvoff16, p);
+  };
+  auto issue_wx = [&](int b) {                          // 13 operations
+    const unsigned long long p = uniform_ptr(wxb + (size_t)b * kMxWxBytes), p2 = uniform_ptr(wxb + (size_t)b * kMxWxBytes + kWxH6a);
+    gld8<kWxL6b>(wl6b[0], wvoff8, p); gld8<kWxL6b + 512>(wl6b[1], wvoff8, p); gld8<kWxL6b + 1024>(wl6b[2], wvoff8, p);
+    gld16<kWxL6a>(wl6a[0], wvoff16, p); gld16<kWxL6a + 1024>(wl6a[1], wvoff16, p); gld16<kWxL6a + 2048>(wl6a[2], wvoff16, p);
+    gld8<kWxH6b - kWxH6a>(wh6b[0], wvoff8, p2); gld8<kWxH6b - kWxH6a + 512>(wh6b[1], wvoff8, p2); gld8<kWxH6b - kWxH6a + 1024>(wh6b[2], wvoff8, p2);
+    gld16<0>(wh6a[0], wvoff16, p2); gld16<1024>(wh6a[1], wvoff16, p2); gld16<2048>(wh6a[2], wvoff16, p2);
+    gld8<kWxSc - kWxH6a>(wsc, wvoff8, p2);
+  };
+  constexpr int NWX = 13;
+
+  f32x4 acc[1][MT][TN];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[0][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  // per-lane read addresses (row tile i adds 16 rows)
+  const unsigned rd_hi = lds_base + L_HI + (unsigned)(r16 * 64 + ((g ^ mx_f4(r16)) << 4));                 // + 1024 i + 8192 s
+  const unsigned rd_l8 = lds_base + (unsigned)(r16 * 128 + ((g ^ mx_f8(r16)) << 4));      // 128-byte lo rows: + 2048 i + slot; chunk g + 4 at ^ 64
+  const unsigned rd_h6b = lds_base + L_H6B + (unsigned)(r16 * 32 + ((g ^ (2 * ((r16 >> 3) & 1))) << 3));  // + 512 i
+  const unsigned rd_sc = lds_base + L_SC + (unsigned)(r16 * 4 + g);                                        // + 64 i + slot
+
+  // ---- prologue
+  issue_whi(0, whi[0]);
+  issue_whi(1, whi[1]);
+  issue_l8(0);
+  issue_hi(0);
+  issue_wx(0);
+
+  // one 128-deep step; P = b % 3 fixes the W register sets of its sub-steps ((4 b + s) % 3 = (b + s) % 3)
+  auto step = [&](auto p_c, int b) {
+    constexpr int P = decltype(p_c)::value;
+    const bool more = b + 1 < nb;
+    // B1: hi units, lo / scale unit and the first two W hi sets of this step have landed (only the 13 operations of W's fp6 images are younger)
+    wait_vmcnt<NWX>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    sfor<4>([&](auto s_c) {
+      constexpr int S = decltype(s_c)::value;
+      constexpr int SW = (P + S) % 3;
+      if constexpr (S == 2) wait_vmcnt<3>();                        // W hi of sub-step 2 (issued at sub-step 0); sub-step 3's may fly
+      if constexpr (S == 3) { if (more) wait_vmcnt<3>(); else wait_vmcnt<0>(); }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(whi[SW][j]));
+      // W hi two sub-steps ahead
+      if constexpr (S < 2) issue_whi(4 * b + S + 2, whi[(SW + 2) % 3]);
+      else if (more) issue_whi(4 * b + S + 2, whi[(SW + 2) % 3]);
+      __builtin_amdgcn_sched_barrier(0);
+      f16x8 ah[2];
+      lds_rd128h<S * 8192>(ah[0], rd_hi);
+      sfor<MT>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int cur = i & 1, nxt = cur ^ 1;
+        if constexpr (i + 1 < MT) {
+          lds_rd128h<S * 8192 + (i + 1) * 1024>(ah[nxt], rd_hi);
+          asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(ah[cur])::"memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[cur])::"memory");
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[0][i][j] = mfma_f16(whi[SW][j], ah[cur], acc[0][i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      pin_acc(acc);
+    });
+    // the next step's lo and scale units (their slot was last read in the MX phase of step b - 1, which every wave left before B1)
+    if (more) issue_l8(b + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef MXDBG_NOCONV
+    // ---- conversion: this wave turns the hi rows of row tiles 2 w, 2 w + 1 into fp6 for everybody
+    {
+      const unsigned cv_hi = rd_hi + (unsigned)(wave * 2048), cv_sc = rd_sc + (unsigned)(wave * 128 + (b & 1) * L_SC_SLOT);
+      const unsigned cv_b = rd_h6b + (unsigned)(wave * 1024);
+      sfor<2>([&](auto u_c) {
+        constexpr int U = decltype(u_c)::value;
+        f16x8 h[4];
+        unsigned sb;
+        lds_rd128h<U * 1024>(h[0], cv_hi);
+        lds_rd128h<U * 1024 + 8192>(h[1], cv_hi);
+        lds_rd128h<U * 1024 + 16384>(h[2], cv_hi);
+        lds_rd128h<U * 1024 + 24576>(h[3], cv_hi);
+        lds_rd8<U * 64>(sb, cv_sc);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(sb)::"memory");
+        h32 hv;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) hv[8 * s + e] = h[s][e];
+        const u32x6 c = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(hv, e8m0_float((int)sb + kMxShDelta));
+        lds_wr128<L_H6A + U * 1024>(cv_hi, u32v4{c[0], c[1], c[2], c[3]});
+        lds_wr64<U * 512>(cv_b, u32v2{c[4], c[5]});
+      });
+    }
+#endif
+    // B2: fp6 rows visible to every wave, hi slots free
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (more) {
+      issue_hi(b + 1);
+    } else {
+      // the residual tile's first three 32-column units: two into the hi slots, one into the lo slot of the other parity
+      issue_z(0, L_HI);
+      issue_z(1, L_HI + 16384);
+      issue_z(2, L_L8 + ((b + 1) & 1) * 16384);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- MX phase
+#ifndef MXDBG_NOMX
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(wl6a[j]), "+v"(wl6b[j]), "+v"(wh6a[j]), "+v"(wh6b[j]));
+    asm volatile("" : "+v"(wsc));
+    i32x8 wl6[TN], wh6[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { wl6[j] = op6(wl6a[j], wl6b[j]); wh6[j] = op6(wh6a[j], wh6b[j]); }
+    {
+      const unsigned m_l8a = rd_l8 + (unsigned)(L_L8 + (b & 1) * 16384), m_l8b = m_l8a ^ 64u;
+      const unsigned m_sc = rd_sc + (unsigned)((b & 1) * L_SC_SLOT);
+      u32v4 la[2], lb[2], ha[2];
+      u32v2 hb[2];
+      unsigned sb[2];
+      lds_rd128<0>(la[0], m_l8a); lds_rd128<0>(lb[0], m_l8b); lds_rd128<L_H6A>(ha[0], rd_hi); lds_rd64<0>(hb[0], rd_h6b); lds_rd8<0>(sb[0], m_sc);
+      sfor<MT>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int cur = i & 1, nxt = cur ^ 1;
+        if constexpr (i + 1 < MT) {
+          lds_rd128<(i + 1) * 2048>(la[nxt], m_l8a); lds_rd128<(i + 1) * 2048>(lb[nxt], m_l8b);
+          lds_rd128<L_H6A + (i + 1) * 1024>(ha[nxt], rd_hi); lds_rd64<(i + 1) * 512>(hb[nxt], rd_h6b); lds_rd8<(i + 1) * 64>(sb[nxt], m_sc);
+          asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(la[cur]), "+v"(lb[cur]), "+v"(ha[cur]), "+v"(hb[cur]), "+v"(sb[cur])::"memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(la[cur]), "+v"(lb[cur]), "+v"(ha[cur]), "+v"(hb[cur]), "+v"(sb[cur])::"memory");
+        }
+        const i32x8 al8 = op8(la[cur], lb[cur]), ah6 = op6(ha[cur], hb[cur]);
+        const int asc = (int)(sb[cur] | ((sb[cur] + kMxShDelta) << 8));      // byte 0: lo scale, byte 1: fp6-hi scale
+        // W hi' (fp6, its sh byte) x A lo (fp8, byte 0);  W lo' (fp6, its sl byte) x A hi' (fp6, byte 1)
+        acc[0][i][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wh6[0], al8, acc[0][i][0], 2, 0, 1, (int)wsc[0], 0, asc);
+        acc[0][i][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wh6[1], al8, acc[0][i][1], 2, 0, 3, (int)wsc[0], 0, asc);
+        acc[0][i][2] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wh6[2], al8, acc[0][i][2], 2, 0, 1, (int)wsc[1], 0, asc);
+        acc[0][i][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wl6[0], ah6, acc[0][i][0], 2, 2, 0, (int)wsc[0], 1, asc);
+        acc[0][i][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wl6[1], ah6, acc[0][i][1], 2, 2, 2, (int)wsc[0], 1, asc);
+        acc[0][i][2] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wl6[2], ah6, acc[0][i][2], 2, 2, 0, (int)wsc[1], 1, asc);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+    pin_acc(acc);
+#endif
+    if (more) issue_wx(b + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  int b = 0;
+  for (; b + 3 <= nb; b += 3) {
+    step(std::integral_constant<int, 0>{}, b);
+    step(std::integral_constant<int, 1>{}, b + 1);
+    step(std::integral_constant<int, 2>{}, b + 2);
+  }
+  if (b < nb) step(std::integral_constant<int, 0>{}, b);
+  if (b + 1 < nb) step(std::integral_constant<int, 1>{}, b + 1);
+
+  // everything the epilogue needs from memory: requested behind the last operand batch, in front of the residual units, whose six
+  // barriers cover the round trip (20 registers that the K loop does not have to carry)
+  float4 zb4[TN];
+  float zpm[MT];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * (16 * TN) + 16 * j + 4 * g;
+    zb4[j] = n < epi.N ? *reinterpret_cast<const float4*>(epi.bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + 16 * i + r16;
+    zpm[i] = (epi.prev != nullptr && m < M) ? epi.prev[(size_t)m * epi.prev_stride].y : 0.f;
+  }
+#ifndef MXDBG_NOZ
+  // ---- the residual tile: unit t holds columns n0 + 32 t .. + 31 of the stored rows (gemm_duo.hip, EpiResidZK)
+  {
+    const int last = nb - 1;
+    const unsigned rd_ps_hi = lds_base + (unsigned)lds_off(r16, 2 * g);      // packed-split rows: hi chunk 2 g, lo chunk at ^ 16
+    const int zslot[4] = {L_HI, L_HI + 16384, L_L8 + ((last + 1) & 1) * 16384, L_L8 + (last & 1) * 16384};
+    const int p8 = r16 & 7;
+    const unsigned one = (p8 & 1) ? 0x3C000000u : 0x00003C00u;
+    const u32x4 pat = {(p8 >> 1) == 0 ? one : 0u, (p8 >> 1) == 1 ? one : 0u, (p8 >> 1) == 2 ? one : 0u, (p8 >> 1) == 3 ? one : 0u};
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    const f16x8 id0 = __builtin_bit_cast(f16x8, g == (r16 >> 3) ? pat : zero4), id16 = __builtin_bit_cast(f16x8, g == 2 + (r16 >> 3) ? pat : zero4);
+    int zsel[TN];
+    f16x8 idj[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int c0 = wn * (16 * TN) + 16 * j;
+      zsel[j] = n0 + c0 < epi.N ? (c0 >> 5) : -1;
+      idj[j] = (c0 & 16) ? id16 : id0;
+    }
+    sfor<ZS>([&](auto t_c) {
+      constexpr int t = decltype(t_c)::value;
+      constexpr int younger = (ZS - 1 - t) < 2 ? (ZS - 1 - t) : 2;      // units requested behind unit t
+      wait_vmcnt<4 * younger>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if constexpr (t + 3 < ZS) issue_z(t + 3, zslot[(t + 3) & 3]);
+      __builtin_amdgcn_sched_barrier(0);
+      bool mine = false;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) mine = mine || zsel[j] == t;
+      if (mine) {      // wave-uniform
+        const unsigned a_hi_s = rd_ps_hi + (unsigned)zslot[t & 3], a_lo_s = a_hi_s ^ 16u;
+        f16x8 ah[2], al[2];
+        lds_rd128h<0>(ah[0], a_hi_s);
+        lds_rd128h<0>(al[0], a_lo_s);
+        sfor<MT>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          constexpr int cur = i & 1, nxt = cur ^ 1;
+          if constexpr (i + 1 < MT) {
+            lds_rd128h<(i + 1) * 2048>(ah[nxt], a_hi_s);
+            lds_rd128h<(i + 1) * 2048>(al[nxt], a_lo_s);
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[cur]), "+v"(al[cur])::"memory");
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[cur]), "+v"(al[cur])::"memory");
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            if (zsel[j] == t) {
+              acc[0][i][j] = mfma_f16(idj[j], al[cur], acc[0][i][j]);
+              acc[0][i][j] = mfma_f16(idj[j], ah[cur], acc[0][i][j]);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+    });
+  }
+
+#endif
+  if (ABL & 1) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[0][i][j]));
+    return;
+  }
+  const int mbase = m0 + r16, nbase = n0 + wn * (16 * TN) + 4 * g;
+  if (n0 + wn * (16 * TN) >= epi.N) return;
+  const int blk = nt * 4 + wn;
+  if (m0 + BM <= M) resid_zk_epilogue<TN, MT, MT, true>(epi, mbase, nbase, blk, g, acc, zb4, zpm);
+  else resid_zk_epilogue<TN, MT, MT, false>(epi, mbase, nbase, blk, g, acc, zb4, zpm);
+}
+
+// ----------------------------------------------------------------------------------------------------------- host side
+bool gemm_mx_supported(int N, int Kp) { return N % 48 == 0 && N % 8 == 0 && Kp % 128 == 0 && Kp >= 128; }
+
+template <class Epi, int ABL>
+static void launch_mx_impl(const MxAct& A, const MxWeight& W, int M, int N, const Epi& epi, hipStream_t s) {
+  const int mtiles = (M + MX_BM - 1) / MX_BM, ntiles = (N + MX_BN - 1) / MX_BN;
+  const int nb = A.Kp / 128;
+  void (*kernel)(MxAct, const uint16_t*, const unsigned char*, int, int, int, int, Epi) = gemm_mx_duo_kernel<Epi, ABL>;
+  static bool attr_set = false;      // (one process per GPU: see launch_duo_impl)
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL);
+    attr_set = true;
+  }
+  kernel<<<dim3(mtiles * ntiles), dim3(256), L_TOTAL, s>>>(A, W.wh, W.wx, M, nb, mtiles, ntiles, epi);
+}
+
+// z (packed-split) = (z - prev mean) + A W^T + bias with A in MX3, W in the mx_pack_w image; statistics per 48-column wave block
+ResidStatGeom launch_gemm_mx_resid(const MxAct& A, const MxWeight& W, int M, int N, const float* bias, uint16_t* z, int ldz, float2* part, const float2* prev,
+                                   int prev_stride, hipStream_t s, int abl) {
+  const EpiResidZK epi{z, ldz, bias, M, N, part, prev, prev_stride};
+#ifdef RIBCA_DIAG
+  if (abl == 1) { launch_mx_impl<EpiResidZK, 1>(A, W, M, N, epi, s); return ResidStatGeom{N / 48, 48}; }
+#endif
+  (void)abl;
+  launch_mx_impl<EpiResidZK, 0>(A, W, M, N, epi, s);
+  return ResidStatGeom{N / 48, 48};
+}
+
+}  // namespace ribca

@@ -879,6 +879,33 @@ int ribca_test_gemm_resid_ps_duo(const uint16_t* A, int32_t lda, const uint16_t*
   HIP_TRY(hipGetLastError());
   return 0;
 }
+int64_t ribca_test_mx_weight_bytes(int32_t N, int32_t Kp, int32_t which) {
+  const int Np = (N + 15) / 16 * 16;
+  return (int64_t)(which == 0 ? mx_wh_bytes(Np, Kp) : mx_wx_bytes(Np, Kp));
+}
+int ribca_test_mx_pack_act(const uint16_t* A, int32_t lda, int32_t M, int32_t Kp, uint16_t* hi_out, uint8_t* l8_out, uint8_t* sc_out, void* stream) {
+  if (!A || !hi_out || !l8_out || !sc_out) return fail("ribca_test_mx_pack_act: NULL buffer");
+  if (Kp % 32 != 0) return fail("ribca_test_mx_pack_act: Kp must be a multiple of 32");
+  const MxAct a{hi_out, l8_out, sc_out, round_up(Kp, 128)};
+  launch_mx_pack_act(A, lda, M, Kp, a, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int ribca_test_gemm_mx_resid(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp, const float* bias,
+                             uint16_t* hi_out, uint8_t* l8_out, uint8_t* sc_out, uint16_t* wh_scratch, uint8_t* wx_scratch, uint16_t* z_ps,
+                             int32_t ldz, float* part, float* rowstat, const float* prev, void* stream) {
+  if (!gemm_mx_supported(N, Kp)) return fail("ribca_test_gemm_mx_resid: N must be a multiple of 48 and Kp of 128");
+  if ((rowstat != nullptr) != (part != nullptr)) return fail("ribca_test_gemm_mx_resid: part and rowstat go together");
+  hipStream_t s = (hipStream_t)stream;
+  const MxAct a{hi_out, l8_out, sc_out, Kp};
+  launch_mx_pack_act(A, lda, M, Kp, a, s);
+  launch_mx_pack_w(W, ldw, (N + 15) / 16 * 16, Kp, wh_scratch, wx_scratch, s);
+  const MxWeight w{wh_scratch, wx_scratch};
+  const ResidStatGeom sg = launch_gemm_mx_resid(a, w, M, N, bias, z_ps, ldz, reinterpret_cast<float2*>(part), reinterpret_cast<const float2*>(prev), 1, s);
+  if (rowstat) launch_ln_finalize(reinterpret_cast<const float2*>(part), sg.tiles, M, sg.bn, N, reinterpret_cast<float2*>(rowstat), s);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
 int ribca_test_gemm_fold(int32_t kind, const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
                          const float* bias2, const float* csum, const float* rowstat, void* out, int32_t ldo, void* stream) {
   if (kind != 1) return fail("ribca_test_gemm_fold: kind must be 1");

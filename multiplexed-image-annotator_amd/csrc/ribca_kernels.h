@@ -64,6 +64,21 @@ void launch_gemm_qkv_ln(const GemmArgs& g, const float2* rowstat, const float* c
 void launch_gemm_rowmap(const GemmArgs& g, float* out, int ldo, const float* add, int ldadd, const int* slot, const int* addrow, int R,
                         int dst_per_cell, hipStream_t s);
 
+// ----- MX GEMM (gemm_mx.hip): fp16 hi * hi + two block-scaled correction products; activations in the three-plane "MX3" format
+// (hi fp16 permuted inside every 128 columns, lo as e4m3 bytes, one E8M0 scale byte per 32 columns -- see gemm_mx.hip), Kp % 128 == 0
+struct MxAct { uint16_t* hi; unsigned char* l8; unsigned char* sc; int Kp; };
+struct MxWeight { const uint16_t* wh; const unsigned char* wx; };     // mx_pack_w image of a packed-split weight [Np][2 Kp]
+size_t mx_wh_bytes(int Np, int Kp);
+size_t mx_wx_bytes(int Np, int Kp);
+inline size_t mx_act_hi_elems(size_t M, int Kp128) { return M * (size_t)Kp128; }          // fp16 elements; l8: the same count of bytes; sc: / 32
+void launch_mx_pack_w(const uint16_t* W, int ldw, int Np, int Kp, uint16_t* WH, unsigned char* WX, hipStream_t s);
+// packed-split rows [M][2 Kp] -> MX3 (a.Kp = Kp rounded up to 128): the reference producer of the format
+void launch_mx_pack_act(const uint16_t* ps, int ldps, int M, int Kp, const MxAct& a, hipStream_t s);
+bool gemm_mx_supported(int N, int Kp);
+// z_ps = (z_ps - prev mean) + A W^T + bias, statistics per 48-column wave block (as launch_gemm_resid_ps on the duo kernel)
+ResidStatGeom launch_gemm_mx_resid(const MxAct& A, const MxWeight& W, int M, int N, const float* bias, uint16_t* z, int ldz, float2* part,
+                                   const float2* prev, int prev_stride, hipStream_t s, int abl = 0);
+
 // ----- attention (attention.hip) ---------------------------------------------------------------------------
 // q,k: [cells][H][TP][2*hdq]  vt: V operand, layout per attention_v_rowmajor()  out: packed-split [cells*T][ldo]
 // q_tiles > 0 restricts the QUERY rows to the first q_tiles 16-token tiles (keys/values are always complete)

@@ -12,7 +12,7 @@ import pytest
 from multiplexed_image_annotator_amd import build as B
 
 
-@pytest.mark.parametrize("src", ["gemm_duo.hip", "gemm_split16.hip", "cell_attention.hip", "attention.hip"])
+@pytest.mark.parametrize("src", ["gemm_duo.hip", "gemm_mx.hip", "gemm_split16.hip", "cell_attention.hip", "attention.hip"])
 def test_no_spills_no_scratch(src, tmp_path):
     cmd = [B._hipcc()] + B.FLAGS + ["--cuda-device-only", "-c", os.path.join(B.CSRC, src), "-o", str(tmp_path / "x.o"),
                                     "-Rpass-analysis=kernel-resource-usage"]

@@ -72,9 +72,10 @@ static int floor_log2(double a) { int e; frexp(a, &e); return e - 1; }   // a > 
 // scale word per operand side: byte 0 = lo scale, byte 1 = h' scale (E8M0)
 struct LaneOps {
   h8 ah[2][4], wh[2][4];
-  i32x8 al8[2], wh8[2], wl6[2];
+  i32x8 al8[2], wh8[2], wl6[2], wh6[2];
   int a_sc[2], w_sc[2];
 };
+template <int MIXED>
 __global__ void scheme_kernel(const LaneOps* ops, f32x4* out, u32x6* h6_out) {
   const LaneOps o = ops[threadIdx.x];
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -92,7 +93,8 @@ __global__ void scheme_kernel(const LaneOps* ops, f32x4* out, u32x6* h6_out) {
     if (b == 0) h6_out[threadIdx.x] = h6;
     i32x8 ah6 = {(int)h6[0], (int)h6[1], (int)h6[2], (int)h6[3], (int)h6[4], (int)h6[5], 0, 0};
     // Term 2: W h' (fp8, scale byte 1 of w_sc) x A lo (fp8, scale byte 0 of a_sc)
-    acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(o.wh8[b], o.al8[b], acc, 0, 0, 1, o.w_sc[b], 0, o.a_sc[b]);
+    if (MIXED) acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(o.wh6[b], o.al8[b], acc, 2, 0, 2, o.w_sc[b], 0, o.a_sc[b]);      // W hi as fp6 (scale byte 2) x A lo fp8
+    else acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(o.wh8[b], o.al8[b], acc, 0, 0, 1, o.w_sc[b], 0, o.a_sc[b]);
     // Term 3: W lo (fp6, scale byte 0 of w_sc) x A h' (fp6, scale byte 1 of a_sc)
     acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(o.wl6[b], ah6, acc, 2, 2, 0, o.w_sc[b], 1, o.a_sc[b]);
   }
@@ -280,14 +282,14 @@ int main() {
     }
     std::vector<LaneOps> ops(64);
     // host emulation accumulators
-    std::vector<double> emu(16 * 16, 0.0), ref(16 * 16, 0.0), t1only(16 * 16, 0.0);
+    std::vector<double> emu(16 * 16, 0.0), ref(16 * 16, 0.0), t1only(16 * 16, 0.0), emu6(16 * 16, 0.0);
     std::vector<float> Ah(16 * K), Al(16 * K), Wh(16 * K), Wl(16 * K);
     for (int i = 0; i < 16 * K; ++i) {
       Ah[i] = f16_round(A[i]); Al[i] = A[i] - Ah[i];
       Wh[i] = f16_round(W[i]); Wl[i] = W[i] - Wh[i];
     }
     // dequantised correction operands for the emulation
-    std::vector<double> Al_q(16 * K), Ah_q(16 * K), Wl_q(16 * K), Wh_q(16 * K);
+    std::vector<double> Al_q(16 * K), Ah_q(16 * K), Wl_q(16 * K), Wh_q(16 * K), Wh6_q(16 * K);
     for (int l = 0; l < 64; ++l) {
       const int r = l & 15, g = l >> 4;
       LaneOps& o = ops[l];
@@ -307,8 +309,9 @@ int main() {
         // fp8 h' (W): max / 2^(E-7) in [128, 256) < 448
         const int a_sh = Ea - 2 + 127, a_sl = Ea - 19 + 127, w_sh = Ew - 7 + 127, w_sl = Ew - 13 + 127;
         o.a_sc[b] = (a_sl & 0xff) | ((a_sh & 0xff) << 8) | (0x55 << 16) | (0x66 << 24);
-        o.w_sc[b] = (w_sl & 0xff) | ((w_sh & 0xff) << 8) | (0x11 << 16) | (0x22 << 24);
-        unsigned al8[8] = {0}, wh8[8] = {0}, wl6[8] = {0};
+        const int w_sh6 = Ew - 2 + 127;
+        o.w_sc[b] = (w_sl & 0xff) | ((w_sh & 0xff) << 8) | ((w_sh6 & 0xff) << 16) | (0x22 << 24);
+        unsigned al8[8] = {0}, wh8[8] = {0}, wl6[8] = {0}, wh6[8] = {0};
         for (int f = 0; f < 32; ++f) {
           const int k = k0 + f;
           const int ca = e4m3_encode((double)Al[r * K + k] / ldexp(1.0, a_sl - 127));
@@ -322,26 +325,31 @@ int main() {
           wl6[bit >> 5] |= (unsigned)cl << (bit & 31);
           if ((bit & 31) > 26) wl6[(bit >> 5) + 1] |= (unsigned)cl >> (32 - (bit & 31));
           Wl_q[r * K + k] = e2m3_value(cl) * ldexp(1.0, w_sl - 127);
+          const int ch6 = e2m3_encode((double)Wh[r * K + k] / ldexp(1.0, w_sh6 - 127));
+          wh6[bit >> 5] |= (unsigned)ch6 << (bit & 31);
+          if ((bit & 31) > 26) wh6[(bit >> 5) + 1] |= (unsigned)ch6 >> (32 - (bit & 31));
+          Wh6_q[r * K + k] = e2m3_value(ch6) * ldexp(1.0, w_sh6 - 127);
           const int ch = e2m3_encode((double)Ah[r * K + k] / ldexp(1.0, a_sh - 127));
           Ah_q[r * K + k] = e2m3_value(ch) * ldexp(1.0, a_sh - 127);
         }
-        for (int e = 0; e < 8; ++e) { o.al8[b][e] = (int)al8[e]; o.wh8[b][e] = (int)wh8[e]; o.wl6[b][e] = (int)wl6[e]; }
+        for (int e = 0; e < 8; ++e) { o.al8[b][e] = (int)al8[e]; o.wh8[b][e] = (int)wh8[e]; o.wl6[b][e] = (int)wl6[e]; o.wh6[b][e] = (int)wh6[e]; }
       }
     }
     for (int n = 0; n < 16; ++n)
       for (int m = 0; m < 16; ++m) {
-        double e = 0, rr = 0, t1 = 0;
+        double e = 0, rr = 0, t1 = 0, e6 = 0;
         for (int k = 0; k < K; ++k) {
           e += (double)Wh[n * K + k] * Ah[m * K + k] + Wh_q[n * K + k] * Al_q[m * K + k] + Wl_q[n * K + k] * Ah_q[m * K + k];
           t1 += (double)Wh[n * K + k] * Ah[m * K + k];
+          e6 += (double)Wh[n * K + k] * Ah[m * K + k] + Wh6_q[n * K + k] * Al_q[m * K + k] + Wl_q[n * K + k] * Ah_q[m * K + k];
           rr += (double)W[n * K + k] * (double)A[m * K + k];
         }
-        emu[n * 16 + m] = e; ref[n * 16 + m] = rr; t1only[n * 16 + m] = t1;
+        emu[n * 16 + m] = e; ref[n * 16 + m] = rr; t1only[n * 16 + m] = t1; emu6[n * 16 + m] = e6;
       }
     LaneOps* dops; f32x4* dout; u32x6* dh6;
     CK(hipMalloc(&dops, 64 * sizeof(LaneOps))); CK(hipMalloc(&dout, 64 * sizeof(f32x4))); CK(hipMalloc(&dh6, 64 * sizeof(u32x6)));
     CK(hipMemcpy(dops, ops.data(), 64 * sizeof(LaneOps), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(scheme_kernel, dim3(1), dim3(64), 0, 0, dops, dout, dh6);
+    hipLaunchKernelGGL(scheme_kernel<0>, dim3(1), dim3(64), 0, 0, dops, dout, dh6);
     CK(hipDeviceSynchronize());
     std::vector<f32x4> hc(64);
     CK(hipMemcpy(hc.data(), dout, 64 * sizeof(f32x4), hipMemcpyDeviceToHost));
@@ -360,6 +368,18 @@ int main() {
     printf("   device vs host emulation of the same roundings : max abs %.3e  (fp32 summation noise expected, ~1e-6 x |ref|)\n", e_emu);
     printf("   device vs fp64 product                         : max abs %.3e  = %.3e of max |ref|\n", e_ref, e_ref / mag);
     printf("   hi*hi alone vs fp64 product                    : max abs %.3e  = %.3e of max |ref|\n", e_t1, e_t1 / mag);
+    // the kernel's own Term 2: W hi as fp6 (6 dwords) x A lo as fp8 (8 dwords) -- mixed operand formats
+    hipLaunchKernelGGL(scheme_kernel<1>, dim3(1), dim3(64), 0, 0, dops, dout, dh6);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(hc.data(), dout, 64 * sizeof(f32x4), hipMemcpyDeviceToHost));
+    double e_emu6 = 0, e_ref6 = 0;
+    for (int l = 0; l < 64; ++l)
+      for (int reg = 0; reg < 4; ++reg) {
+        const int m = l & 15, n = 4 * (l >> 4) + reg;
+        e_emu6 = fmax(e_emu6, fabs((double)hc[l][reg] - emu6[n * 16 + m]));
+        e_ref6 = fmax(e_ref6, fabs((double)hc[l][reg] - ref[n * 16 + m]));
+      }
+    printf("   mixed formats (W hi fp6 x A lo fp8): device vs its emulation max abs %.3e, vs fp64 %.3e = %.3e of max |ref|\n", e_emu6, e_ref6, e_ref6 / mag);
     CK(hipFree(dops)); CK(hipFree(dout)); CK(hipFree(dh6));
   }
   // ---------------------------------------------------------------- B
