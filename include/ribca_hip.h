@@ -213,6 +213,15 @@ int ribca_test_mx_pack_act(const uint16_t* A, int32_t lda, int32_t M, int32_t Kp
 int ribca_test_gemm_mx_resid(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp, const float* bias,
                              uint16_t* hi_out, uint8_t* l8_out, uint8_t* sc_out, uint16_t* wh_scratch, uint8_t* wx_scratch, uint16_t* z_ps,
                              int32_t ldz, float* part, float* rowstat, const float* prev, void* stream);
+/* the same GEMM on operands that are already in the MX formats (what the forward does; tools/bench_mx.py times it) */
+int ribca_test_gemm_mx_resid_packed(const uint16_t* hi, const uint8_t* l8, const uint8_t* sc, int32_t Kp, const uint16_t* wh, const uint8_t* wx,
+                                    int32_t M, int32_t N, const float* bias, uint16_t* z_ps, int32_t ldz, float* part, float* rowstat,
+                                    const float* prev, void* stream);
+/* mlp.fc1 with the LayerNorm fold writing its GELU output straight in the MX3 format (csrc/gemm_duo.hip, EpiGeluMx): N % 128 == 0,
+ * hi_out [M][N] fp16 (permuted inside every 128 columns), l8_out [M][N] bytes, sc_out [M][N / 32] bytes */
+int ribca_test_gemm_gelu_mx(const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp, const float* bias2,
+                            const float* csum, const float* rowstat, uint16_t* wf_scratch, uint16_t* hi_out, uint8_t* l8_out, uint8_t* sc_out,
+                            void* stream);
 int ribca_test_gemm_fold(int32_t kind, const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
                          const float* bias2, const float* csum, const float* rowstat, void* out, int32_t ldo, void* stream);
 int ribca_test_qkv_attention_fold(const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t cells, int32_t D, int32_t Kp,

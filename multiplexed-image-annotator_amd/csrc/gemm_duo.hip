@@ -457,6 +457,10 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
     const int blk = nt * WN + wn;
     if (m0 + BM <= M) resid_zk_epilogue<TN, MT, RB, true>(epi, mbase, nbase, blk, g, acc, zb4, zpm);
     else resid_zk_epilogue<TN, MT, RB, false>(epi, mbase, nbase, blk, g, acc, zb4, zpm);
+  } else if constexpr (is_mx_out<Epi>::value) {
+    static_assert(WM == 1 && TN == 2 && NB == 1, "the MX3-emitting GELU epilogue: 4 waves as 1 x 4 over a 128-wide tile");
+    if (m0 + BM <= M) gelu_mx_epilogue<MT, true>(epi, m0 + r16, n0 + wn * 32, g, acc);
+    else gelu_mx_epilogue<MT, false>(epi, m0 + r16, n0 + wn * 32, g, acc);
   } else if (m0 + BM <= M && n0 + BN <= epi.N && !(mode & 0x10)) {      // mode bit 4 (RIBCA_DUO_GUARDED=1): A/B switch, always the guarded form
 #pragma unroll
     for (int b = 0; b < NB; ++b) run_epilogue<TN, Epi, RB, true>(epi, mbase + 16 * RB * b, nbase, acc[b]);
@@ -599,6 +603,14 @@ bool launch_duo(const GemmArgs& g, const Epi& epi, hipStream_t s, int abl) {
 #endif
     return launch_duo_impl<192, 4, 2, 3, BN, Epi>(g, epi, s, abl);
   }
+}
+
+// mlp.fc1 (LayerNorm folded) writing its GELU output in the MX3 format of gemm_mx.hip: 192 x 128 tiles, 4 waves as 1 x 4 (one 32-column
+// block per wave and row).  N % 128 == 0 and a fragment-order weight are required.
+bool launch_gemm_gelu_mx(const GemmArgs& g, const float2* rowstat, const float* csum, const MxAct& out, hipStream_t s) {
+  if (g.N % 128 != 0 || g.WF == nullptr || out.Kp != g.N) return false;
+  const EpiGeluMx epi{out, g.bias, g.M, g.N, rowstat, csum, 1};
+  return launch_duo_impl<192, 4, 1, 3, 128, EpiGeluMx>(g, epi, s, 0);
 }
 
 #define RIBCA_DUO_INST(BN, EPI) template bool launch_duo<BN, EPI>(const GemmArgs&, const EPI&, hipStream_t, int);

@@ -367,6 +367,104 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, int mbase, int nbas
   }
 }
 
+// ---------------------------------------------------------------------------------------------- MX3 activation format (gemm_mx.hip)
+// exponent byte shared by the producers: ef = exponent field of the block's largest |hi| (fp16 bits)
+__device__ __host__ __forceinline__ int mx_sl_byte(int ef) { return (ef < 1 ? 1 : ef) + 93; }     // E - 19 + 127, E = max(ef, 1) - 15
+constexpr int kMxShDelta = 17;                                                                       // sh = sl + 17  (E - 2 + 127)
+__device__ __forceinline__ float e8m0_float(int byte) { return __builtin_bit_cast(float, (unsigned)byte << 23); }
+// position of logical column c in the permuted hi plane
+__device__ __host__ __forceinline__ int mx_hi_pos(int c) { return (c & ~127) | (((c >> 3) & 3) << 5) | (((c >> 5) & 3) << 3) | (c & 7); }
+
+// mlp.fc1 with the LayerNorm fold whose output IS the MX3 operand of the MX fc2 (gemm_mx.hip): gelu(rstd acc + (nm c + b')) written as
+// fp16 hi (permuted plane) + e4m3 lo + one scale byte per (row, 32 columns) -- 3 bytes per element instead of the 4 of the packed-split
+// form, and nothing left to convert in front of fc2.  Exists on the two-workgroups-per-CU kernel with 4 waves as 1 x 4 and 128-wide tiles
+// only (gemm_duo.hip): a wave then owns exactly ONE 32-column block of each of its rows, so the block's scale is a four-lane maximum.
+struct EpiGeluMx {
+  static constexpr bool kTouch = false, kFold = true, kMxOut = true;
+  MxAct out; const float* bias; int M, N;
+  const float2* rowstat; const float* csum; int rs_stride = 1;
+  struct Ctx {};
+  typedef LnRow RowS;
+};
+template <class Epi, class = void> struct is_mx_out : std::false_type {};
+template <class Epi> struct is_mx_out<Epi, std::enable_if_t<Epi::kMxOut>> : std::true_type {};
+
+// maximum over the four lanes (r16, g = 0 .. 3) that share an output row (see g4_sum below for the inline asm)
+__device__ __forceinline__ float g4_max(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  float c = fmaxf(a, b), d;
+  asm volatile("v_mov_b32 %0, %1\n\ts_nop 1\n\tv_permlane32_swap_b32 %1, %0\n\ts_nop 1" : "=&v"(d), "+v"(c));
+  return fmaxf(c, d);
+}
+typedef short mx_s16x2 __attribute__((ext_vector_type(2)));
+// acc: the wave's MT x 2 tiles (lane: row r16 of every row tile, columns 4 g .. 4 g + 3 of both column tiles); n32 = first column of the
+// wave's 32-column block.  IN: every row of the tile is inside M (N is a multiple of the tile width by construction).
+template <int MT, bool IN>
+__device__ __forceinline__ void gelu_mx_epilogue(const EpiGeluMx& epi, int mbase, int n32, int g, f32x4 (&acc)[1][MT][2]) {
+  const int nb0 = n32 + 4 * g;
+  float4 b4[2], c4[2];
+  LnRow rs[MT];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    b4[j] = *reinterpret_cast<const float4*>(epi.bias + nb0 + 16 * j);
+    c4[j] = *reinterpret_cast<const float4*>(epi.csum + nb0 + 16 * j);
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = mbase + 16 * i;
+    const float2 r = epi.rowstat[(size_t)(IN || m < epi.M ? m : epi.M - 1) * epi.rs_stride];
+    rs[i] = LnRow{r.x, -r.y * r.x};
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { settle(b4[j]); settle(c4[j]); }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) settle_row(rs[i]);
+  const int Kp = epi.out.Kp;
+  // this lane's store columns: the pair (g, g ^ 1) owns 8 consecutive columns of each column tile; the even lane stores tile 0's, the odd lane tile 1's
+  const int c8 = n32 + 16 * (g & 1) + 8 * (g >> 1);
+  const int hpos = mx_hi_pos(c8);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = mbase + 16 * i;
+    const bool ok = IN || m < epi.M;
+    float x[2][4];
+    float mx = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float4 f = ln_fold4<true>(acc[0][i][j], b4[j], c4[j], rs[i]);
+      const f32x2v u0 = gelu_erf2(f32x2v{f.x, f.y}), u1 = gelu_erf2(f32x2v{f.z, f.w});
+      x[j][0] = clamp_f16_range(u0.x); x[j][1] = clamp_f16_range(u0.y); x[j][2] = clamp_f16_range(u1.x); x[j][3] = clamp_f16_range(u1.y);
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(x[j][0]), fabsf(x[j][1])), fmaxf(fabsf(x[j][2]), fabsf(x[j][3]))));
+    }
+    mx = g4_max(mx);
+    // the block's exponent byte from fp16(max |x|) (rounding is monotone: the largest |hi| is the hi of the largest |x|)
+    const int ef = (int)(f16_bits(mx) >> 10);
+    const int sl = mx_sl_byte(ef);
+    const float scale = e8m0_float(sl);
+    uint2 hi[2];
+    unsigned l8[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      hi[j].x = cvt_pk_f16(x[j][0], x[j][1]);
+      hi[j].y = cvt_pk_f16(x[j][2], x[j][3]);
+      mx_s16x2 r = {0, 0};
+      r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, f32_minus_f16lo(x[j][0], hi[j].x), f32_minus_f16hi(x[j][1], hi[j].x), scale, false);
+      r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, f32_minus_f16lo(x[j][2], hi[j].y), f32_minus_f16hi(x[j][3], hi[j].y), scale, true);
+      l8[j] = __builtin_bit_cast(unsigned, r);
+    }
+    // even lane: its own 4 columns of tile 0 and the partner's; odd lane: the partner's 4 columns of tile 1 and its own
+    const auto rx = __builtin_amdgcn_permlane16_swap(hi[0].x, hi[1].x, false, false);
+    const auto ry = __builtin_amdgcn_permlane16_swap(hi[0].y, hi[1].y, false, false);
+    const auto rl = __builtin_amdgcn_permlane16_swap(l8[0], l8[1], false, false);
+    if (ok) {
+      *reinterpret_cast<u32x4*>(epi.out.hi + (size_t)m * Kp + hpos) = u32x4{rx[0], ry[0], rx[1], ry[1]};
+      *reinterpret_cast<uint2*>(epi.out.l8 + (size_t)m * Kp + c8) = uint2{rl[0], rl[1]};
+      if (g == 0) epi.out.sc[(size_t)m * (Kp >> 5) + (n32 >> 5)] = (unsigned char)sl;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- EpiResidZK pieces shared by gemm_duo.hip and gemm_mx.hip
 // ---- EpiResidZK (gemm_epi.h): descriptor over the residual tile's rows, the four-lane sum and the load-free epilogue
 template <class Epi>

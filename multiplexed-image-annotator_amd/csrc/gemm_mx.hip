@@ -62,14 +62,6 @@ __device__ __forceinline__ void sfor(F&& f) {
   sfor_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
-// exponent byte shared by the producers: ef = exponent field of the block's largest |hi| (fp16 bits)
-__device__ __host__ __forceinline__ int mx_sl_byte(int ef) { return (ef < 1 ? 1 : ef) + 93; }     // E - 19 + 127, E = max(ef, 1) - 15
-constexpr int kMxShDelta = 17;                                                                       // sh = sl + 17  (E - 2 + 127)
-__device__ __forceinline__ float e8m0_float(int byte) { return __builtin_bit_cast(float, (unsigned)byte << 23); }
-
-// position of logical column c in the permuted hi plane
-__device__ __host__ __forceinline__ int mx_hi_pos(int c) { return (c & ~127) | (((c >> 3) & 3) << 5) | (((c >> 5) & 3) << 3) | (c & 7); }
-
 template <int OFF>
 __device__ __forceinline__ void lds_rd128(u32v4& dst, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");

@@ -83,7 +83,17 @@ struct BlockW {
   // LayerNorm folded into qkv / fc1 (classifiers): qkvw / fc1w then hold gamma o W, and per output column the sum of the packed row
   // and the bias with beta folded in (vit_misc.hip pack_weight_fold_kernel)
   const float *qkvc = nullptr, *qkvb2 = nullptr, *fc1c = nullptr, *fc1b2 = nullptr;
+  // mlp.fc2 in the MX weight image (gemm_mx.hip) where the width allows (4 D % 128 == 0, D % 48 == 0): fc1 then writes its GELU output in
+  // the MX3 format and fc2 runs as fp16 hi * hi + two block-scaled corrections
+  const uint16_t* fc2mxh = nullptr; const unsigned char* fc2mxx = nullptr;
 };
+
+// RIBCA_MX=0: the fp16x3 kernels everywhere (A/B).  The choice depends on the model's width alone, never on the chunk: a cell's bits must
+// not depend on the size of the chunk it was computed in.
+bool mx_on(int D) {
+  static const bool on = !(getenv("RIBCA_MX") && atoi(getenv("RIBCA_MX")) == 0);
+  return on && (4 * D) % 128 == 0 && gemm_mx_supported(D, 4 * D);
+}
 
 struct ribca_vit {
   int D, C, K, depth, hd, hdp, hdv, Dp, H4;
@@ -137,6 +147,10 @@ void layout_block(Carver& c, BlockW& L, int D, bool fold = false) {
   L.fc1wf = c.take<uint16_t>((size_t)gemm_padded_n(4 * D) * 2 * Dp);
   L.fc2w = c.take<uint16_t>((size_t)gemm_padded_n(D) * 2 * H4);
   if (fold) L.fc2wf = c.take<uint16_t>((size_t)gemm_padded_n(D) * 2 * H4);
+  if (fold && mx_on(D)) {
+    L.fc2mxh = c.take<uint16_t>(mx_wh_bytes(round_up(D, 16), H4) / 2);
+    L.fc2mxx = c.take<unsigned char>(mx_wx_bytes(round_up(D, 16), H4));
+  }
 }
 
 // lays the arena out; with base == nullptr only measures
@@ -210,6 +224,7 @@ struct BlobReader {
     launch_pack_wf(L.fc1w, 2 * Dp, gemm_padded_n(4 * D), Dp, const_cast<uint16_t*>(L.fc1wf), s);
     pack(L.fc2w, D, 4 * D, 4 * D); copy(L.fc2b, D);
     if (fold) launch_pack_wf(L.fc2w, 2 * 4 * D, gemm_padded_n(D), 4 * D, const_cast<uint16_t*>(L.fc2wf), s);
+    if (L.fc2mxh) launch_mx_pack_w(L.fc2w, 2 * 4 * D, round_up(D, 16), 4 * D, const_cast<uint16_t*>(L.fc2mxh), const_cast<unsigned char*>(L.fc2mxx), s);
   }
 };
 int64_t block_params(int64_t d) { return 2 * d + 3 * d * d + 3 * d + d * d + d + 2 * d + 4 * d * d + 4 * d + 4 * d * d + d; }
@@ -349,6 +364,23 @@ void run_block_fold(const BlockW& L, const BlockWs& w, int cells, const AttnGeom
     ProfScope ps(P_PROJ, s);
     GemmArgs g{w.xa, ld_x, L.projw, ld_x, Mc, D, Dp, L.projb, L.projwf};
     resid_ps_and_stats(g, w, ld_x, D, true, 1, s);
+  }
+  if (L.fc2mxh != nullptr) {
+    // the MX pair: fc1's GELU epilogue emits the three-plane operand (3 bytes per element, carved out of the h buffer), fc2 multiplies it
+    // as fp16 hi * hi + two block-scaled corrections (gemm_mx.hip)
+    const size_t hn = (size_t)Mc * 4 * D;
+    const MxAct hmx{w.h, reinterpret_cast<unsigned char*>(w.h + hn), reinterpret_cast<unsigned char*>(w.h + hn) + hn, 4 * D};
+    {
+      ProfScope ps(P_FC1, s);
+      GemmArgs g{w.zps, ld_x, L.fc1w, ld_x, Mc, 4 * D, Dp, L.fc1b2, L.fc1wf};
+      (void)launch_gemm_gelu_mx(g, w.rs, L.fc1c, hmx, s);
+    }
+    {
+      ProfScope ps(P_FC2, s);
+      const ResidStatGeom sg = launch_gemm_mx_resid(hmx, MxWeight{L.fc2mxh, L.fc2mxx}, Mc, D, L.fc2b, w.zps, ld_x, w.part, w.rs, 1, s);
+      launch_ln_finalize(w.part, sg.tiles, Mc, sg.bn, D, w.rs, s);
+    }
+    return;
   }
   {
     ProfScope ps(P_FC1, s);
@@ -903,6 +935,31 @@ int ribca_test_gemm_mx_resid(const uint16_t* A, int32_t lda, const uint16_t* W, 
   const MxWeight w{wh_scratch, wx_scratch};
   const ResidStatGeom sg = launch_gemm_mx_resid(a, w, M, N, bias, z_ps, ldz, reinterpret_cast<float2*>(part), reinterpret_cast<const float2*>(prev), 1, s);
   if (rowstat) launch_ln_finalize(reinterpret_cast<const float2*>(part), sg.tiles, M, sg.bn, N, reinterpret_cast<float2*>(rowstat), s);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int ribca_test_gemm_mx_resid_packed(const uint16_t* hi, const uint8_t* l8, const uint8_t* sc, int32_t Kp, const uint16_t* wh, const uint8_t* wx,
+                                    int32_t M, int32_t N, const float* bias, uint16_t* z_ps, int32_t ldz, float* part, float* rowstat,
+                                    const float* prev, void* stream) {
+  if (!gemm_mx_supported(N, Kp)) return fail("ribca_test_gemm_mx_resid_packed: N must be a multiple of 48 and Kp of 128");
+  if ((rowstat != nullptr) != (part != nullptr)) return fail("ribca_test_gemm_mx_resid_packed: part and rowstat go together");
+  hipStream_t s = (hipStream_t)stream;
+  const MxAct a{const_cast<uint16_t*>(hi), const_cast<uint8_t*>(l8), const_cast<uint8_t*>(sc), Kp};
+  const MxWeight w{wh, wx};
+  const ResidStatGeom sg = launch_gemm_mx_resid(a, w, M, N, bias, z_ps, ldz, reinterpret_cast<float2*>(part), reinterpret_cast<const float2*>(prev), 1, s);
+  if (rowstat) launch_ln_finalize(reinterpret_cast<const float2*>(part), sg.tiles, M, sg.bn, N, reinterpret_cast<float2*>(rowstat), s);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int ribca_test_gemm_gelu_mx(const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp, const float* bias2,
+                            const float* csum, const float* rowstat, uint16_t* wf_scratch, uint16_t* hi_out, uint8_t* l8_out, uint8_t* sc_out,
+                            void* stream) {
+  if (!wf_scratch || !csum || !rowstat) return fail("ribca_test_gemm_gelu_mx: NULL buffer");
+  launch_pack_wf(W, ldw, gemm_padded_n(N), Kp, wf_scratch, (hipStream_t)stream);
+  GemmArgs g{z_ps, lda, W, ldw, M, N, Kp, bias2, wf_scratch};
+  const MxAct out{hi_out, l8_out, sc_out, N};
+  if (!launch_gemm_gelu_mx(g, reinterpret_cast<const float2*>(rowstat), csum, out, (hipStream_t)stream))
+    return fail("ribca_test_gemm_gelu_mx: N must be a multiple of 128");
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -75,6 +75,8 @@ void launch_mx_pack_w(const uint16_t* W, int ldw, int Np, int Kp, uint16_t* WH, 
 // packed-split rows [M][2 Kp] -> MX3 (a.Kp = Kp rounded up to 128): the reference producer of the format
 void launch_mx_pack_act(const uint16_t* ps, int ldps, int M, int Kp, const MxAct& a, hipStream_t s);
 bool gemm_mx_supported(int N, int Kp);
+// out (MX3, out.Kp == g.N) = gelu(rstd acc + (-mean rstd csum + bias)): mlp.fc1 in front of an MX fc2 (gemm_duo.hip); false = not launched
+bool launch_gemm_gelu_mx(const GemmArgs& g, const float2* rowstat, const float* csum, const MxAct& out, hipStream_t s);
 // z_ps = (z_ps - prev mean) + A W^T + bias, statistics per 48-column wave block (as launch_gemm_resid_ps on the duo kernel)
 ResidStatGeom launch_gemm_mx_resid(const MxAct& A, const MxWeight& W, int M, int N, const float* bias, uint16_t* z, int ldz, float2* part,
                                    const float2* prev, int prev_stride, hipStream_t s, int abl = 0);

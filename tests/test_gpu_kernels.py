@@ -493,8 +493,10 @@ def test_vit_forward_vs_oracle(dev, name):
     err = (got - ref).abs().max().item()
     note_err(f"vit_forward {name}", err)
     # north-star tolerance is 1e-3 on confidences; the fp16 hi+lo split holds 2e-5 through 12 blocks (emulated on the oracle:
-    # tests/precision_study.py f16x3 3.7e-6 ... 5.4e-6 over 256 cells; measured here 1.2e-6 ... 3.4e-6)
-    assert err < 2e-5, err
+    # tests/precision_study.py f16x3 3.7e-6 ... 5.4e-6 over 256 cells; measured here 1.2e-6 ... 3.4e-6).  Widths whose products run as
+    # fp16 hi * hi + block-scaled corrections (csrc/gemm_mx.hip: 4 D % 128 == 0) carry the 2^-16-class operand error of that scheme
+    # through 12 blocks: emulated 4.3e-5 ... 9.6e-5 with EVERY product in that form (same study, rows "MX-fp8 / MX-fp6 corrections")
+    assert err < (2e-5 if (4 * d) % 128 else 1.5e-4), err
     assert torch.equal(got.argmax(1), ref.argmax(1))
     got2 = model.predict_proba(x.to(dev), list(range(c)), chunk_cells=64).cpu()
     assert torch.equal(got, got2)     # chunking does not change results

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import mx_emulation as mx
-from test_gpu_kernels import _row_stats, _stats_err, note_err, ps_decode, ps_encode, rnd
+from test_gpu_kernels import _fold, _ln_case, _row_stats, _stats_err, note_err, ps_decode, ps_encode, rnd
 
 pytestmark = pytest.mark.gpu
 
@@ -105,3 +105,51 @@ def test_gemm_mx_resid(dev, m, n, k, recentre):
     e1, e2 = _stats_err(rs, got)
     note_err(f"gemm_mx stats {m}x{n}x{k}", max(e1, e2))
     assert e1 < 1e-6 and e2 < 1e-6, (e1, e2)
+
+
+@pytest.mark.parametrize("m,d", [(150, 288), (260, 576), (7001, 288), (5000, 576), (12000, 384)])
+@pytest.mark.parametrize("mean,std", [(0.5, 3.0), (30.0, 1.0)])
+def test_gemm_gelu_mx(dev, m, d, mean, std):
+    """norm2 -> mlp.fc1 folded, GELU output straight in the MX3 format: the hi plane and the scale bytes are exactly what the packer makes
+    of the packed-split kernel's output (same accumulation order: same x), the lo bytes differ from it only where rounding x - hi to fp16
+    first (the packed-split detour) crosses an e4m3 rounding boundary -- x - hi has up to 13 significant bits, fp16 keeps 11, an e4m3 code
+    boundary sits every 2^-4 relative: about one value in 64 (measured 1.54-1.60 %), one code step each"""
+    from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
+    n = 4 * d
+    z_ps, zq, g, b, dp = _ln_case(m, d, 50, dev, mean, std, row_scale=(mean == 0.5))
+    w = rnd((n, d), 53, dev, 2.0 / np.sqrt(d))
+    bias = rnd((n,), 54, dev, 0.1)
+    w_ps, csum, bias2 = _fold(w, g, b, bias, dp, dev)
+    rs = _row_stats(z_ps, dp, m, d, dev)
+    wf = torch.zeros_like(w_ps)
+    hi_p, l8_p, sc_p = _planes(m, n, dev)
+    check(lib().ribca_test_gemm_gelu_mx(ptr(z_ps), 2 * dp, ptr(w_ps), 2 * dp, m, n, dp, ptr(bias2), ptr(csum), ptr(rs), ptr(wf), ptr(hi_p), ptr(l8_p),
+                                        ptr(sc_p), stream_ptr()), "gelu_mx")
+    # the packed-split kernel's output of the same product, through the reference packer
+    out = torch.zeros((m, 2 * n), dtype=torch.int16, device=dev)
+    check(lib().ribca_test_gemm_fold(1, ptr(z_ps), 2 * dp, ptr(w_ps), 2 * dp, m, n, dp, ptr(bias2), ptr(csum), ptr(rs), ptr(out), 2 * n,
+                                     stream_ptr()), "gemm_fold")
+    hi_r, l8_r, sc_r = _planes(m, n, dev)
+    check(lib().ribca_test_mx_pack_act(ptr(out), 2 * n, m, n, ptr(hi_r), ptr(l8_r), ptr(sc_r), stream_ptr()), "mx_pack_act")
+    assert torch.equal(hi_p, hi_r)
+    assert torch.equal(sc_p, sc_r)
+    got, want = mx.e4m3_decode(l8_p.cpu().numpy()), mx.e4m3_decode(l8_r.cpu().numpy())
+    diff = got != want
+    frac = diff.mean()
+    note_err(f"gelu_mx lo codes differing from the packed-split detour {m}x{n}", frac)
+    assert frac < 0.03, frac
+    # where they differ: by one e4m3 step at that magnitude (subnormal step 2^-9 below 2^-6), plus -- for lo below the fp16 normal
+    # range, i.e. |x| < 0.25 -- the 2^-24 quantum of the detour's fp16 lo, which the fused epilogue (fp32 lo) does not have
+    scale_e = np.repeat(2.0 ** (sc_p.cpu().numpy().astype(np.float64) - 127), 32, axis=1)
+    step = np.maximum(np.abs(want), 2.0 ** -6) * 2.0 ** -3
+    assert np.all((np.abs(got - want) * scale_e)[diff] <= (step * scale_e)[diff] * 1.01 + 2.0 ** -24)
+    # and the operand as fc2 will see it against the exact product
+    ln = torch.nn.functional.layer_norm(zq, (d,), g.double(), b.double(), 1e-6)
+    ref = torch.nn.functional.gelu(ln @ w.double().t() + bias.double()).cpu().numpy()
+    hi = hi_p.cpu().numpy().view(np.float16)[:, mx.hi_pos(np.arange(n))].astype(np.float64)
+    scale = 2.0 ** (sc_p.cpu().numpy().astype(np.float64) - 127)
+    val = hi + (got.reshape(m, n // 32, 32) * scale[:, :, None]).reshape(m, n)
+    err = np.abs(val - ref).max()
+    note_err(f"gelu_mx hi + lo vs exact {m}x{n}x{d} mean {mean}", err)
+    # test_gemm_fold_gelu's bound plus the e4m3 rounding of lo: 2^-4 of |lo| <= 2^-16 of the block's largest value
+    assert err < 2e-5 * (1.0 + abs(mean) / std) + 2.0 ** -15 * np.abs(ref).max(), err
