@@ -30,8 +30,9 @@
 //
 // Kernel: two 256-thread workgroups per CU (77 KB of LDS each), tile 128 x 192, 4 waves as 1 x 4 (a wave owns all 128 rows x 48 columns
 // = 8 x 3 accumulator tiles), W straight from L2 into registers, A through LDS by buffer_load ... lds.  One 128-deep step:
-//     [B1: the step's four hi units have landed]  f16 phase: 4 sub-steps x 8 row tiles x 3 MFMAs, W hi fragments streamed two sub-steps
-//     ahead  ->  conversion: every wave turns the hi rows of TWO row tiles into fp6 (2 v_cvt_scalef32_pk32_fp6_f16 per wave instead of 8)
+//     [B1: the step's four hi units have landed]  f16 phase: 4 sub-steps x 8 row tiles x 3 MFMAs, each sub-step's W hi fragments in a register set of their own
+//     that is refilled for the NEXT step right behind its last use (a whole MX phase ahead: with one MFMA per tile a sub-step lasts a third
+//     of an fp16x3 K step, two of them are shorter than an L2 round trip)  ->  conversion: every wave turns the hi rows of TWO row tiles into fp6 (2 v_cvt_scalef32_pk32_fp6_f16 per wave instead of 8)
 //     and leaves them in LDS  ->  [B2]  the next step's hi units are requested into the slots just freed  ->  MX phase: 8 row tiles x
 //     (lo, fp6 hi, scale from LDS) x 3 x 2 scaled MFMAs.
 // Two barriers per 128 k (the fp16x3 kernels: four).  The residual tile rides the ring behind the product's own steps exactly as in
@@ -240,6 +241,9 @@ void launch_mx_pack_act(const uint16_t* ps, int ldps, int M, int Kp, const MxAct
 }
 
 // ----------------------------------------------------------------------------------------------------------- kernel
+#ifndef MXDBG_PF
+#define MXDBG_PF 3
+#endif
 namespace {
 constexpr int MX_BM = 128, MX_BN = 192, MX_MT = 8, MX_TN = 3;
 // LDS map: the fp6 rows sit right behind the hi slots so that one per-lane address register (plus instruction offsets < 64 KB) reaches both
@@ -293,6 +297,9 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
     sc_voff = (wave * 32 + lane) * (Kp >> 5);
   }
   auto issue_hi = [&](int b) {      // the four hi units of step b: 8 operations per wave
+#ifdef MXDBG_NOA
+    return;
+#endif
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -300,7 +307,31 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
         __builtin_amdgcn_raw_ptr_buffer_load_lds(hi_rsrc, (__attribute__((address_space(3))) void*)(smem + L_HI + s * 8192 + wave * 2048 + u * 1024), 16,
                                                  hi_voff, u * 16 * Kp * 2 + b * 256 + s * 64, 0, 0);
   };
+  // one of the 8 pieces of step b's hi units (piece = 2 * sub-step + half): the K loop spreads them over the MX phase's row tiles
+  auto issue_hi_piece = [&](int b, int piece) {
+#ifdef MXDBG_NOA
+    return;
+#endif
+    const int s = piece >> 1, u = piece & 1;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(hi_rsrc, (__attribute__((address_space(3))) void*)(smem + L_HI + s * 8192 + wave * 2048 + u * 1024), 16, hi_voff,
+                                             u * 16 * Kp * 2 + b * 256 + s * 64, 0, 0);
+  };
+  auto issue_l8_piece = [&](int b, int piece) {      // pieces 0 .. 3: the lo unit's four groups; 4: the scale unit
+#ifdef MXDBG_NOA
+    return;
+#endif
+    if (piece < 4) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(l8_rsrc, (__attribute__((address_space(3))) void*)(smem + L_L8 + (b & 1) * 16384 + wave * 1024 + piece * 4096), 16,
+                                               l8_voff, piece * 32 * Kp + b * 128, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(sc_rsrc, (__attribute__((address_space(3))) void*)(smem + L_SC + (b & 1) * L_SC_SLOT + wave * 128), 4, sc_voff,
+                                               b * 4, 0, 0);
+    }
+  };
   auto issue_l8 = [&](int b) {      // lo unit + scale unit of step b: 5 operations per wave
+#ifdef MXDBG_NOA
+    return;
+#endif
     char* st = smem + L_L8 + (b & 1) * 16384 + wave * 1024;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -326,17 +357,23 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
   const size_t jb = (size_t)(n0 / 48) + (size_t)wn;
   const char* whb = reinterpret_cast<const char*>(WH) + jb * (size_t)nb * kMxWhBytes;
   const char* wxb = reinterpret_cast<const char*>(WX) + jb * (size_t)nb * kMxWxBytes;
-  f16x8 whi[3][TN];
+  f16x8 whi[4][TN];      // one set per sub-step, refilled for the NEXT 128-deep step right behind its last use
   u32v4 wl6a[TN], wh6a[TN];
   u32v2 wl6b[TN], wh6b[TN];
   u32v2 wsc;      // bytes: sl0 sh0 sl1 sh1 | sl2 sh2 - -
   auto issue_whi = [&](int t, f16x8 (&dst)[TN]) {      // sub-step t = 4 b + s of the K loop: 3 operations
+#ifdef MXDBG_NOW
+    return;
+#endif
     const unsigned long long p = uniform_ptr(whb + (size_t)t * 3072);
     gld16h<0>(dst[0], wvoff16, p);
     gld16h<1024>(dst[1], wvoff16, p);
     gld16h<2048>(dst[2], wvoff16, p);
   };
   auto issue_wx = [&](int b) {                          // 13 operations
+#ifdef MXDBG_NOW
+    return;
+#endif
     const unsigned long long p = uniform_ptr(wxb + (size_t)b * kMxWxBytes), p2 = uniform_ptr(wxb + (size_t)b * kMxWxBytes + kWxH6a);
     gld8<kWxL6b>(wl6b[0], wvoff8, p); gld8<kWxL6b + 512>(wl6b[1], wvoff8, p); gld8<kWxL6b + 1024>(wl6b[2], wvoff8, p);
     gld16<kWxL6a>(wl6a[0], wvoff16, p); gld16<kWxL6a + 1024>(wl6a[1], wvoff16, p); gld16<kWxL6a + 2048>(wl6a[2], wvoff16, p);
@@ -362,48 +399,63 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
   // ---- prologue
   issue_whi(0, whi[0]);
   issue_whi(1, whi[1]);
+  issue_whi(2, whi[2]);
+  issue_whi(3, whi[3]);
   issue_l8(0);
   issue_hi(0);
   issue_wx(0);
 
-  // one 128-deep step; P = b % 3 fixes the W register sets of its sub-steps ((4 b + s) % 3 = (b + s) % 3)
-  auto step = [&](auto p_c, int b) {
-    constexpr int P = decltype(p_c)::value;
-    const bool more = b + 1 < nb;
-    // B1: hi units, lo / scale unit and the first two W hi sets of this step have landed (only the 13 operations of W's fp6 images are younger)
+  // one 128-deep step
+  // (the last step is its own instance: "more" is a compile-time constant, so no phase is cut into basic blocks by the requests for the next step)
+  auto step = [&](auto more_c, int b) {
+    constexpr bool more = decltype(more_c)::value;
+    // B1: hi units, lo / scale unit and the four W hi sets of this step have landed (only the 13 operations of W's fp6 images are younger)
     wait_vmcnt<NWX>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     sfor<4>([&](auto s_c) {
       constexpr int S = decltype(s_c)::value;
-      constexpr int SW = (P + S) % 3;
-      if constexpr (S == 2) wait_vmcnt<3>();                        // W hi of sub-step 2 (issued at sub-step 0); sub-step 3's may fly
-      if constexpr (S == 3) { if (more) wait_vmcnt<3>(); else wait_vmcnt<0>(); }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(whi[SW][j]));
-      // W hi two sub-steps ahead
-      if constexpr (S < 2) issue_whi(4 * b + S + 2, whi[(SW + 2) % 3]);
-      else if (more) issue_whi(4 * b + S + 2, whi[(SW + 2) % 3]);
+      for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(whi[S][j]));
       __builtin_amdgcn_sched_barrier(0);
-      f16x8 ah[2];
-      lds_rd128h<S * 8192>(ah[0], rd_hi);
+      // A hi fragments PF row tiles ahead of their MFMAs: a row tile is 3 MFMAs = 48 cycles here (the fp16x3 kernels: 9), less than one LDS
+      // round trip -- with the next tile's read as the only one in flight every iteration waited for it (timing ablation without any
+      // global load: 2.2 x the matrix time)
+      constexpr int PF = MXDBG_PF;
+      f16x8 ah[PF + 1];
+      sfor<PF>([&](auto pc) {
+        constexpr int q = decltype(pc)::value;
+        lds_rd128h<S * 8192 + q * 1024>(ah[q], rd_hi);
+      });
       sfor<MT>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        constexpr int cur = i & 1, nxt = cur ^ 1;
-        if constexpr (i + 1 < MT) {
-          lds_rd128h<S * 8192 + (i + 1) * 1024>(ah[nxt], rd_hi);
-          asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(ah[cur])::"memory");
+        constexpr int cur = i % (PF + 1);
+        if constexpr (i + PF < MT) {
+          lds_rd128h<S * 8192 + (i + PF) * 1024>(ah[(i + PF) % (PF + 1)], rd_hi);
+          asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ah[cur]) : "n"(PF) : "memory");
         } else {
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[cur])::"memory");
+          asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ah[cur]) : "n"(MT - 1 - i) : "memory");
         }
+#ifndef MXDBG_NOF16
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[0][i][j] = mfma_f16(whi[SW][j], ah[cur], acc[0][i][j]);
+        for (int j = 0; j < TN; ++j) acc[0][i][j] = mfma_f16(whi[S][j], ah[cur], acc[0][i][j]);
+#endif
+#ifdef MXDBG_SPREAD
+        // the next step's lo and scale units, one piece behind each of the last sub-step's first five row tiles (their slot was last read in
+        // the MX phase of step b - 1, which every wave left before B1): a burst of LDS-DMA pieces holds the wave's issue for ~100 cycles each
+        if constexpr (more && S == 3 && i < 5) issue_l8_piece(b + 1, i);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       });
       pin_acc(acc);
+      // this sub-step's W hi set for the next 128-deep step: a whole MX phase (and more) ahead of its use
+      if constexpr (more) issue_whi(4 * b + 4 + S, whi[S]);
+      __builtin_amdgcn_sched_barrier(0);
     });
+#ifndef MXDBG_SPREAD
     // the next step's lo and scale units (their slot was last read in the MX phase of step b - 1, which every wave left before B1)
-    if (more) issue_l8(b + 1);
+    if constexpr (more) issue_l8(b + 1);
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #ifndef MXDBG_NOCONV
     // ---- conversion: this wave turns the hi rows of row tiles 2 w, 2 w + 1 into fp6 for everybody
@@ -435,8 +487,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (more) {
+    if constexpr (more) {
+#ifndef MXDBG_SPREAD
       issue_hi(b + 1);
+#endif
     } else {
       // the residual tile's first three 32-column units: two into the hi slots, one into the lo slot of the other parity
       issue_z(0, L_HI);
@@ -478,23 +532,20 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
         acc[0][i][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wl6[0], ah6, acc[0][i][0], 2, 2, 0, (int)wsc[0], 1, asc);
         acc[0][i][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wl6[1], ah6, acc[0][i][1], 2, 2, 2, (int)wsc[0], 1, asc);
         acc[0][i][2] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wl6[2], ah6, acc[0][i][2], 2, 2, 0, (int)wsc[1], 1, asc);
+#ifdef MXDBG_SPREAD
+        if constexpr (more) issue_hi_piece(b + 1, i);      // the next step's hi units (slots free since B2), one piece per row tile
+#endif
         __builtin_amdgcn_sched_barrier(0);
       });
     }
     pin_acc(acc);
 #endif
-    if (more) issue_wx(b + 1);
+    if constexpr (more) issue_wx(b + 1);
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  int b = 0;
-  for (; b + 3 <= nb; b += 3) {
-    step(std::integral_constant<int, 0>{}, b);
-    step(std::integral_constant<int, 1>{}, b + 1);
-    step(std::integral_constant<int, 2>{}, b + 2);
-  }
-  if (b < nb) step(std::integral_constant<int, 0>{}, b);
-  if (b + 1 < nb) step(std::integral_constant<int, 1>{}, b + 1);
+  for (int b = 0; b + 1 < nb; ++b) step(std::true_type{}, b);
+  step(std::false_type{}, nb - 1);
 
   // everything the epilogue needs from memory: requested behind the last operand batch, in front of the residual units, whose six
   // barriers cover the round trip (20 registers that the K loop does not have to carry)
@@ -569,7 +620,11 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
   }
 
 #endif
+#ifdef MXDBG_NOEPI
+  if (true) {
+#else
   if (ABL & 1) {
+#endif
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll

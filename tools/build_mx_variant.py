@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""A second build of the library that differs in gemm_mx.hip only (timing ablations of the MX kernel: -DMXDBG_NOA / NOW / NOCONV / NOMX / NOF16 /
+NOZ / NOEPI, results wrong on purpose): python tools/build_mx_variant.py libribca_mx_noa.so -DMXDBG_NOA ; then RIBCA_LIB=libribca_mx_noa.so"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from multiplexed_image_annotator_amd import build as B
+name, extra = sys.argv[1], sys.argv[2:]
+B.build(verbose=False)
+objdir = os.path.join(B.HERE, "build")
+obj = os.path.join(B.HERE, "build_" + os.path.splitext(name)[0] + "_gemm_mx.o")
+subprocess.run([B._hipcc()] + B.FLAGS + extra + ["-c", os.path.join(B.CSRC, "gemm_mx.hip"), "-o", obj], check=True)
+objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in B.SOURCES if s != "gemm_mx.hip"] + [obj]
+subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(B.HERE, name)] + objs, check=True)
+print("built", name)
