@@ -208,28 +208,55 @@ def main():
 
     ag_events, ag_state = [], {}
 
-    def one_pass(streams=None, models_sel=None):
+    # as Annotator.predict does: cells whose fast (MX) result lies within 1e-3 of a decision boundary (top-2 margin, the vote's confidence
+    # threshold) are re-evaluated with three fp16 passes per product INSIDE the timed region
+    RECHECK = [0.3]
+    stage_events = []      # per timed pass: [(stage, start event, end event)] on the current stream (the ViT's segment streams join it)
+    STAGES = ("normalise", "label_table", "crop", "imputer", "vit", "all_gather", "vote", "d2h")
+
+    def one_pass(streams=None, models_sel=None, record=False):
         streams = args.streams if streams is None else streams
-        image = ops.normalize_image(raw, blur=0.3, amax=99.8, u16_bits=True)
-        ids, tab = ops.label_table(mask)
-        n = len(ids)
+        marks = []
+
+        def stage(name):      # context manager: two events around a stage, read after the timed region (no synchronisation here)
+            class _S:
+                def __enter__(self_inner):
+                    if record:
+                        self_inner.a = torch.cuda.Event(enable_timing=True); self_inner.a.record()
+                def __exit__(self_inner, *exc):
+                    if record:
+                        b = torch.cuda.Event(enable_timing=True); b.record()
+                        marks.append((name, self_inner.a, b))
+                    return False
+            return _S()
+
+        with stage("normalise"):
+            image = ops.normalize_image(raw, blur=0.3, amax=99.8, u16_bits=True)
+        with stage("label_table"):
+            # ids and boxes stay on the device: the crop reads them there (only the label range and the cell count cross PCIe)
+            ids_all, bb_all = ops.label_table_device(mask)
+            n = int(ids_all.numel())
         lo, hi = dist.shard_bounds(n, rank, world) if sharded else (0, n)
-        cmin = ops.channel_min(image)
-        ids_d = torch.from_numpy(ids[lo:hi].astype(np.int32)).to(dev)
-        bb_d = torch.from_numpy(tab[lo:hi, :4].astype(np.int32)).to(dev)
-        patches, _ = ops.extract_patches(image, mask, cmin, ids_d, bb_d)
+        with stage("crop"):
+            cmin = ops.channel_min(image)
+            ids_d = ids_all[lo:hi].contiguous()
+            bb_d = bb_all[lo:hi].contiguous()
+            patches, _ = ops.extract_patches(image, mask, cmin, ids_d, bb_d)
         probs = {}
         for name, model in models.items():
             if models_sel is not None and name not in models_sel:
                 continue
             if imputer is not None and name == "immune_full":
                 # reference preprocess.py:268-281: the panel tensor with its missing plane imputed feeds that panel's classifier
-                panel = patches[:, :15].contiguous()
-                imputer.impute(panel, imp_present, chunk_cells=args.chunk)
-                probs[name] = model.predict_proba(panel, list(range(15)), chunk_cells=args.chunk, streams=streams)
+                with stage("imputer"):
+                    panel = patches[:, :15].contiguous()
+                    imputer.impute(panel, imp_present, chunk_cells=args.chunk)
+                with stage("vit"):
+                    probs[name] = model.predict_proba(panel, list(range(15)), chunk_cells=args.chunk, streams=streams, recheck=RECHECK)
                 del panel
                 continue
-            probs[name] = model.predict_proba(patches, srcs[name], chunk_cells=args.chunk, streams=streams)
+            with stage("vit"):
+                probs[name] = model.predict_proba(patches, srcs[name], chunk_cells=args.chunk, streams=streams, recheck=RECHECK)
         if sharded:         # ONE all-gather per tile: the five models' probability columns side by side (33 floats per cell)
             names = list(probs)
             widths = [probs[k].shape[1] for k in names]
@@ -239,12 +266,19 @@ def main():
             full = dist.all_gather_rows(local_rows, n)
             ev1.record()
             ag_events.append((ev0, ev1))
+            if record:
+                marks.append(("all_gather", ev0, ev1))
             ag_state["local"] = local_rows
             probs = {k: t.contiguous() for k, t in zip(names, torch.split(full, widths, dim=1))}
         a, b = vote_pair if models_sel is None else (next(iter(probs)), None)
-        lab, conf = ops.vote(probs[a], [gid[c] for c in CLASS_NAMES[a]], probs[b] if b else None,
-                             [gid[c] for c in CLASS_NAMES[b]] if b else None, tc, 0.3)
-        return n, lab.cpu(), conf.cpu()
+        with stage("vote"):
+            lab, conf = ops.vote(probs[a], [gid[c] for c in CLASS_NAMES[a]], probs[b] if b else None,
+                                 [gid[c] for c in CLASS_NAMES[b]] if b else None, tc, 0.3)
+        with stage("d2h"):
+            lab_h, conf_h = lab.cpu(), conf.cpu()
+        if record:
+            stage_events.append(marks)
+        return n, lab_h, conf_h
 
     def sync_all():
         torch.cuda.synchronize()
@@ -265,7 +299,7 @@ def main():
     t0 = time.perf_counter()
     n_cells = 0
     for i in range(args.steps):
-        n_cells, lab, conf = one_pass()
+        n_cells, lab, conf = one_pass(record=True)
         note(f"step {i + 1}/{args.steps} done at {time.perf_counter() - t0:.2f}s")
     sync_all()
     dt = time.perf_counter() - t0
@@ -291,14 +325,28 @@ def main():
                                + f"{len(models)} ViT classifiers per cell (normalise + label table + crop/soft-mask + ViT + vote)",
                    "baseline_config": "configs[4] (one tile per GPU, imputation)" if args.impute else ("configs[2]" if world == 1 else "configs[3]"),
                    "cells": n_cells, "models": list(models), "chunk_cells": args.chunk, "segment_streams": args.streams,
-                   "precision": "fp16 hi+lo split operands, 3 MFMA passes per product, fp32 accumulate",
+                   "precision": "fp16 hi+lo split operands, fp32 accumulate: 3 fp16 MFMA passes per product, or (mlp.fc2 where 4 D % 128 == 0) fp16 hi*hi + "
+                                "two block-scaled fp8/fp6 corrections = 1.75 matrix units (matrix_units_per_product)",
                    "parallelism": ("single GPU" if world == 1 else f"one tile per rank x {world} (replicas only)" if args.impute
                                    else f"cells sharded over {world} rank(s), one all-gather of per-cell probabilities")},
         "vit_gflop_per_cell": round(flops_cell / 1e9, 4),
         "vit_mfma_util_vs_bf16_dense": round(value * flops_cell / (world * PEAK_BF16_DENSE_TFLOPS * 1e12), 5),
-        "mfma_cap_3_pass": 0.3333,      # three fp16 MFMA passes per product: the algorithmic fraction of the 16-bit dense peak cannot exceed 1/3
+        # the algorithmic fraction of the 16-bit dense peak cannot exceed 1 / (matrix units issued per product), FLOP-weighted over the products
+        "mfma_cap_by_units": round(1.0 / avg_units({n: m.D for n, m in models.items()}, {n: m.depth for n, m in models.items()}), 4),
         "kernel_source_sha256": lib_sha256(),
     }
+    # where a step's time goes, stage by stage (events on the stream the stage is enqueued on, averaged over the timed steps; a stage that
+    # ends in a host read -- the label range, the percentile scalars, the final D2H -- includes the wait for it).  With cells sharded over
+    # ranks the first two stages are REPLICATED work (every rank normalises the tile and builds the label table): the serial term of
+    # the scaling curve.
+    per_stage = {k: 0.0 for k in STAGES}
+    for marks in stage_events:
+        for name, a, b in marks:
+            per_stage[name] += a.elapsed_time(b)
+    out["per_stage_ms"] = {k: round(v / max(len(stage_events), 1), 3) for k, v in per_stage.items() if v > 0.0 or k in ("normalise", "label_table", "crop", "vit", "vote", "d2h")}
+    out["replicated_preprocessing_ms"] = round((per_stage["normalise"] + per_stage["label_table"]) / max(len(stage_events), 1), 3)
+    out["matrix_units_per_product"] = {name: matrix_units(m.D) for name, m in models.items()}
+    out["cells_re_evaluated_at_full_precision"] = {name: m.last_recheck["cells"] for name, m in models.items() if getattr(m, "last_recheck", None)}
     if sharded:
         ag_ms = sum(a.elapsed_time(b) for a, b in ag_events)
         out["collective"] = collective_record(world, ag_ms, args.steps, ag_state.get("local", torch.zeros(0)))
@@ -312,7 +360,10 @@ def main():
         prof, per_model = {}, []
         # the per-cell fused qkv + attention kernel (D <= 384) belongs to the family: it carries the qkv product of those classifiers
         GEMM_OPS = ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2", "cell_qkv_attention")
-        fused_attn = os.environ.get("RIBCA_CELL_ATTN", "1") != "0"
+        try:      # as the library reads it (atoi)
+            fused_attn = int(os.environ.get("RIBCA_CELL_ATTN", "1")) != 0
+        except ValueError:
+            fused_attn = False
         for name, model in models.items():
             ops.prof_enable(True)
             one_pass(streams=1, models_sel=[name])
@@ -326,17 +377,20 @@ def main():
             m_fl = n_local * ((model.depth - 1) * 24.0 * 101 * d * d + 6.0 * 101 * d * d + 18.0 * d * d)
             if fused_attn and d <= 384:      # its attention FLOPs run inside the family's kernel
                 m_fl += n_local * (model.depth - 1) * 4.0 * 101 * 101 * d
-            # A in + output out + z read / written, 4 B per element (the fused qkv + attention kernel writes D instead of 3 D columns)
-            m_by = n_local * 101 * (model.depth - 1) * (64.0 if (fused_attn and d <= 384) else 72.0) * d
+            # A in + output out + z read / written, 4 B per element (the fused qkv + attention kernel writes D instead of 3 D columns);
+            # the MX pair moves h (4 D columns) at 3 B per element in both directions: 8 D bytes fewer per row and layer
+            units = matrix_units(d)
+            mu = (3.0 * units["qkv"] + units["proj"] + 4.0 * units["fc1"] + 4.0 * units["fc2"]) / 12.0
+            m_by = n_local * 101 * (model.depth - 1) * ((64.0 if (fused_attn and d <= 384) else 72.0) - (8.0 if units["fc2"] < 3.0 else 0.0)) * d
             ai = m_fl / m_by
-            # ridge of the issued work: 3 MFMA passes per product against the 16-bit dense peak, HBM at 8 TB/s
-            ridge = PEAK_BF16_DENSE_TFLOPS * 1e12 / 3.0 / 8.0e12
+            # ridge of the issued work: this classifier's matrix units per product against the 16-bit dense peak, HBM at 8 TB/s
+            ridge = PEAK_BF16_DENSE_TFLOPS * 1e12 / mu / 8.0e12
             tf, gbs = m_fl / (m_ms * 1e-3) / 1e12, m_by / (m_ms * 1e-3) / 1e9
             bound = "mfma" if ai >= ridge else "hbm"
             per_model.append({"model": name, "D": d, "gemm_ms": round(m_ms, 2), "algorithmic_tflops": round(tf, 1),
                               "algorithmic_gb_per_s": round(gbs, 1), "flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1),
-                              "bound": bound,
-                              "frac_of_bound": round(3.0 * tf / PEAK_BF16_DENSE_TFLOPS if bound == "mfma" else gbs / 8000.0, 4)})
+                              "bound": bound, "matrix_units": round(mu, 3),
+                              "frac_of_bound": round(mu * tf / PEAK_BF16_DENSE_TFLOPS if bound == "mfma" else gbs / 8000.0, 4)})
         gemm_flops = 0.0
         for name, model in models.items():
             d = model.D
@@ -352,19 +406,19 @@ def main():
         # carry the fingerprint of the kernel sources they were measured on: other sources being timed here -> null, not stale numbers
         traffic, traffic_src, busy, lds, pass_bytes = None, None, None, None, None
         sha = out["kernel_source_sha256"]
-        tpath = os.path.join(ROOT, "profiles", "r3", "gemm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r4", "gemm_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj.get("kernel_source_sha256") == sha:
                 traffic = round(tj["traffic_bytes_per_launch"])
-                traffic_src = "profiles/r3/gemm_traffic.json"
+                traffic_src = "profiles/r4/gemm_traffic.json"
                 if tj.get("vit_bytes_per_cell"):
                     pass_bytes = tj["vit_bytes_per_cell"] * n_local
-        spath = os.path.join(ROOT, "profiles", "r3", "sq_summary.json")
+        spath = os.path.join(ROOT, "profiles", "r4", "sq_summary.json")
         if os.path.exists(spath):
             sq = json.load(open(spath))
             if sq.get("kernel_source_sha256") == sha:
-                gem = [v for k, v in sq.items() if k.startswith(("gemm_ps_split_kernel", "gemm_ps_duo_kernel", "cell_qkv_attention_kernel"))]
+                gem = [v for k, v in sq.items() if k.startswith(("gemm_ps_split_kernel", "gemm_ps_duo_kernel", "gemm_mx_duo_kernel", "cell_qkv_attention_kernel"))]
                 cyc = sum(v["kernel_cycles"] for v in gem)
                 if cyc > 0:
                     busy = round(sum(v["mfma_busy_frac"] * v["kernel_cycles"] for v in gem) / cyc, 4)
@@ -373,10 +427,13 @@ def main():
         for name, model in models.items():      # algorithmic bytes per pass of the four GEMMs: A read once, output written once, z RMW
             d = model.D
             qkv_io = (1 + 1) if (fused_attn and d <= 384) else (1 + 3)      # fused with attention: z in, attention output out; else z in, q / k / v out
-            per_row = 4.0 * d * qkv_io + 4.0 * d * (1 + 2) + 4.0 * d * (1 + 4) + 4.0 * d * (4 + 2)      # qkv, proj, fc1, fc2
+            hb = 3.0 if matrix_units(d)["fc2"] < 3.0 else 4.0      # bytes per element of h (MX3: fp16 hi + e4m3 lo + scale bytes)
+            per_row = 4.0 * d * qkv_io + 4.0 * d * (1 + 2) + (4.0 * d + hb * 4 * d) + (hb * 4 * d + 4.0 * d * 2)      # qkv, proj, fc1, fc2
             alg_bytes += n_local * 101 * (model.depth - 1) * per_row + 12.0 * d * d * 4.0 * model.depth * ((n_local + args.chunk - 1) // args.chunk)
         # the bound that binds most of the GEMM time: every classifier's GEMMs are priced against their own roofline (per_model_*),
         # the family's label is the time-weighted majority
+        sustained = sustained_probe_tflops()
+        mu_all = avg_units({n: m.D for n, m in models.items()}, {n: m.depth for n, m in models.items()})
         t_mfma = sum(m["gemm_ms"] for m in per_model if m["bound"] == "mfma")
         t_hbm = sum(m["gemm_ms"] for m in per_model if m["bound"] == "hbm")
         out["per_kernel_ms"] = {k: round(v[0], 3) for k, v in prof.items() if v[1]}
@@ -391,23 +448,27 @@ def main():
         out["roofline"] = {"bound": "mfma" if t_mfma >= t_hbm else "hbm",
                            "bound_note": f"time-weighted over the classifiers: {t_mfma:.0f} ms of GEMMs MFMA-bound ({', '.join(m['model'] for m in per_model if m['bound'] == 'mfma')}), "
                                          f"{t_hbm:.0f} ms HBM-bound ({', '.join(m['model'] for m in per_model if m['bound'] == 'hbm')}); "
-                                         "a classifier's side of the ridge follows its algorithmic FLOP per byte (per_model_flop_per_byte; 104 at the ridge of the issued work)",
-                           "kernel": "gemm_ps_split_kernel (fc2 at D = 288 / 384, proj at D = 384) + gemm_ps_duo_kernel (fc1, qkv at D = 576; proj at D = 144 / 288 / 576 and fc2 at D = 144 / 576 with the residual tile through the operand ring) + cell_qkv_attention_kernel (norm1 + qkv + attention, D <= 384), fp16x3", "achieved": round(achieved, 2),
+                                         "a classifier's side of the ridge follows its algorithmic FLOP per byte (per_model_flop_per_byte) against 2.5 PF / its matrix units per product / 8 TB/s",
+                           "kernel": "gemm_mx_duo_kernel (mlp.fc2 at D = 288 / 384 / 576: fp16 hi*hi + block-scaled fp8/fp6 corrections, 3-byte activations) + "
+                                     "gemm_ps_duo_kernel (fc1 -- its GELU epilogue writes the MX operand --, qkv at D = 576; proj at D = 144 / 288 / 576 and fc2 at D = 144 with the "
+                                     "residual tile through the operand ring) + gemm_ps_split_kernel (proj at D = 384, the last blocks' CLS rows) + cell_qkv_attention_kernel "
+                                     "(norm1 + qkv + attention, D <= 384), fp16x3", "achieved": round(achieved, 2),
                            "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 5),
                            "traffic": traffic, "traffic_unit": f"bytes/launch (2*FETCH_SIZE + WRITE_SIZE, {traffic_src})",
                            "algorithmic_bytes_per_launch": round(alg_bytes / max(g_n, 1)),
                            # not the peak the fraction is priced against: what register-resident MFMA loops sustain on this chip under its
                            # power management (tools/mfma_sustain_probe.hip, profiles/r3/mfma_sustain_probe.txt: 1.88 PF at 1.89 GHz)
-                           "mfma_sustained_tflops_probe": 1880.0,
-                           "frac_of_sustained_3_pass_cap": round(achieved / (1880.0 / 3.0), 4),
+                           "mfma_sustained_tflops_probe": sustained,
+                           "frac_of_sustained_cap": round(achieved / (sustained / mu_all), 4) if sustained else None,
                            "mfma_busy_frac": busy, "lds_active_frac": lds,
                            "counters": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), SQ_LDS_IDX_ACTIVE / (256 CUs x ...): "
-                                       "profiles/r3/sq_summary.json; null = the committed counters belong to another build of the library",
+                                       "profiles/r4/sq_summary.json; null = the committed counters belong to another build of the library",
                            "launches": int(g_n), "avg_launch_ms": round(g_ms / max(g_n, 1), 5),
-                           "algorithmic_gflop_per_launch": round(gemm_flops / max(g_n, 1) / 1e9, 4), "mfma_passes_per_product": 3,
-                           "issued_mfma_frac_of_peak": round(3 * achieved / PEAK_BF16_DENSE_TFLOPS, 4),
+                           "algorithmic_gflop_per_launch": round(gemm_flops / max(g_n, 1) / 1e9, 4),
+                           "matrix_units_per_product": round(mu_all, 4),      # FLOP-weighted over the classifiers (per shape: top-level matrix_units_per_product)
+                           "issued_mfma_frac_of_peak": round(mu_all * achieved / PEAK_BF16_DENSE_TFLOPS, 4),
                            "per_model_note": "GEMMs of one classifier: algorithmic FLOP per algorithmic byte against the ridge of the ISSUED "
-                                             "work (3 MFMA passes per product at 2.5 PF dense / 8 TB/s = 104 FLOP/B); frac_of_bound = issued "
+                                             "work (the classifier's matrix units per product at 2.5 PF dense / 8 TB/s: 104 FLOP/B at 3 units); frac_of_bound = issued "
                                              "MFMA fraction of peak where MFMA-bound, algorithmic GB/s of 8 TB/s where HBM-bound "
                                              "(top-level per_model_* keys)"}
 
@@ -425,6 +486,40 @@ def main():
         print(json.dumps(out))
     if world > 1:
         tdist.destroy_process_group()
+
+
+def matrix_units(d):
+    """matrix units (one unit = one pass of the 16-bit dense rate) issued per product of the four Linears of a full block at width d:
+    three fp16 passes, or 1.75 (4 x f16 + fp8 x fp6 at half rate + fp6 x fp6 at quarter rate per 128 k) where the MX pair runs"""
+    from multiplexed_image_annotator_amd import _lib
+    mx = bool(_lib.lib().ribca_mx_enabled(int(d)))
+    return {"qkv": 3.0, "proj": 3.0, "fc1": 3.0, "fc2": 1.75 if mx else 3.0}
+
+
+def avg_units(dims, depths):
+    """FLOP-weighted matrix units per product over the classifiers' full blocks (qkv 3 D^2, proj D^2, fc1 4 D^2, fc2 4 D^2 per row)"""
+    num = den = 0.0
+    for name, d in dims.items():
+        u = matrix_units(d)
+        w = {"qkv": 3.0, "proj": 1.0, "fc1": 4.0, "fc2": 4.0}
+        blocks = max(depths[name] - 1, 1)
+        num += blocks * d * d * sum(w[k] * u[k] for k in w)
+        den += blocks * d * d * sum(w.values())
+    return num / den
+
+
+def sustained_probe_tflops():
+    """what register-resident fp16 MFMA loops sustained on one MI355X in ONE probe session (tools/mfma_sustain_probe.hip): read from the
+    committed output, None when the file is absent -- a one-off measurement, not a property of the box this line was timed on"""
+    path = os.path.join(ROOT, "profiles", "r3", "mfma_sustain_probe.txt")
+    try:
+        best = 0.0
+        for line in open(path):
+            if "mfma_f32_16x16x32_f16" in line and "TFLOP/s dense" in line:
+                best = max(best, float(line.split("ms")[1].split("TFLOP/s")[0]))
+        return best or None
+    except (OSError, ValueError, IndexError):
+        return None
 
 
 def lib_sha256():

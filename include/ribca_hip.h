@@ -90,6 +90,9 @@ int ribca_norm_finalize(float* x, int32_t planes, int64_t hw, const int32_t* mod
  *              mlp.fc2.weight[D*4D], mlp.fc2.bias[D],
  *   norm.weight[D], norm.bias[D], head.weight[K*D], head.bias[K]
  * (the state-dict key order of the checkpoints Annotator.load_models reads, model.py:188-239). */
+/* 1 if classifiers of width D run mlp.fc1 -> mlp.fc2 as the MX pair (csrc/gemm_mx.hip: fp16 hi * hi + two block-scaled corrections, 1.75
+ * matrix units per product and 3 bytes per element of h instead of 3 passes / 4 bytes): 4 D % 128 == 0, D % 48 == 0 and RIBCA_MX != 0 */
+int32_t ribca_mx_enabled(int32_t D);
 int64_t ribca_vit_blob_len(int32_t D, int32_t C, int32_t K, int32_t depth);
 
 /* Replaces Annotator.load_models for one model: repacks the fp32 parameters (device blob) into the MFMA layouts.
@@ -106,6 +109,11 @@ int64_t ribca_vit_workspace_bytes(const ribca_vit_t* m, int32_t chunk_cells);
  * src_chan: (C) int32, image channel feeding each model channel, -1 = blank plane of -1.0 (preprocess.py:110-120);
  * probs: (n_cells, K) fp32.  Cells are processed in chunks of chunk_cells through `workspace`. */
 int ribca_vit_forward(const ribca_vit_t* m, const float* patches, int32_t c_img, const int32_t* src_chan, int32_t n_cells,
+                      float* probs, void* workspace, int64_t workspace_bytes, int32_t chunk_cells, void* stream);
+/* The same forward with every product as three fp16 passes (the 22-bit operands of round 3), whatever ribca_mx_enabled says: what
+ * Annotator.predict re-evaluates the few cells with whose fast result lies within the MX arithmetic's error of a decision boundary
+ * (top-2 margin, confidence thresholds), so that labels are those of the full-precision path.  Same arguments, same workspace. */
+int ribca_vit_forward_precise(const ribca_vit_t* m, const float* patches, int32_t c_img, const int32_t* src_chan, int32_t n_cells,
                       float* probs, void* workspace, int64_t workspace_bytes, int32_t chunk_cells, void* stream);
 
 /* Algorithmic FLOPs per cell of this model (BASELINE.md section 3 formula). */

@@ -43,6 +43,7 @@ SIGNATURES = {
     "ribca_vit_destroy": (None, [c_void_p]),
     "ribca_vit_workspace_bytes": (c_int64, [c_void_p, c_int32]),
     "ribca_vit_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "ribca_vit_forward_precise": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "ribca_vit_flops_per_cell": (c_double, [c_void_p]),
     "ribca_mae_blob_len": (c_int64, [c_int32, c_int32, c_int32]),
     "ribca_mae_create": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, POINTER(c_void_p)]),
@@ -77,6 +78,7 @@ SIGNATURES = {
                                                   c_void_p, c_void_p, c_void_p, c_void_p]),
     "ribca_test_gemm_gelu_mx": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ribca_mx_enabled": (c_int32, [c_int32]),
     "ribca_test_gemm_fold": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_int32, c_void_p]),
     "ribca_test_qkv_attention_fold": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,

@@ -125,6 +125,7 @@ class Annotator(object):
         self._weights: Dict[str, Dict[str, torch.Tensor]] = {}
         self.probs: List[Dict[str, np.ndarray]] = []       # per image: model -> (n, K) fp32 host table
         self._conf_arrays: List[np.ndarray] = []           # per image: the float32 confidences behind self.confidence (-1.0 = thresholded)
+        self.recheck_stats: List[Dict[str, int]] = []      # per image: cells, re-evaluated near a decision boundary, still within the noise floor
         self.label_ids: List[np.ndarray] = []
         self.chunk_cells = int(os.environ.get("RIBCA_CHUNK_CELLS", "1024"))
         self.streams = int(os.environ.get("RIBCA_STREAMS", "3"))      # cell segments in flight per classifier (ops.VitModel.predict_proba)
@@ -200,6 +201,7 @@ class Annotator(object):
         self.struct_pred, self.nerve_pred = [], []
         self.annotations = []
         self._conf_arrays = []
+        self.recheck_stats: List[Dict[str, int]] = []      # per image: cells, re-evaluated near a boundary, still within the noise floor
 
     def _active_models(self) -> Dict[str, Optional[str]]:
         """model.py:241-349: one immune model (full > extended > base) plus struct / nerve when their panels apply."""
@@ -207,16 +209,18 @@ class Annotator(object):
         immune = "immune_full" if p.immune_full else ("immune_extended" if p.immune_extended else ("immune_base" if p.immune_base else None))
         return {"immune": immune, "struct": "struct" if p.struct else None, "nerve": "nerve" if p.nerve else None}
 
-    def _predict_cell_types(self, image_idx, model_name, batch_size=None) -> torch.Tensor:
-        """softmax(model(x), dim=1) for THIS RANK's cells of one image: (n_local, K) device table (predict() gathers)."""
+    def _predict_cell_types(self, image_idx, model_name, batch_size=None, rows: Optional[torch.Tensor] = None, precise: bool = False) -> torch.Tensor:
+        """softmax(model(x), dim=1) for THIS RANK's cells of one image: (n_local, K) device table (predict() gathers).  ``rows``: only
+        these local cells (device index tensor); ``precise``: three fp16 passes per product whatever the width (the re-evaluation of
+        cells near a decision boundary, see predict())."""
         pre = self.preprocessor
         model = self.models[model_name]
         index = self.channel_parser.indices[MODEL_PANEL[model_name]]
-        n = len(pre.cell_ids[image_idx])
-        lo, hi = pre.shards[image_idx]
         c_img = pre.images_dev[image_idx].shape[0]
         src = ops.resolve_channels(index, c_img)
         patches = pre.panel_patches(image_idx)
+        if rows is not None:
+            patches = patches.index_select(0, rows)
         # preprocess.py:268-281: missing markers of an immune panel are imputed unless infer is off (never for structure / nerve)
         if self.infer and -1 in index and MODEL_PANEL[model_name] not in ("structure", "nerve"):
             imputer = self._imputer(MODEL_PANEL[model_name])
@@ -225,7 +229,37 @@ class Annotator(object):
             present = [i for i, c in enumerate(index) if c != -1]
             imputer.impute(panel, present, chunk_cells=self.chunk_cells)
             patches, src = panel, list(range(len(index)))
+        if precise:
+            return model._forward(patches, src, chunk_cells=self.chunk_cells, streams=1, precise=True)
         return model.predict_proba(patches, src, chunk_cells=self.chunk_cells, streams=self.streams)
+
+    # cells whose vote lies this close to a decision boundary are re-evaluated with three fp16 passes per product (ops.VitModel.RECHECK_MARGIN);
+    # those still within NOISE_FLOOR afterwards are counted and logged: two correct fp32 evaluations need not agree on their label
+    NOISE_FLOOR = 2.0e-4
+
+    def _recheck_near_boundaries(self, image_idx, tables, pair, tc) -> Dict[str, int]:
+        """The MX arithmetic (csrc/gemm_mx.hip) moves softmax outputs by a few 1e-5: a cell whose vote sits within 1e-3 of a boundary
+        (top-2 margin, "Others", confidence thresholds -- ops.decision_distance) is recomputed at the full 22-bit operand precision, for
+        every model of the voting pair, and its table rows are replaced.  Returns the counts that predict() logs."""
+        others = {k: (CLASS_NAMES[k].index("Others") if "Others" in CLASS_NAMES[k] else None) for k in pair if k}
+        thresholds = [self.confidence_thresh] + [t for t in tc if t is not None and t >= 0]
+        def distance():
+            pb = tables[pair[1]] if pair[1] else None
+            return ops.decision_distance(tables[pair[0]], others[pair[0]], pb, others.get(pair[1]) if pair[1] else None, thresholds)
+        stats = {"cells": int(tables[pair[0]].shape[0]), "re_evaluated": 0, "within_noise_floor": 0}
+        if stats["cells"] == 0:
+            return stats
+        d = distance()
+        uses_mx = [k for k in pair if k and _lib.lib().ribca_mx_enabled(self.models[k].D)]
+        if uses_mx:
+            rows = torch.nonzero(d < ops.VitModel.RECHECK_MARGIN).flatten()
+            if rows.numel():
+                for k in uses_mx:
+                    tables[k].index_copy_(0, rows, self._predict_cell_types(image_idx, k, rows=rows, precise=True))
+                stats["re_evaluated"] = int(rows.numel())
+                d = distance()
+        stats["within_noise_floor"] = int((d < self.NOISE_FLOOR).sum().item())
+        return stats
 
     def predict(self, batch_size=32):
         self.logger.log("\nStart predicting cell types and tissue structures.")
@@ -250,13 +284,21 @@ class Annotator(object):
                 tables[name] = self._predict_cell_types(image_idx, name, batch_size)
             if not tables:
                 raise ValueError("No predictions to merge")
+            imm, st, nv = active["immune"], active["struct"], active["nerve"]
+            if not (imm == "immune_full" and st and nv):      # (that combination raises below, as the reference does)
+                pair0 = (imm, st) if imm and st else (st, nv) if st and nv else (imm, nv) if imm and nv else (imm or st or nv, None)
+                rs = self._recheck_near_boundaries(image_idx, tables, pair0, tc)
+                self.recheck_stats.append(rs)      # (this rank's shard: the counts are logged per rank, no collective for a log line)
+                msg = ("{} of {} cells lay within {:g} of a decision boundary and were re-evaluated at full operand precision; {} remain within "
+                       "{:g} (inside the arithmetic's noise floor: another correct fp32 evaluation may label them differently)."
+                       ).format(rs["re_evaluated"], rs["cells"], ops.VitModel.RECHECK_MARGIN, rs["within_noise_floor"], self.NOISE_FLOOR)
+                self.logger.log(msg if self.world_size == 1 else "rank {}: {}".format(self.rank, msg))
             if self.world_size > 1:
                 # ONE all-gather per image: the models' probability columns side by side (<= 33 floats per cell), SURVEY 8(e)
                 names = list(tables)
                 widths = [tables[k].shape[1] for k in names]
                 full = dist.all_gather_rows(torch.cat([tables[k] for k in names], dim=1), len(self.preprocessor.cell_ids[image_idx]))
                 tables = {k: t.contiguous() for k, t in zip(names, torch.split(full, widths, dim=1))}
-            imm, st, nv = active["immune"], active["struct"], active["nerve"]
             if imm == "immune_full" and st and nv:
                 raise KeyError("Others")       # reference branch 1 (model.py:483-510) fails exactly like this
             if imm and st:

@@ -100,7 +100,9 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
     // Later experiment, NOT kept: the same stream through one buffer descriptor with scalar / precomputed offsets (4 instructions per DMA
     // instead of a dependent 64-bit address chain, 40 GB/s from this one wave) bought 0.15 % end to end and was NOT deterministic at
     // 18 DMAs per stage (D = 144, 288): a few rows per thousand cells differed by up to 5e-4 between identical launches
-    // (tools/check_determinism.py; tests/test_gpu_e2e.py::test_config3_full_size_properties caught it).  Cause not established.
+    // (tools/check_determinism.py; tests/test_gpu_e2e.py::test_config3_full_size_properties caught it).  Cause (round 4, from the ISA): the
+    // CONSUMERS left fragment reads of the slot in flight across the step barrier -- see the wait in front of it below; with that wait the
+    // protocol no longer depends on how soon behind the barrier the first piece is issued.
     auto issue = [&](int step) {
       const int hg = step / NK, s = step - hg * NK;
       char* st = smem + (step % kRing) * kWStage;
@@ -156,6 +158,13 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
     for (int j = 0; j < NTILES; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NK; ++s, ++step) {
+      // Every fragment read of the PREVIOUS stage must have RETURNED before this barrier: behind it the loader refills that very slot
+      // (ring of 3, two stages ahead).  Without the wait hipcc software-pipelines the loop -- the last ds_read_b128s of a stage are issued
+      // in front of the barrier and waited for behind it, their MFMAs sunk below it (11 of the 19 barriers of the D = 384 kernel, found
+      // in the ISA) -- and the slot is only protected by the DMA's latency exceeding an LDS read's.  That is the non-repeatability the
+      // round-3 buffer-descriptor loader showed (a few rows per thousand cells at D = 144 / 288): it issues its first piece a few
+      // cycles behind the barrier instead of ~70 and so closed the window.
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       const char* st = smem + (step % kRing) * kWStage;

@@ -307,27 +307,6 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
         __builtin_amdgcn_raw_ptr_buffer_load_lds(hi_rsrc, (__attribute__((address_space(3))) void*)(smem + L_HI + s * 8192 + wave * 2048 + u * 1024), 16,
                                                  hi_voff, u * 16 * Kp * 2 + b * 256 + s * 64, 0, 0);
   };
-  // one of the 8 pieces of step b's hi units (piece = 2 * sub-step + half): the K loop spreads them over the MX phase's row tiles
-  auto issue_hi_piece = [&](int b, int piece) {
-#ifdef MXDBG_NOA
-    return;
-#endif
-    const int s = piece >> 1, u = piece & 1;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(hi_rsrc, (__attribute__((address_space(3))) void*)(smem + L_HI + s * 8192 + wave * 2048 + u * 1024), 16, hi_voff,
-                                             u * 16 * Kp * 2 + b * 256 + s * 64, 0, 0);
-  };
-  auto issue_l8_piece = [&](int b, int piece) {      // pieces 0 .. 3: the lo unit's four groups; 4: the scale unit
-#ifdef MXDBG_NOA
-    return;
-#endif
-    if (piece < 4) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(l8_rsrc, (__attribute__((address_space(3))) void*)(smem + L_L8 + (b & 1) * 16384 + wave * 1024 + piece * 4096), 16,
-                                               l8_voff, piece * 32 * Kp + b * 128, 0, 0);
-    } else {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(sc_rsrc, (__attribute__((address_space(3))) void*)(smem + L_SC + (b & 1) * L_SC_SLOT + wave * 128), 4, sc_voff,
-                                               b * 4, 0, 0);
-    }
-  };
   auto issue_l8 = [&](int b) {      // lo unit + scale unit of step b: 5 operations per wave
 #ifdef MXDBG_NOA
     return;
@@ -440,11 +419,6 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[0][i][j] = mfma_f16(whi[S][j], ah[cur], acc[0][i][j]);
 #endif
-#ifdef MXDBG_SPREAD
-        // the next step's lo and scale units, one piece behind each of the last sub-step's first five row tiles (their slot was last read in
-        // the MX phase of step b - 1, which every wave left before B1): a burst of LDS-DMA pieces holds the wave's issue for ~100 cycles each
-        if constexpr (more && S == 3 && i < 5) issue_l8_piece(b + 1, i);
-#endif
         __builtin_amdgcn_sched_barrier(0);
       });
       pin_acc(acc);
@@ -452,10 +426,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
       if constexpr (more) issue_whi(4 * b + 4 + S, whi[S]);
       __builtin_amdgcn_sched_barrier(0);
     });
-#ifndef MXDBG_SPREAD
     // the next step's lo and scale units (their slot was last read in the MX phase of step b - 1, which every wave left before B1)
     if constexpr (more) issue_l8(b + 1);
-#endif
     __builtin_amdgcn_sched_barrier(0);
 #ifndef MXDBG_NOCONV
     // ---- conversion: this wave turns the hi rows of row tiles 2 w, 2 w + 1 into fp6 for everybody
@@ -483,14 +455,17 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
       });
     }
 #endif
-    // B2: fp6 rows visible to every wave, hi slots free
+    // B2: fp6 rows visible to every wave, hi slots free.  W's fp6 images of THIS step (requested behind the previous MX phase) must have
+    // landed before the MX phase reads them: only the requests made during this step's f16 phase are younger -- 4 x 3 W hi fragments and
+    // the 5 pieces of the next lo / scale unit; none in the last step.  (A first version of the four-set W hi schedule had dropped the
+    // wait that used to cover them: tests/test_gpu_e2e.py::test_classifier_bitwise_repeatable caught it.)
+    if constexpr (more) wait_vmcnt<4 * TN + 5>();
+    else wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if constexpr (more) {
-#ifndef MXDBG_SPREAD
       issue_hi(b + 1);
-#endif
     } else {
       // the residual tile's first three 32-column units: two into the hi slots, one into the lo slot of the other parity
       issue_z(0, L_HI);
@@ -532,9 +507,6 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
         acc[0][i][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wl6[0], ah6, acc[0][i][0], 2, 2, 0, (int)wsc[0], 1, asc);
         acc[0][i][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wl6[1], ah6, acc[0][i][1], 2, 2, 2, (int)wsc[0], 1, asc);
         acc[0][i][2] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wl6[2], ah6, acc[0][i][2], 2, 2, 0, (int)wsc[1], 1, asc);
-#ifdef MXDBG_SPREAD
-        if constexpr (more) issue_hi_piece(b + 1, i);      // the next step's hi units (slots free since B2), one piece per row tile
-#endif
         __builtin_amdgcn_sched_barrier(0);
       });
     }

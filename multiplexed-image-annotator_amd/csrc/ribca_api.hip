@@ -346,7 +346,7 @@ bool cell_attn_on(const AttnGeom& a) {
   static const int v = getenv("RIBCA_CELL_ATTN") ? atoi(getenv("RIBCA_CELL_ATTN")) : 1;
   return v != 0 && cell_attention_supported(a.D, a.H, a.T);
 }
-void run_block_fold(const BlockW& L, const BlockWs& w, int cells, const AttnGeom& a, hipStream_t s) {
+void run_block_fold(const BlockW& L, const BlockWs& w, int cells, const AttnGeom& a, hipStream_t s, bool precise = false) {
   const int D = a.D, Dp = round_up(D, 32), ld_x = 2 * Dp, ld_h = 2 * 4 * D, Mc = cells * a.T;
   const float scale = 1.0f / sqrtf((float)a.hd);
   if (cell_attn_on(a)) {
@@ -365,7 +365,7 @@ void run_block_fold(const BlockW& L, const BlockWs& w, int cells, const AttnGeom
     GemmArgs g{w.xa, ld_x, L.projw, ld_x, Mc, D, Dp, L.projb, L.projwf};
     resid_ps_and_stats(g, w, ld_x, D, true, 1, s);
   }
-  if (L.fc2mxh != nullptr) {
+  if (L.fc2mxh != nullptr && !precise) {
     // the MX pair: fc1's GELU epilogue emits the three-plane operand (3 bytes per element, carved out of the h buffer), fc2 multiplies it
     // as fp16 hi * hi + two block-scaled corrections (gemm_mx.hip)
     const size_t hn = (size_t)Mc * 4 * D;
@@ -436,6 +436,8 @@ int32_t ribca_gemm_padded_n(int32_t N) { return gemm_padded_n(N); }
 int ribca_set_gemm_variant(int32_t v) { gemm_set_variant(v); return 0; }
 int ribca_set_gemm_stamps(void* dev_buffer, int64_t capacity_blocks) { return gemm_set_stamp_buffer(dev_buffer, capacity_blocks); }
 
+int32_t ribca_mx_enabled(int32_t D) { return mx_on(D) ? 1 : 0; }
+
 int64_t ribca_vit_blob_len(int32_t D, int32_t C, int32_t K, int32_t depth) {
   const int64_t d = D;
   return d + (int64_t)kTokens * d + d * C * 16 + d + (int64_t)depth * (2 * d + 3 * d * d + 3 * d + d * d + d + 2 * d + 4 * d * d + 4 * d + 4 * d * d + d) +
@@ -494,8 +496,18 @@ int64_t ribca_vit_workspace_bytes(const ribca_vit_t* m, int32_t chunk_cells) {
   return (int64_t)c.off;
 }
 
+static int vit_forward_impl(const ribca_vit_t* m, const float* patches, int32_t c_img, const int32_t* src_chan, int32_t n_cells, float* probs,
+                            void* workspace, int64_t workspace_bytes, int32_t chunk_cells, void* stream, bool precise);
 int ribca_vit_forward(const ribca_vit_t* m, const float* patches, int32_t c_img, const int32_t* src_chan, int32_t n_cells, float* probs,
                       void* workspace, int64_t workspace_bytes, int32_t chunk_cells, void* stream) {
+  return vit_forward_impl(m, patches, c_img, src_chan, n_cells, probs, workspace, workspace_bytes, chunk_cells, stream, false);
+}
+int ribca_vit_forward_precise(const ribca_vit_t* m, const float* patches, int32_t c_img, const int32_t* src_chan, int32_t n_cells, float* probs,
+                              void* workspace, int64_t workspace_bytes, int32_t chunk_cells, void* stream) {
+  return vit_forward_impl(m, patches, c_img, src_chan, n_cells, probs, workspace, workspace_bytes, chunk_cells, stream, true);
+}
+static int vit_forward_impl(const ribca_vit_t* m, const float* patches, int32_t c_img, const int32_t* src_chan, int32_t n_cells, float* probs,
+                            void* workspace, int64_t workspace_bytes, int32_t chunk_cells, void* stream, bool precise) {
   if (!m) return fail("ribca_vit_forward: model is NULL");
   if (n_cells < 0 || chunk_cells <= 0) return fail("ribca_vit_forward: bad cell counts");
   if (n_cells == 0) return 0;
@@ -524,7 +536,7 @@ int ribca_vit_forward(const ribca_vit_t* m, const float* patches, int32_t c_img,
         launch_cls_rows_ps(w.zps, ld_z, m->cls, m->pos, D, bc, kTokens, s);
       }
       { ProfScope ps(P_LN, s); launch_row_stats_ps(w.zps, ld_z, bc * kTokens, D, w.rs, true, s); }
-      for (size_t li = 0; li + 1 < m->layers.size(); ++li) run_block_fold(m->layers[li], w, bc, geom, s);
+      for (size_t li = 0; li + 1 < m->layers.size(); ++li) run_block_fold(m->layers[li], w, bc, geom, s, precise);
       run_last_block_cls_fold(m->layers.back(), w, bc, geom, s);
       {
         ProfScope ps(P_HEAD, s);

@@ -83,18 +83,23 @@ def mask_minmax(mask: torch.Tensor) -> Tuple[int, int]:
     return mx, mn
 
 
-def label_table(mask: torch.Tensor) -> Tuple[np.ndarray, np.ndarray]:
+def label_table(mask: torch.Tensor, with_device: bool = False):
     """(H, W) int32 device mask -> (ids ascending int64 [n], table int64 [n, 7]: rmin, rmax, cmin, cmax, sum_r, sum_c,
-    count) on the host.  The per-label reduction runs on the GPU; the host only drops absent labels."""
+    count) on the host.  The per-label reduction runs on the GPU; the host only drops absent labels.  ``with_device``: additionally the
+    device-resident (ids int32 [n], bbox int32 [n, 4]) the crop consumes, so that a caller that needs the host table anyway (CSV
+    centroids) does not send the id list back up."""
     assert mask.dtype == torch.int32 and mask.is_cuda and mask.dim() == 2
     h, w = mask.shape
+    def none():
+        e = (np.zeros(0, np.int64), np.zeros((0, 7), np.int64))
+        return e + (torch.zeros(0, dtype=torch.int32, device=mask.device), torch.zeros((0, 4), dtype=torch.int32, device=mask.device)) if with_device else e
     if mask.numel() == 0:
-        return np.zeros(0, np.int64), np.zeros((0, 7), np.int64)
+        return none()
     mx, mn = mask_minmax(mask)
     if mn < 0:
         raise ValueError("segmentation mask holds negative labels; cell ids must be 1..N with 0 = background")
     if mx <= 0:
-        return np.zeros(0, np.int64), np.zeros((0, 7), np.int64)
+        return none()
     L = mx + 1
     ti = torch.empty((5, L), dtype=torch.int32, device=mask.device)
     tu = torch.empty((2, L), dtype=torch.int64, device=mask.device)
@@ -103,7 +108,34 @@ def label_table(mask: torch.Tensor) -> Tuple[np.ndarray, np.ndarray]:
     tu_h = tu.cpu().numpy()
     ids = np.flatnonzero(ti_h[4] > 0)
     table = np.stack([ti_h[0, ids], ti_h[1, ids], ti_h[2, ids], ti_h[3, ids], tu_h[0, ids], tu_h[1, ids], ti_h[4, ids]], axis=1)
+    if with_device:
+        ids_d = torch.nonzero(ti[4] > 0).flatten()
+        return ids.astype(np.int64), table.astype(np.int64), ids_d.to(torch.int32), ti[:4].index_select(1, ids_d).t().contiguous()
     return ids.astype(np.int64), table.astype(np.int64)
+
+
+def label_table_device(mask: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The same reduction with the result left ON THE DEVICE: (ids int32 [n] ascending, bbox int32 [n, 4]: rmin, rmax, cmin, cmax) --
+    what ``extract_patches`` consumes.  Only the label range (two scalars) and the cell count cross PCIe; the sharded path uses it so
+    that no rank bounces the id list through numpy between the label table and the crop (reference preprocess.py:159-211 builds the
+    whole dict on the host)."""
+    assert mask.dtype == torch.int32 and mask.is_cuda and mask.dim() == 2
+    h, w = mask.shape
+    empty = (torch.zeros(0, dtype=torch.int32, device=mask.device), torch.zeros((0, 4), dtype=torch.int32, device=mask.device))
+    if mask.numel() == 0:
+        return empty
+    mx, mn = mask_minmax(mask)
+    if mn < 0:
+        raise ValueError("segmentation mask holds negative labels; cell ids must be 1..N with 0 = background")
+    if mx <= 0:
+        return empty
+    L = mx + 1
+    ti = torch.empty((5, L), dtype=torch.int32, device=mask.device)
+    tu = torch.empty((2, L), dtype=torch.int64, device=mask.device)
+    check(lib().ribca_label_table(ptr(mask), h, w, L, ptr(ti), ptr(tu), stream_ptr()), "ribca_label_table")
+    ids = torch.nonzero(ti[4] > 0).flatten()                       # ascending; the one host sync (its length)
+    bbox = ti[:4].index_select(1, ids).t().contiguous()
+    return ids.to(torch.int32), bbox
 
 
 def channel_min(image: torch.Tensor) -> torch.Tensor:
@@ -382,6 +414,37 @@ def normalize_image(raw, blur=0, amax=100, u16_bits: bool = False) -> torch.Tens
 
 
 # ------------------------------------------------------------------------------------------- ViT
+def decision_distance(pa: torch.Tensor, others_a: Optional[int], pb: Optional[torch.Tensor], others_b: Optional[int],
+                      thresholds: Sequence[float]) -> torch.Tensor:
+    """How far (in probability) each cell is from the nearest boundary of the vote (reference model.py:481-633): the smaller of the top-2
+    margin among the candidate classes and the distance of the best candidate from every quantity it is compared with -- the models'
+    "Others" probabilities, the confidence threshold, the per-type thresholds in force.  Conservative (a threshold that does not bind
+    for a cell still counts): it decides which cells Annotator.predict re-evaluates at full precision and which it reports as inside the
+    arithmetic's noise floor.  ``others_x`` = column of "Others" in table x (None: the table has none)."""
+    def split(p, o):
+        if o is None:
+            return p, None
+        keep = [i for i in range(p.shape[1]) if i != o]
+        return p[:, keep], p[:, o]
+    va, oa = split(pa, others_a)
+    cand, oth = [va], [oa] if oa is not None else []
+    if pb is not None:
+        vb, ob = split(pb, others_b)
+        cand.append(vb)
+        if ob is not None:
+            oth.append(ob)
+    v = torch.cat(cand, dim=1)
+    top = torch.topk(v, min(2, v.shape[1]), dim=1).values
+    best = top[:, 0]
+    dist_ = (top[:, 0] - top[:, -1]) if v.shape[1] > 1 else torch.full_like(best, 2.0)
+    for o in oth:
+        dist_ = torch.minimum(dist_, (best - o).abs())
+    for t in thresholds:
+        if t is not None and t >= 0:
+            dist_ = torch.minimum(dist_, (best - float(t)).abs())
+    return dist_
+
+
 class VitModel:
     """One packed classifier on one device (replaces a timm ``VisionTransformer`` instance of reference
     model.py:188-234).  ``state_dict`` uses the timm key names of the reference checkpoints."""
@@ -419,8 +482,40 @@ class VitModel:
                 pass
             self._h = None
 
+    # Cells whose fast (MX) result lies this close to a decision boundary are re-evaluated with three fp16 passes per product.  The MX
+    # pair moves softmax outputs by 2-4e-5 against the fp16x3 path (measured; 1e-4 class with every product in that form, emulated):
+    # 1e-3 leaves an order of magnitude, and is the north star's own confidence tolerance.
+    RECHECK_MARGIN = 1.0e-3
+
     def predict_proba(self, patches: torch.Tensor, src_chan: Sequence[int], chunk_cells: int = 1024, ws_slot: int = 0,
-                      streams: int = 1) -> torch.Tensor:
+                      streams: int = 1, recheck: Optional[Sequence[float]] = None) -> torch.Tensor:
+        """``_forward`` plus, where this width runs the MX pair, the full-precision re-evaluation of the cells near a decision boundary:
+        ``recheck`` = the thresholds the caller will compare confidences with (``[]``: only the top-2 margin counts; ``None``: no
+        re-evaluation).  A cell is re-evaluated when its two best classes are closer than RECHECK_MARGIN or its best probability is
+        within RECHECK_MARGIN of a threshold -- a property of the cell's own fast result, so results stay independent of chunking.
+        ``self.last_recheck`` = {"cells": re-evaluated, "undecidable": of those, still within 2e-4 of a boundary afterwards}."""
+        probs = self._forward(patches, src_chan, chunk_cells, ws_slot, streams, precise=False)
+        self.last_recheck = {"cells": 0, "undecidable": 0}
+        if recheck is None or probs.shape[0] == 0 or not lib().ribca_mx_enabled(self.D):
+            return probs
+
+        def near(p, eps):
+            top = torch.topk(p, min(2, p.shape[1]), dim=1).values
+            m = (top[:, 0] - top[:, -1]) < eps if p.shape[1] > 1 else torch.zeros(p.shape[0], dtype=torch.bool, device=p.device)
+            for t in recheck:
+                if t is not None and t > 0:
+                    m |= (top[:, 0] - float(t)).abs() < eps
+            return m
+
+        idx = torch.nonzero(near(probs, self.RECHECK_MARGIN)).flatten()
+        if idx.numel():
+            again = self._forward(patches.index_select(0, idx), src_chan, chunk_cells, ws_slot, 1, precise=True)
+            probs.index_copy_(0, idx, again)
+            self.last_recheck = {"cells": int(idx.numel()), "undecidable": int(near(again, 2.0e-4).sum().item())}
+        return probs
+
+    def _forward(self, patches: torch.Tensor, src_chan: Sequence[int], chunk_cells: int = 1024, ws_slot: int = 0,
+                 streams: int = 1, precise: bool = False) -> torch.Tensor:
         """softmax(model(x), dim=1) for full-channel patches (n, C_img, 40, 40); ``src_chan[c]`` = image channel of model
         channel c or -1 for a blank plane (reference preprocess.py:110-120, model.py:397-406).
 
@@ -436,6 +531,7 @@ class VitModel:
         probs = torch.empty((n, self.K), dtype=torch.float32, device=patches.device)
         if n == 0:
             return probs
+        fwd = lib().ribca_vit_forward_precise if precise else lib().ribca_vit_forward
         chunk = max(1, min(int(chunk_cells), n))
         src = torch.tensor(list(src_chan), dtype=torch.int32, device=patches.device)
         nbytes = lib().ribca_vit_workspace_bytes(self._h, chunk)
@@ -445,8 +541,7 @@ class VitModel:
         if nseg == 1:
             ws = workspace(nbytes + 256, patches.device, ws_slot)
             aligned = (ws.data_ptr() + 255) & ~255
-            check(lib().ribca_vit_forward(self._h, ptr(patches), c_img, ptr(src), n, ptr(probs), aligned, nbytes, chunk, stream_ptr()),
-                  "ribca_vit_forward")
+            check(fwd(self._h, ptr(patches), c_img, ptr(src), n, ptr(probs), aligned, nbytes, chunk, stream_ptr()), "ribca_vit_forward")
             return probs
         main = torch.cuda.current_stream(patches.device)
         ready = torch.cuda.Event()
@@ -461,8 +556,8 @@ class VitModel:
             aligned = (ws.data_ptr() + 255) & ~255
             st.wait_event(ready)
             with torch.cuda.stream(st):
-                check(lib().ribca_vit_forward(self._h, ptr(patches[lo:hi]), c_img, ptr(src), hi - lo, ptr(probs[lo:hi]), aligned, nbytes, chunk,
-                                              stream_ptr()), "ribca_vit_forward")
+                check(fwd(self._h, ptr(patches[lo:hi]), c_img, ptr(src), hi - lo, ptr(probs[lo:hi]), aligned, nbytes, chunk, stream_ptr()),
+                      "ribca_vit_forward")
             done = torch.cuda.Event()
             done.record(st)
             main.wait_event(done)

@@ -278,6 +278,8 @@ class ImageProcessor(object):
         self.cell_tables: List[np.ndarray] = []
         self.shards: List[Tuple[int, int]] = []
         self.patches: List[Optional[torch.Tensor]] = []     # (n_local, C_img, 40, 40) fp32 per image, this rank's cells
+        self.cell_ids_dev: List[torch.Tensor] = []          # per image: ascending cell ids int32 [n] / boxes int32 [n, 4] on the device
+        self.cell_bbox_dev: List[torch.Tensor] = []
         self._log("\n")
         self._log("Starting image processing...")
 
@@ -300,9 +302,9 @@ class ImageProcessor(object):
 
     def crop_cells(self, image_idx: int, lo: int, hi: int, want_avg: bool = False, out: Optional[torch.Tensor] = None):
         """Soft-masked full-channel patches of cells [lo, hi) (cell order = ascending id) of one image (into ``out`` when given)."""
-        dev = self.images_dev[image_idx].device
-        ids = torch.from_numpy(self.cell_ids[image_idx][lo:hi].astype(np.int32)).to(dev)
-        bbox = torch.from_numpy(self.cell_tables[image_idx][lo:hi, :4].astype(np.int32)).to(dev)
+        # the ids and boxes never left the device (transform keeps the label table's device copy beside the host one the CSV needs)
+        ids = self.cell_ids_dev[image_idx][lo:hi].contiguous()
+        bbox = self.cell_bbox_dev[image_idx][lo:hi].contiguous()
         return ops.extract_patches(self.images_dev[image_idx], self.masks_dev[image_idx], self.chan_min[image_idx], ids, bbox,
                                    want_avg=want_avg, out=out, patch_size=self.patch_size)
 
@@ -323,7 +325,9 @@ class ImageProcessor(object):
                 img_d = torch.from_numpy(np.ascontiguousarray(image).astype(np.float32)).to(dev)
             self.masks.append(mask)
             mask_d = torch.from_numpy(mask).to(dev)
-            ids, table = ops.label_table(mask_d)
+            ids, table, ids_d, bbox_d = ops.label_table(mask_d, with_device=True)
+            self.cell_ids_dev.append(ids_d)
+            self.cell_bbox_dev.append(bbox_d)
             self.cell_pos_dict.append(LazyCellPositions(mask, ids, table))
             self.images_dev.append(img_d)
             self.masks_dev.append(mask_d)

@@ -500,6 +500,23 @@ def test_vit_forward_vs_oracle(dev, name):
     assert torch.equal(got.argmax(1), ref.argmax(1))
     got2 = model.predict_proba(x.to(dev), list(range(c)), chunk_cells=64).cpu()
     assert torch.equal(got, got2)     # chunking does not change results
+    # the full-precision forward (what cells near a decision boundary are re-evaluated with): three fp16 passes whatever the width
+    prec = model._forward(x.to(dev), list(range(c)), chunk_cells=8, precise=True).cpu()
+    assert (prec - ref).abs().max().item() < 2e-5
+    if (4 * d) % 128:
+        assert torch.equal(prec, got)      # no MX pair at this width: the same kernels
+    # ... and the re-evaluation itself: with a margin of 2 (every cell "near a boundary") the result is the full-precision one, bit for bit
+    saved = type(model).RECHECK_MARGIN
+    try:
+        type(model).RECHECK_MARGIN = 2.0
+        allc = model.predict_proba(x.to(dev), list(range(c)), chunk_cells=8, recheck=[]).cpu()
+    finally:
+        type(model).RECHECK_MARGIN = saved
+    assert torch.equal(allc, prec)
+    some = model.predict_proba(x.to(dev), list(range(c)), chunk_cells=8, recheck=[0.5]).cpu()
+    top = ref.sort(dim=1, descending=True).values
+    far = ((top[:, 0] - top[:, 1]) > 2e-3) & ((top[:, 0] - 0.5).abs() > 2e-3)
+    assert torch.equal(some[far], got[far])      # cells far from every boundary keep the fast result
 
 
 def _large_mean_state_dict(name, c0=125.0, c1=30.0):

@@ -101,3 +101,20 @@ def test_checkpoint_loader_executes_nothing_from_the_file(tmp_path):
     torch.save({"state": sd}, str(nokey))
     with pytest.raises(RuntimeError, match="'model'"):
         _load_state_dict(str(nokey))
+
+
+def test_decision_distance_covers_every_comparison_of_the_vote():
+    """ops.decision_distance: distance of a cell from the nearest boundary of merge_by_voting (reference model.py:481-633) -- top-2 margin of
+    the candidate classes, the models' "Others" probabilities, the confidence and per-type thresholds"""
+    import torch
+    from multiplexed_image_annotator_amd.ops import decision_distance
+    pa = torch.tensor([[0.50, 0.30, 0.20], [0.40, 0.399, 0.201], [0.26, 0.04, 0.70], [0.90, 0.05, 0.05]])      # Others = column 2
+    pb = torch.tensor([[0.10, 0.90], [0.10, 0.90], [0.2505, 0.7495], [0.05, 0.95]])                              # Others = column 1
+    d = decision_distance(pa, 2, pb, 1, [0.25])
+    # cell 0: candidates .5 .3 | .1 -> margin .2, others .2 / .9, threshold .25 -> nearest: |.5 - .25| = .25? no: margin .2 and |.5 - .2| = .3 -> .2
+    assert abs(d[0].item() - 0.2) < 1e-6
+    assert abs(d[1].item() - 0.001) < 1e-6          # two candidates 1e-3 apart
+    assert abs(d[2].item() - 0.0095) < 1e-6         # best candidate .26 against the other model's best .2505: margin .0095 (threshold .25 is .01 away)
+    assert abs(d[3].item() - 0.05) < 1e-6           # .9 against "Others" .95 of the second model
+    single = decision_distance(pa, 2, None, None, [0.3, -1])
+    assert abs(single[0].item() - 0.2) < 1e-6 and abs(single[2].item() - 0.04) < 1e-6      # cell 2: |.26 - .3|
