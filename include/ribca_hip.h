@@ -213,7 +213,7 @@ int ribca_test_gemm_resid_ps_duo(const uint16_t* A, int32_t lda, const uint16_t*
                                  const float* prev, void* stream);
 /* The MX form of the residual GEMM (csrc/gemm_mx.hip; replaces timm Mlp.fc2 reached from reference model.py:54-55): A given as
  * packed-split rows is first converted to the three-plane MX3 format (hi_out [M][Kp128] fp16, l8_out [M][Kp128] bytes, sc_out
- * [M][Kp128 / 32] bytes, Kp128 = Kp rounded up to 128; all three are outputs the tests inspect), W to the MX weight image
+ * [Kp128 / 128][M][4] bytes, Kp128 = Kp rounded up to 128; all three are outputs the tests inspect), W to the MX weight image
  * (wh_scratch / wx_scratch: ribca_test_mx_weight_bytes), then z_ps = (z_ps - prev mean) + A W^T + bias with statistics per 48-column
  * block (part: (N / 48) * M float2).  N % 48 == 0. */
 int64_t ribca_test_mx_weight_bytes(int32_t N, int32_t Kp, int32_t which);
@@ -226,7 +226,7 @@ int ribca_test_gemm_mx_resid_packed(const uint16_t* hi, const uint8_t* l8, const
                                     int32_t M, int32_t N, const float* bias, uint16_t* z_ps, int32_t ldz, float* part, float* rowstat,
                                     const float* prev, void* stream);
 /* mlp.fc1 with the LayerNorm fold writing its GELU output straight in the MX3 format (csrc/gemm_duo.hip, EpiGeluMx): N % 128 == 0,
- * hi_out [M][N] fp16 (permuted inside every 128 columns), l8_out [M][N] bytes, sc_out [M][N / 32] bytes */
+ * hi_out [M][N] fp16 (permuted inside every 128 columns), l8_out [M][N] bytes, sc_out [N / 128][M][4] bytes */
 int ribca_test_gemm_gelu_mx(const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp, const float* bias2,
                             const float* csum, const float* rowstat, uint16_t* wf_scratch, uint16_t* hi_out, uint8_t* l8_out, uint8_t* sc_out,
                             void* stream);

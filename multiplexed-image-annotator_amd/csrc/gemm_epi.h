@@ -460,7 +460,7 @@ __device__ __forceinline__ void gelu_mx_epilogue(const EpiGeluMx& epi, int mbase
     if (ok) {
       *reinterpret_cast<u32x4*>(epi.out.hi + (size_t)m * Kp + hpos) = u32x4{rx[0], ry[0], rx[1], ry[1]};
       *reinterpret_cast<uint2*>(epi.out.l8 + (size_t)m * Kp + c8) = uint2{rl[0], rl[1]};
-      if (g == 0) epi.out.sc[(size_t)m * (Kp >> 5) + (n32 >> 5)] = (unsigned char)sl;
+      if (g == 0) epi.out.sc[((size_t)(n32 >> 7) * epi.out.M + m) * 4 + ((n32 >> 5) & 3)] = (unsigned char)sl;
     }
   }
 }

@@ -23,7 +23,7 @@
 //     sub-steps -- exactly the block the scaled MFMA wants in one lane, so the fp6 image of hi is ONE v_cvt_scalef32_pk32_fp6_f16 of
 //     registers the kernel has anyway (never stored);
 //   * lo plane  [M][Kp] bytes (e4m3, natural column order: a 128-deep step of a row is one 128-byte line);
-//   * scale plane [M][Kp / 32] bytes.
+//   * scale plane [Kp / 128][M][4] bytes (transposed: a K step's 128 rows x 4 bytes are contiguous).
 //   Weights (mx_pack_w_kernel, once per model): fragment order as in gemm_duo.hip, grouped by the 48 output columns (3 column tiles) one
 //   wave owns -- per group and 128 k: twelve 1 KB hi fragments [sub-step][tile], then the fp6 images of lo and hi (24 bytes per lane and
 //   tile, as 8 + 16) and 8 bytes of scale bytes per lane -- so that ONE scalar base per stream reaches a step's operands.
@@ -132,13 +132,17 @@ __device__ __forceinline__ void pin_acc(f32x4 (&acc)[1][MT][TN]) {
 
 // ----------------------------------------------------------------------------------------------------------- operand packers
 // bytes of the weight image per (48 output columns, 128 k): WH 12 x 1 KB of fp16 hi fragments [sub-step][tile];
-// WX: l6b [tile][64 x 8] | l6a [tile][64 x 16] | scale bytes 64 x 8 (sl0 sh0 sl1 sh1 | sl2 sh2 0 0) | h6b [tile][64 x 8] | h6a [tile][64 x 16]
-// (every piece within the 13-bit signed instruction offset of one of two scalar bases: the block's start and the start of h6a)
-constexpr int kMxWhBytes = 12288, kMxWxBytes = 9728;
-constexpr int kWxL6b = 0, kWxL6a = 1536, kWxSc = 4608, kWxH6b = 5120, kWxH6a = 6656;
+// WX (behind a 512-byte header per 48 columns): scale bytes 64 x 8 (sl0 sh0' sl1 sh1' | sl2 sh2' 0 0) | l6b [tile][64 x 8] | l6a [tile][64 x 16]
+// -- the fp6 image of W lo with its scale bytes sl, and the scale bytes sh' of the NEXT 128 k's hi image (the header holds those of the first):
+// a step's hi scale is needed at the top of the step, one MX phase before the words of its own block are waited for.  The fp6 image of W HI is not stored: the kernel holds a step's four hi fragments of a tile in registers anyway and
+// converts them itself (3 v_cvt_scalef32_pk32_fp6_f16 per wave and step instead of 4.6 KB of loads: the K loop is bound by the CU's
+// fetch path, profiles/r4/mx_kernel_ablations.txt).  Every piece lies within the 13-bit signed instruction offset of ONE scalar base
+// (block start + 1024).
+constexpr int kMxWhBytes = 12288, kMxWxBytes = 5120, kMxWxHeader = 512;
+constexpr int kWxBase = 1024, kWxSc = 0, kWxL6b = 512, kWxL6a = 2048;
 // (sized for whole 192-column tiles: the waves of a last tile that lie beyond N still stream their -- zero -- fragments)
 size_t mx_wh_bytes(int Np, int Kp) { return (size_t)((Np + 191) / 192 * 4) * (Kp / 128) * kMxWhBytes; }
-size_t mx_wx_bytes(int Np, int Kp) { return (size_t)((Np + 191) / 192 * 4) * (Kp / 128) * kMxWxBytes; }
+size_t mx_wx_bytes(int Np, int Kp) { return (size_t)((Np + 191) / 192 * 4) * ((size_t)(Kp / 128) * kMxWxBytes + kMxWxHeader); }
 
 // packed-split weight [Np][2 Kp] (Kp % 128 == 0, rows n >= N read as zeros by the caller's padding) -> WH / WX; one thread per
 // (output column, 32-k block); N48 = columns rounded up to whole 192-column tiles: columns beyond Np are written as zeros
@@ -148,7 +152,7 @@ __global__ void mx_pack_w_kernel(const uint16_t* __restrict__ W, int ldw, int Np
   if (idx >= (long long)N48 * nq) return;
   const int n = (int)(idx / nq), q = (int)(idx - (long long)n * nq);
   const int jb = n / 48, j = (n - 48 * jb) >> 4, r16 = n & 15, b = q >> 2, g = q & 3, lane = g * 16 + r16, nb = Kp / 128;
-  h32 hv, lv;
+  h32 lv;
   unsigned mh = 0, ml = 0;
   uint4 hraw[4] = {};
   if (n < Np) {
@@ -159,32 +163,37 @@ __global__ void mx_pack_w_kernel(const uint16_t* __restrict__ W, int ldw, int Np
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const uint16_t hb = src[16 * t + e], lb = src[16 * t + 8 + e];
-        hv[8 * t + e] = __builtin_bit_cast(_Float16, hb);
         lv[8 * t + e] = __builtin_bit_cast(_Float16, lb);
         mh = max(mh, (unsigned)(hb & 0x7fff)); ml = max(ml, (unsigned)(lb & 0x7fff));
       }
     }
   } else {
 #pragma unroll
-    for (int e = 0; e < 32; ++e) { hv[e] = (_Float16)0.f; lv[e] = (_Float16)0.f; }
+    for (int e = 0; e < 32; ++e) lv[e] = (_Float16)0.f;
   }
   // both images scaled so that the block's largest magnitude lands in [4, 8): the weights are packed once, so lo gets its own exponent
   int eh = (int)(mh >> 10), el = (int)(ml >> 10);
   eh = eh < 1 ? 1 : eh; el = el < 1 ? 1 : el;
   const int sh = eh + 110, sl = el + 110;      // E - 2 + 127, E = ef - 15
-  const u32x6 h6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(hv, e8m0_float(sh));
   const u32x6 l6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(lv, e8m0_float(sl));
   const size_t blk = (size_t)jb * nb + b;
   unsigned char* wh = reinterpret_cast<unsigned char*>(WH) + blk * kMxWhBytes + j * 1024 + lane * 16;
 #pragma unroll
   for (int t = 0; t < 4; ++t) *reinterpret_cast<uint4*>(wh + t * 3072) = hraw[t];
-  unsigned char* wx = WX + blk * kMxWxBytes;
+  unsigned char* wxj = WX + (size_t)jb * ((size_t)nb * kMxWxBytes + kMxWxHeader);      // this 48-column group: header, then nb blocks
+  unsigned char* wx = wxj + kMxWxHeader + (size_t)b * kMxWxBytes;
   *reinterpret_cast<uint2*>(wx + kWxL6b + j * 512 + lane * 8) = uint2{l6[4], l6[5]};
   *reinterpret_cast<uint4*>(wx + kWxL6a + j * 1024 + lane * 16) = uint4{l6[0], l6[1], l6[2], l6[3]};
-  *reinterpret_cast<uint2*>(wx + kWxH6b + j * 512 + lane * 8) = uint2{h6[4], h6[5]};
-  *reinterpret_cast<uint4*>(wx + kWxH6a + j * 1024 + lane * 16) = uint4{h6[0], h6[1], h6[2], h6[3]};
-  *reinterpret_cast<uint16_t*>(wx + kWxSc + lane * 8 + j * 2) = (uint16_t)((unsigned)sl | ((unsigned)sh << 8));
-  if (j == 2) *reinterpret_cast<uint16_t*>(wx + kWxSc + lane * 8 + 6) = 0;
+  wx[kWxSc + lane * 8 + j * 2] = (unsigned char)sl;
+  // the hi image's scale byte goes into the PREVIOUS block's word (the header for the first block)
+  unsigned char* prev = b == 0 ? wxj : wxj + kMxWxHeader + (size_t)(b - 1) * kMxWxBytes + kWxSc;
+  prev[lane * 8 + j * 2 + 1] = (unsigned char)sh;
+  if (b == nb - 1) wx[kWxSc + lane * 8 + j * 2 + 1] = 0;
+  if (b == 0) wxj[lane * 8 + j * 2] = 0;
+  if (j == 2) {
+    *reinterpret_cast<uint16_t*>(wx + kWxSc + lane * 8 + 6) = 0;
+    if (b == 0) *reinterpret_cast<uint16_t*>(wxj + lane * 8 + 6) = 0;
+  }
 }
 void launch_mx_pack_w(const uint16_t* W, int ldw, int Np, int Kp, uint16_t* WH, unsigned char* WX, hipStream_t s) {
   const int N48 = (Np + 191) / 192 * 192;
@@ -233,7 +242,7 @@ __global__ void mx_pack_act_kernel(const uint16_t* __restrict__ ps, int ldps, in
   uint4* lrow = reinterpret_cast<uint4*>(l8 + (size_t)m * Kp128 + 32 * q);
   lrow[0] = uint4{out8[0], out8[1], out8[2], out8[3]};
   lrow[1] = uint4{out8[4], out8[5], out8[6], out8[7]};
-  sc[(size_t)m * nq + q] = (unsigned char)sl;
+  sc[((size_t)(q >> 2) * M + m) * 4 + (q & 3)] = (unsigned char)sl;
 }
 void launch_mx_pack_act(const uint16_t* ps, int ldps, int M, int Kp, const MxAct& a, hipStream_t s) {
   const long long total = (long long)M * (a.Kp / 32);
@@ -246,7 +255,7 @@ void launch_mx_pack_act(const uint16_t* ps, int ldps, int M, int Kp, const MxAct
 #endif
 namespace {
 constexpr int MX_BM = 128, MX_BN = 192, MX_MT = 8, MX_TN = 3;
-// LDS map: the fp6 rows sit right behind the hi slots so that one per-lane address register (plus instruction offsets < 64 KB) reaches both
+// LDS map: hi as two halves of 128 rows x 128 bytes (sub-steps 0-1 | 2-3), the fp6 rows, two scale slots, two lo slots
 constexpr int L_HI = 0, L_H6A = 32768, L_H6B = 40960, L_SC = 45056, L_SC_SLOT = 640, L_L8 = L_SC + 2 * L_SC_SLOT, L_TOTAL = L_L8 + 32768;
 static_assert(L_L8 % 16 == 0, "LDS-DMA destination alignment");
 __device__ __forceinline__ int mx_f4(int row) { return (4 - ((row >> 2) & 3)) & 3; }      // chunk swizzle of the 64-byte hi rows
@@ -284,28 +293,31 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
   // ---- descriptors over the tile's rows of the three planes (rows beyond M read as zeros) and of the residual stream
   const __amdgpu_buffer_rsrc_t hi_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.hi + (size_t)m0 * Kp, 0, rows_here * Kp * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t l8_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.l8 + (size_t)m0 * Kp, 0, rows_here * Kp, 0x00020000);
-  const __amdgpu_buffer_rsrc_t sc_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.sc + (size_t)m0 * (Kp >> 5), 0, rows_here * (Kp >> 5), 0x00020000);
+  // (plane b of the transposed scale bytes starts b * M * 4 bytes further: rows beyond the tile read the next rows' bytes or, at the very end of the
+  // buffer, zeros -- they belong to rows that are never stored)
+  const __amdgpu_buffer_rsrc_t sc_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.sc + (size_t)m0 * 4, 0, ((nb - 1) * A.M + (A.M - m0)) * 4, 0x00020000);
   // (a copy: naming epi inside a lambda that a generic lambda calls makes hipcc drop the kernel's HOST stub without a diagnostic -- the library
   // then fails to load with an undefined symbol)
   const int ldz_ = epi.ldz;
   int hi_voff, l8_voff, sc_voff;
   {
-    const int hrow = wave * 32 + (lane >> 2);                      // + 16 for the wave's second instruction (same swizzle)
-    hi_voff = hrow * Kp * 2 + (((lane & 3) ^ mx_f4(hrow)) << 4);
+    const int hrow = wave * 8 + (lane >> 3);                       // + 32 i for the wave's other groups (same swizzle): 8 rows x 128 bytes per piece
+    hi_voff = hrow * Kp * 2 + (((lane & 7) ^ mx_f8(hrow)) << 4);
     const int drow = wave * 8 + (lane >> 3);                       // + 32 i for the wave's other groups (same swizzle)
     l8_voff = drow * Kp + (((lane & 7) ^ mx_f8(drow)) << 4);
-    sc_voff = (wave * 32 + lane) * (Kp >> 5);
+    sc_voff = (wave * 32 + lane) * 4;
   }
-  auto issue_hi = [&](int b) {      // the four hi units of step b: 8 operations per wave
+  auto issue_hi = [&](int b) {      // the hi columns of step b as two halves of 64 columns (sub-steps 0-1, 2-3): 8 operations per wave
 #ifdef MXDBG_NOA
     return;
 #endif
+    // whole 128-byte lines per row and piece: a sub-step's 64 bytes alone would request every line twice, half at a time
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(hi_rsrc, (__attribute__((address_space(3))) void*)(smem + L_HI + s * 8192 + wave * 2048 + u * 1024), 16,
-                                                 hi_voff, u * 16 * Kp * 2 + b * 256 + s * 64, 0, 0);
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(hi_rsrc, (__attribute__((address_space(3))) void*)(smem + L_HI + h * 16384 + wave * 1024 + i * 4096), 16,
+                                                 hi_voff, i * 32 * Kp * 2 + b * 256 + h * 128, 0, 0);
   };
   auto issue_l8 = [&](int b) {      // lo unit + scale unit of step b: 5 operations per wave
 #ifdef MXDBG_NOA
@@ -317,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
       __builtin_amdgcn_raw_ptr_buffer_load_lds(l8_rsrc, (__attribute__((address_space(3))) void*)(st + i * 4096), 16, l8_voff, i * 32 * Kp + b * 128, 0, 0);
     // 64 rows per wave from row 32 w: the upper half repeats what the next wave writes (the same bytes) and the last wave's spills into the slot's pad
     __builtin_amdgcn_raw_ptr_buffer_load_lds(sc_rsrc, (__attribute__((address_space(3))) void*)(smem + L_SC + (b & 1) * L_SC_SLOT + wave * 128), 4, sc_voff,
-                                             b * 4, 0, 0);
+                                             b * A.M * 4, 0, 0);
   };
   auto issue_z = [&](int t, int slot_off) {      // 32 columns of the residual tile (packed-split: 128 bytes per row): 4 operations per wave
     char* st = smem + slot_off + wave * 1024;
@@ -335,11 +347,14 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
   const unsigned wvoff16 = (unsigned)lane * 16u, wvoff8 = (unsigned)lane * 8u;
   const size_t jb = (size_t)(n0 / 48) + (size_t)wn;
   const char* whb = reinterpret_cast<const char*>(WH) + jb * (size_t)nb * kMxWhBytes;
-  const char* wxb = reinterpret_cast<const char*>(WX) + jb * (size_t)nb * kMxWxBytes;
+  const char* wxh = reinterpret_cast<const char*>(WX) + jb * ((size_t)nb * kMxWxBytes + kMxWxHeader);      // header: hi scale bytes of step 0
+  const char* wxb = wxh + kMxWxHeader;
   f16x8 whi[4][TN];      // one set per sub-step, refilled for the NEXT 128-deep step right behind its last use
-  u32v4 wl6a[TN], wh6a[TN];
-  u32v2 wl6b[TN], wh6b[TN];
-  u32v2 wsc;      // bytes: sl0 sh0 sl1 sh1 | sl2 sh2 - -
+  u32v4 wl6a[TN];
+  u32v2 wl6b[TN];
+  u32x6 wh6r[TN];      // fp6 images of W hi, converted from the four resident hi sets at the top of every step
+  u32v2 wsc;      // bytes: sl0 sh0' sl1 sh1' | sl2 sh2' - -   (sl: this step's lo image, sh': the NEXT step's hi image)
+  u32v2 wsh;      // the hi scale bytes of the current step (taken out of wsc before the next block's words are requested into it)
   auto issue_whi = [&](int t, f16x8 (&dst)[TN]) {      // sub-step t = 4 b + s of the K loop: 3 operations
 #ifdef MXDBG_NOW
     return;
@@ -349,18 +364,16 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
     gld16h<1024>(dst[1], wvoff16, p);
     gld16h<2048>(dst[2], wvoff16, p);
   };
-  auto issue_wx = [&](int b) {                          // 13 operations
+  auto issue_wx = [&](int b) {                          // 7 operations
 #ifdef MXDBG_NOW
     return;
 #endif
-    const unsigned long long p = uniform_ptr(wxb + (size_t)b * kMxWxBytes), p2 = uniform_ptr(wxb + (size_t)b * kMxWxBytes + kWxH6a);
-    gld8<kWxL6b>(wl6b[0], wvoff8, p); gld8<kWxL6b + 512>(wl6b[1], wvoff8, p); gld8<kWxL6b + 1024>(wl6b[2], wvoff8, p);
-    gld16<kWxL6a>(wl6a[0], wvoff16, p); gld16<kWxL6a + 1024>(wl6a[1], wvoff16, p); gld16<kWxL6a + 2048>(wl6a[2], wvoff16, p);
-    gld8<kWxH6b - kWxH6a>(wh6b[0], wvoff8, p2); gld8<kWxH6b - kWxH6a + 512>(wh6b[1], wvoff8, p2); gld8<kWxH6b - kWxH6a + 1024>(wh6b[2], wvoff8, p2);
-    gld16<0>(wh6a[0], wvoff16, p2); gld16<1024>(wh6a[1], wvoff16, p2); gld16<2048>(wh6a[2], wvoff16, p2);
-    gld8<kWxSc - kWxH6a>(wsc, wvoff8, p2);
+    const unsigned long long p = uniform_ptr(wxb + (size_t)b * kMxWxBytes + kWxBase);
+    gld8<kWxL6b - kWxBase>(wl6b[0], wvoff8, p); gld8<kWxL6b - kWxBase + 512>(wl6b[1], wvoff8, p); gld8<kWxL6b - kWxBase + 1024>(wl6b[2], wvoff8, p);
+    gld16<kWxL6a - kWxBase>(wl6a[0], wvoff16, p); gld16<kWxL6a - kWxBase + 1024>(wl6a[1], wvoff16, p); gld16<kWxL6a - kWxBase + 2048>(wl6a[2], wvoff16, p);
+    gld8<kWxSc - kWxBase>(wsc, wvoff8, p);
   };
-  constexpr int NWX = 13;
+  constexpr int NWX = 7;
 
   f32x4 acc[1][MT][TN];
 #pragma unroll
@@ -370,12 +383,17 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
 
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   // per-lane read addresses (row tile i adds 16 rows)
-  const unsigned rd_hi = lds_base + L_HI + (unsigned)(r16 * 64 + ((g ^ mx_f4(r16)) << 4));                 // + 1024 i + 8192 s
+  // hi rows are 128 bytes = two sub-steps: sub-step s reads chunk 4 (s & 1) + g of half s >> 1   (+ 2048 i + 16384 (s >> 1), second sub-step at ^ 64)
+  const unsigned rd_hi = lds_base + L_HI + (unsigned)(r16 * 128 + ((g ^ mx_f8(r16)) << 4));
+  const unsigned rd_h6a = lds_base + L_H6A + (unsigned)(r16 * 64 + ((g ^ mx_f4(r16)) << 4));               // + 1024 i
   const unsigned rd_l8 = lds_base + (unsigned)(r16 * 128 + ((g ^ mx_f8(r16)) << 4));      // 128-byte lo rows: + 2048 i + slot; chunk g + 4 at ^ 64
   const unsigned rd_h6b = lds_base + L_H6B + (unsigned)(r16 * 32 + ((g ^ (2 * ((r16 >> 3) & 1))) << 3));  // + 512 i
   const unsigned rd_sc = lds_base + L_SC + (unsigned)(r16 * 4 + g);                                        // + 64 i + slot
 
   // ---- prologue
+#ifndef MXDBG_NOW
+  gld8<0>(wsh, wvoff8, uniform_ptr(wxh));
+#endif
   issue_whi(0, whi[0]);
   issue_whi(1, whi[1]);
   issue_whi(2, whi[2]);
@@ -388,29 +406,46 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
   // (the last step is its own instance: "more" is a compile-time constant, so no phase is cut into basic blocks by the requests for the next step)
   auto step = [&](auto more_c, int b) {
     constexpr bool more = decltype(more_c)::value;
-    // B1: hi units, lo / scale unit and the four W hi sets of this step have landed (only the 13 operations of W's fp6 images are younger)
+    // B1: hi units, lo / scale unit and the four W hi sets of this step have landed (only the 7 operations of W's fp6 lo image and scale bytes are younger)
     wait_vmcnt<NWX>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    // the fp6 image of this step's W hi, from the four resident fragment sets (they are refilled for the next step right behind their last use,
+    // so now is the moment); scale byte = the packer's sh of the tile, which travelled with the PREVIOUS block's words (wsh)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(whi[s4][j]));
+    asm volatile("" : "+v"(wsh));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      h32 hv;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hv[8 * s4 + e] = whi[s4][j][e];
+      const unsigned shb = (j == 0 ? (wsh[0] >> 8) : j == 1 ? (wsh[0] >> 24) : (wsh[1] >> 8)) & 0xffu;
+      wh6r[j] = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(hv, e8m0_float((int)shb));
+    }
     sfor<4>([&](auto s_c) {
       constexpr int S = decltype(s_c)::value;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(whi[S][j]));
       __builtin_amdgcn_sched_barrier(0);
       // A hi fragments PF row tiles ahead of their MFMAs: a row tile is 3 MFMAs = 48 cycles here (the fp16x3 kernels: 9), less than one LDS
       // round trip -- with the next tile's read as the only one in flight every iteration waited for it (timing ablation without any
       // global load: 2.2 x the matrix time)
       constexpr int PF = MXDBG_PF;
       f16x8 ah[PF + 1];
+      const unsigned rd_s = (S & 1) ? (rd_hi ^ 64u) : rd_hi;
+      constexpr int HOFF = (S >> 1) * 16384;
       sfor<PF>([&](auto pc) {
         constexpr int q = decltype(pc)::value;
-        lds_rd128h<S * 8192 + q * 1024>(ah[q], rd_hi);
+        lds_rd128h<HOFF + q * 2048>(ah[q], rd_s);
       });
       sfor<MT>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int cur = i % (PF + 1);
         if constexpr (i + PF < MT) {
-          lds_rd128h<S * 8192 + (i + PF) * 1024>(ah[(i + PF) % (PF + 1)], rd_hi);
+          lds_rd128h<HOFF + (i + PF) * 2048>(ah[(i + PF) % (PF + 1)], rd_s);
           asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ah[cur]) : "n"(PF) : "memory");
         } else {
           asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ah[cur]) : "n"(MT - 1 - i) : "memory");
@@ -432,16 +467,16 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
 #ifndef MXDBG_NOCONV
     // ---- conversion: this wave turns the hi rows of row tiles 2 w, 2 w + 1 into fp6 for everybody
     {
-      const unsigned cv_hi = rd_hi + (unsigned)(wave * 2048), cv_sc = rd_sc + (unsigned)(wave * 128 + (b & 1) * L_SC_SLOT);
-      const unsigned cv_b = rd_h6b + (unsigned)(wave * 1024);
+      const unsigned cv_hi = rd_hi + (unsigned)(wave * 4096), cv_hi1 = cv_hi ^ 64u, cv_sc = rd_sc + (unsigned)(wave * 128 + (b & 1) * L_SC_SLOT);
+      const unsigned cv_a = rd_h6a + (unsigned)(wave * 2048), cv_b = rd_h6b + (unsigned)(wave * 1024);
       sfor<2>([&](auto u_c) {
         constexpr int U = decltype(u_c)::value;
         f16x8 h[4];
         unsigned sb;
-        lds_rd128h<U * 1024>(h[0], cv_hi);
-        lds_rd128h<U * 1024 + 8192>(h[1], cv_hi);
-        lds_rd128h<U * 1024 + 16384>(h[2], cv_hi);
-        lds_rd128h<U * 1024 + 24576>(h[3], cv_hi);
+        lds_rd128h<U * 2048>(h[0], cv_hi);
+        lds_rd128h<U * 2048>(h[1], cv_hi1);
+        lds_rd128h<U * 2048 + 16384>(h[2], cv_hi);
+        lds_rd128h<U * 2048 + 16384>(h[3], cv_hi1);
         lds_rd8<U * 64>(sb, cv_sc);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(sb)::"memory");
         h32 hv;
@@ -450,7 +485,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
 #pragma unroll
           for (int e = 0; e < 8; ++e) hv[8 * s + e] = h[s][e];
         const u32x6 c = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(hv, e8m0_float((int)sb + kMxShDelta));
-        lds_wr128<L_H6A + U * 1024>(cv_hi, u32v4{c[0], c[1], c[2], c[3]});
+        lds_wr128<U * 1024>(cv_a, u32v4{c[0], c[1], c[2], c[3]});
         lds_wr64<U * 512>(cv_b, u32v2{c[4], c[5]});
       });
     }
@@ -476,24 +511,27 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
     // ---- MX phase
 #ifndef MXDBG_NOMX
 #pragma unroll
-    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(wl6a[j]), "+v"(wl6b[j]), "+v"(wh6a[j]), "+v"(wh6b[j]));
+    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(wl6a[j]), "+v"(wl6b[j]));
     asm volatile("" : "+v"(wsc));
     i32x8 wl6[TN], wh6[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { wl6[j] = op6(wl6a[j], wl6b[j]); wh6[j] = op6(wh6a[j], wh6b[j]); }
+    for (int j = 0; j < TN; ++j) {
+      wl6[j] = op6(wl6a[j], wl6b[j]);
+      wh6[j] = __builtin_bit_cast(i32x8, __builtin_shufflevector(wh6r[j], wh6r[j], 0, 1, 2, 3, 4, 5, -1, -1));
+    }
     {
       const unsigned m_l8a = rd_l8 + (unsigned)(L_L8 + (b & 1) * 16384), m_l8b = m_l8a ^ 64u;
       const unsigned m_sc = rd_sc + (unsigned)((b & 1) * L_SC_SLOT);
       u32v4 la[2], lb[2], ha[2];
       u32v2 hb[2];
       unsigned sb[2];
-      lds_rd128<0>(la[0], m_l8a); lds_rd128<0>(lb[0], m_l8b); lds_rd128<L_H6A>(ha[0], rd_hi); lds_rd64<0>(hb[0], rd_h6b); lds_rd8<0>(sb[0], m_sc);
+      lds_rd128<0>(la[0], m_l8a); lds_rd128<0>(lb[0], m_l8b); lds_rd128<0>(ha[0], rd_h6a); lds_rd64<0>(hb[0], rd_h6b); lds_rd8<0>(sb[0], m_sc);
       sfor<MT>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int cur = i & 1, nxt = cur ^ 1;
         if constexpr (i + 1 < MT) {
           lds_rd128<(i + 1) * 2048>(la[nxt], m_l8a); lds_rd128<(i + 1) * 2048>(lb[nxt], m_l8b);
-          lds_rd128<L_H6A + (i + 1) * 1024>(ha[nxt], rd_hi); lds_rd64<(i + 1) * 512>(hb[nxt], rd_h6b); lds_rd8<(i + 1) * 64>(sb[nxt], m_sc);
+          lds_rd128<(i + 1) * 1024>(ha[nxt], rd_h6a); lds_rd64<(i + 1) * 512>(hb[nxt], rd_h6b); lds_rd8<(i + 1) * 64>(sb[nxt], m_sc);
           asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(la[cur]), "+v"(lb[cur]), "+v"(ha[cur]), "+v"(hb[cur]), "+v"(sb[cur])::"memory");
         } else {
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(la[cur]), "+v"(lb[cur]), "+v"(ha[cur]), "+v"(hb[cur]), "+v"(sb[cur])::"memory");
@@ -501,9 +539,9 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
         const i32x8 al8 = op8(la[cur], lb[cur]), ah6 = op6(ha[cur], hb[cur]);
         const int asc = (int)(sb[cur] | ((sb[cur] + kMxShDelta) << 8));      // byte 0: lo scale, byte 1: fp6-hi scale
         // W hi' (fp6, its sh byte) x A lo (fp8, byte 0);  W lo' (fp6, its sl byte) x A hi' (fp6, byte 1)
-        acc[0][i][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wh6[0], al8, acc[0][i][0], 2, 0, 1, (int)wsc[0], 0, asc);
-        acc[0][i][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wh6[1], al8, acc[0][i][1], 2, 0, 3, (int)wsc[0], 0, asc);
-        acc[0][i][2] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wh6[2], al8, acc[0][i][2], 2, 0, 1, (int)wsc[1], 0, asc);
+        acc[0][i][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wh6[0], al8, acc[0][i][0], 2, 0, 1, (int)wsh[0], 0, asc);
+        acc[0][i][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wh6[1], al8, acc[0][i][1], 2, 0, 3, (int)wsh[0], 0, asc);
+        acc[0][i][2] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wh6[2], al8, acc[0][i][2], 2, 0, 1, (int)wsh[1], 0, asc);
         acc[0][i][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wl6[0], ah6, acc[0][i][0], 2, 2, 0, (int)wsc[0], 1, asc);
         acc[0][i][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wl6[1], ah6, acc[0][i][1], 2, 2, 2, (int)wsc[0], 1, asc);
         acc[0][i][2] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wl6[2], ah6, acc[0][i][2], 2, 2, 0, (int)wsc[1], 1, asc);
@@ -512,6 +550,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
     }
     pin_acc(acc);
 #endif
+    wsh = wsc;      // the next step's hi scale bytes, before the next block's words are requested into wsc
+    asm volatile("" : "+v"(wsh));
     if constexpr (more) issue_wx(b + 1);
     __builtin_amdgcn_sched_barrier(0);
   };

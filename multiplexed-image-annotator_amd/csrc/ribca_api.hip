@@ -369,7 +369,7 @@ void run_block_fold(const BlockW& L, const BlockWs& w, int cells, const AttnGeom
     // the MX pair: fc1's GELU epilogue emits the three-plane operand (3 bytes per element, carved out of the h buffer), fc2 multiplies it
     // as fp16 hi * hi + two block-scaled corrections (gemm_mx.hip)
     const size_t hn = (size_t)Mc * 4 * D;
-    const MxAct hmx{w.h, reinterpret_cast<unsigned char*>(w.h + hn), reinterpret_cast<unsigned char*>(w.h + hn) + hn, 4 * D};
+    const MxAct hmx{w.h, reinterpret_cast<unsigned char*>(w.h + hn), reinterpret_cast<unsigned char*>(w.h + hn) + hn, 4 * D, Mc};
     {
       ProfScope ps(P_FC1, s);
       GemmArgs g{w.zps, ld_x, L.fc1w, ld_x, Mc, 4 * D, Dp, L.fc1b2, L.fc1wf};
@@ -930,7 +930,7 @@ int64_t ribca_test_mx_weight_bytes(int32_t N, int32_t Kp, int32_t which) {
 int ribca_test_mx_pack_act(const uint16_t* A, int32_t lda, int32_t M, int32_t Kp, uint16_t* hi_out, uint8_t* l8_out, uint8_t* sc_out, void* stream) {
   if (!A || !hi_out || !l8_out || !sc_out) return fail("ribca_test_mx_pack_act: NULL buffer");
   if (Kp % 32 != 0) return fail("ribca_test_mx_pack_act: Kp must be a multiple of 32");
-  const MxAct a{hi_out, l8_out, sc_out, round_up(Kp, 128)};
+  const MxAct a{hi_out, l8_out, sc_out, round_up(Kp, 128), M};
   launch_mx_pack_act(A, lda, M, Kp, a, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -941,7 +941,7 @@ int ribca_test_gemm_mx_resid(const uint16_t* A, int32_t lda, const uint16_t* W, 
   if (!gemm_mx_supported(N, Kp)) return fail("ribca_test_gemm_mx_resid: N must be a multiple of 48 and Kp of 128");
   if ((rowstat != nullptr) != (part != nullptr)) return fail("ribca_test_gemm_mx_resid: part and rowstat go together");
   hipStream_t s = (hipStream_t)stream;
-  const MxAct a{hi_out, l8_out, sc_out, Kp};
+  const MxAct a{hi_out, l8_out, sc_out, Kp, M};
   launch_mx_pack_act(A, lda, M, Kp, a, s);
   launch_mx_pack_w(W, ldw, (N + 15) / 16 * 16, Kp, wh_scratch, wx_scratch, s);
   const MxWeight w{wh_scratch, wx_scratch};
@@ -956,7 +956,7 @@ int ribca_test_gemm_mx_resid_packed(const uint16_t* hi, const uint8_t* l8, const
   if (!gemm_mx_supported(N, Kp)) return fail("ribca_test_gemm_mx_resid_packed: N must be a multiple of 48 and Kp of 128");
   if ((rowstat != nullptr) != (part != nullptr)) return fail("ribca_test_gemm_mx_resid_packed: part and rowstat go together");
   hipStream_t s = (hipStream_t)stream;
-  const MxAct a{const_cast<uint16_t*>(hi), const_cast<uint8_t*>(l8), const_cast<uint8_t*>(sc), Kp};
+  const MxAct a{const_cast<uint16_t*>(hi), const_cast<uint8_t*>(l8), const_cast<uint8_t*>(sc), Kp, M};
   const MxWeight w{wh, wx};
   const ResidStatGeom sg = launch_gemm_mx_resid(a, w, M, N, bias, z_ps, ldz, reinterpret_cast<float2*>(part), reinterpret_cast<const float2*>(prev), 1, s);
   if (rowstat) launch_ln_finalize(reinterpret_cast<const float2*>(part), sg.tiles, M, sg.bn, N, reinterpret_cast<float2*>(rowstat), s);
@@ -969,7 +969,7 @@ int ribca_test_gemm_gelu_mx(const uint16_t* z_ps, int32_t lda, const uint16_t* W
   if (!wf_scratch || !csum || !rowstat) return fail("ribca_test_gemm_gelu_mx: NULL buffer");
   launch_pack_wf(W, ldw, gemm_padded_n(N), Kp, wf_scratch, (hipStream_t)stream);
   GemmArgs g{z_ps, lda, W, ldw, M, N, Kp, bias2, wf_scratch};
-  const MxAct out{hi_out, l8_out, sc_out, N};
+  const MxAct out{hi_out, l8_out, sc_out, N, M};
   if (!launch_gemm_gelu_mx(g, reinterpret_cast<const float2*>(rowstat), csum, out, (hipStream_t)stream))
     return fail("ribca_test_gemm_gelu_mx: N must be a multiple of 128");
   HIP_TRY(hipGetLastError());

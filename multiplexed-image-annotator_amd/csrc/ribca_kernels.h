@@ -65,8 +65,10 @@ void launch_gemm_rowmap(const GemmArgs& g, float* out, int ldo, const float* add
                         int dst_per_cell, hipStream_t s);
 
 // ----- MX GEMM (gemm_mx.hip): fp16 hi * hi + two block-scaled correction products; activations in the three-plane "MX3" format
-// (hi fp16 permuted inside every 128 columns, lo as e4m3 bytes, one E8M0 scale byte per 32 columns -- see gemm_mx.hip), Kp % 128 == 0
-struct MxAct { uint16_t* hi; unsigned char* l8; unsigned char* sc; int Kp; };
+// (hi fp16 permuted inside every 128 columns, lo as e4m3 bytes, one E8M0 scale byte per 32 columns -- see gemm_mx.hip), Kp % 128 == 0.
+// The scale plane is TRANSPOSED, [Kp / 128][M][4]: the 128 rows x 4 bytes a K step needs are 512 contiguous bytes (four lines), not 128
+// pieces of four bytes one row pitch apart.
+struct MxAct { uint16_t* hi; unsigned char* l8; unsigned char* sc; int Kp; int M; };
 struct MxWeight { const uint16_t* wh; const unsigned char* wx; };     // mx_pack_w image of a packed-split weight [Np][2 Kp]
 size_t mx_wh_bytes(int Np, int Kp);
 size_t mx_wx_bytes(int Np, int Kp);

@@ -29,6 +29,11 @@ def _planes(m, kp128, dev):
             torch.zeros((m, kp128 // 32), dtype=torch.uint8, device=dev))
 
 
+def _scales(sc, m):
+    """the device's transposed scale plane [Kp / 128][M][4] -> [M, Kp / 32] (numpy uint8)"""
+    return sc.view(-1, m, 4).permute(1, 0, 2).reshape(m, -1).cpu().numpy()
+
+
 @pytest.mark.parametrize("m,k", [(37, 96), (130, 288), (257, 1152), (64, 2304)])
 def test_mx_pack_act(dev, m, k):
     """packed-split rows -> MX3 planes: permuted hi plane, e4m3 lo bytes, E8M0 scale bytes, all bit for bit; rows with tiny, huge and
@@ -48,7 +53,7 @@ def test_mx_pack_act(dev, m, k):
     lo_pad = np.zeros((m, kp128), np.float64); lo_pad[:, :kp] = lo16.astype(np.float64)
     plane, _, q, sl = mx.pack_act(hi_pad, lo_pad)
     assert np.array_equal(hi_p.cpu().numpy().view(np.float16).view(np.uint16), plane.view(np.uint16))
-    assert np.array_equal(sc_p.cpu().numpy(), sl)
+    assert np.array_equal(_scales(sc_p, m), sl)
     got = mx.e4m3_decode(l8_p.cpu().numpy())
     assert np.array_equal(got, q), np.abs(got - q).max()
     assert np.abs(q).max() <= 256.0      # the scale rule keeps lo / scale away from the e4m3 maximum (the conversion does not saturate)
@@ -140,14 +145,14 @@ def test_gemm_gelu_mx(dev, m, d, mean, std):
     assert frac < 0.03, frac
     # where they differ: by one e4m3 step at that magnitude (subnormal step 2^-9 below 2^-6), plus -- for lo below the fp16 normal
     # range, i.e. |x| < 0.25 -- the 2^-24 quantum of the detour's fp16 lo, which the fused epilogue (fp32 lo) does not have
-    scale_e = np.repeat(2.0 ** (sc_p.cpu().numpy().astype(np.float64) - 127), 32, axis=1)
+    scale_e = np.repeat(2.0 ** (_scales(sc_p, m).astype(np.float64) - 127), 32, axis=1)
     step = np.maximum(np.abs(want), 2.0 ** -6) * 2.0 ** -3
     assert np.all((np.abs(got - want) * scale_e)[diff] <= (step * scale_e)[diff] * 1.01 + 2.0 ** -24)
     # and the operand as fc2 will see it against the exact product
     ln = torch.nn.functional.layer_norm(zq, (d,), g.double(), b.double(), 1e-6)
     ref = torch.nn.functional.gelu(ln @ w.double().t() + bias.double()).cpu().numpy()
     hi = hi_p.cpu().numpy().view(np.float16)[:, mx.hi_pos(np.arange(n))].astype(np.float64)
-    scale = 2.0 ** (sc_p.cpu().numpy().astype(np.float64) - 127)
+    scale = 2.0 ** (_scales(sc_p, m).astype(np.float64) - 127)
     val = hi + (got.reshape(m, n // 32, 32) * scale[:, :, None]).reshape(m, n)
     err = np.abs(val - ref).max()
     note_err(f"gelu_mx hi + lo vs exact {m}x{n}x{d} mean {mean}", err)
