@@ -93,6 +93,9 @@ int ribca_norm_finalize(float* x, int32_t planes, int64_t hw, const int32_t* mod
 /* 1 if classifiers of width D run mlp.fc1 -> mlp.fc2 as the MX pair (csrc/gemm_mx.hip: fp16 hi * hi + two block-scaled corrections, 1.75
  * matrix units per product and 3 bytes per element of h instead of 3 passes / 4 bytes): 4 D % 128 == 0, D % 48 == 0 and RIBCA_MX != 0 */
 int32_t ribca_mx_enabled(int32_t D);
+/* 1 if, beyond that, the residual rows of a classifier of width D are ALSO kept in the MX3 format and attn.qkv (where it is a GEMM of its own)
+ * and mlp.fc1 run on the MX kernel too: ribca_mx_enabled(D), D % 192 == 0 and RIBCA_MXZ != 0 */
+int32_t ribca_mxz_enabled(int32_t D);
 int64_t ribca_vit_blob_len(int32_t D, int32_t C, int32_t K, int32_t depth);
 
 /* Replaces Annotator.load_models for one model: repacks the fp32 parameters (device blob) into the MFMA layouts.
@@ -230,6 +233,25 @@ int ribca_test_gemm_mx_resid_packed(const uint16_t* hi, const uint8_t* l8, const
 int ribca_test_gemm_gelu_mx(const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp, const float* bias2,
                             const float* csum, const float* rowstat, uint16_t* wf_scratch, uint16_t* hi_out, uint8_t* l8_out, uint8_t* sc_out,
                             void* stream);
+/* mlp.fc1 on the MX kernel (csrc/gemm_mx.hip, EpiGeluMx with 48-column wave blocks): z_ps (packed-split, Kp columns, Kp % 32 == 0) is first
+ * converted to MX3 (a_hi / a_l8 / a_sc: scratch planes with Kp rounded up to 128 columns) and W to the MX weight image of that padded K
+ * (ribca_test_mx_weight_bytes(N, Kp128, .)); outputs as ribca_test_gemm_gelu_mx.  N % 192 == 0. */
+int ribca_test_gemm_mx_fc1(const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp, const float* bias2,
+                           const float* csum, const float* rowstat, uint16_t* a_hi, uint8_t* a_l8, uint8_t* a_sc, uint16_t* wh_scratch,
+                           uint8_t* wx_scratch, uint16_t* hi_out, uint8_t* l8_out, uint8_t* sc_out, void* stream);
+/* ribca_test_qkv_attention_fold with the qkv product on the MX kernel (scratch planes / images as above, N = 3 D, (3 D) % 192 == 0) */
+int ribca_test_qkv_attention_mx(const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t cells, int32_t D, int32_t Kp,
+                                const float* bias2, const float* csum, const float* rowstat, uint16_t* a_hi, uint8_t* a_l8, uint8_t* a_sc,
+                                uint16_t* wh_scratch, uint8_t* wx_scratch, uint16_t* q, uint16_t* k, uint16_t* vt, uint16_t* out, int32_t ldo,
+                                void* stream);
+/* attn.proj / mlp.fc2 writing the NEW residual rows twice: packed-split into z_ps (as ribca_test_gemm_resid_ps_duo / ribca_test_gemm_mx_resid) and
+ * in MX3 into z_hi / z_l8 / z_sc (row pitch z_Kp, a multiple of 128 >= N; columns >= N are not written).  kind 0: packed-split A on the
+ * two-workgroups kernel's 128 x 192 tile (w_scratch: fragment-order copy of W; a_*, wx_scratch unused); kind 1: the MX kernel (a_*: MX3 image
+ * of A, Kp % 128 == 0; w_scratch / wx_scratch: MX weight image).  N % 192 == 0; part: (N / 48) * M float2. */
+int ribca_test_gemm_resid_zmx(int32_t kind, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
+                              const float* bias, uint16_t* a_hi, uint8_t* a_l8, uint8_t* a_sc, uint16_t* w_scratch, uint8_t* wx_scratch,
+                              uint16_t* z_ps, int32_t ldz, float* part, float* rowstat, const float* prev, uint16_t* z_hi, uint8_t* z_l8,
+                              uint8_t* z_sc, int32_t z_Kp, void* stream);
 int ribca_test_gemm_fold(int32_t kind, const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
                          const float* bias2, const float* csum, const float* rowstat, void* out, int32_t ldo, void* stream);
 int ribca_test_qkv_attention_fold(const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t cells, int32_t D, int32_t Kp,

@@ -457,6 +457,15 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
     const int blk = nt * WN + wn;
     if (m0 + BM <= M) resid_zk_epilogue<TN, MT, RB, true>(epi, mbase, nbase, blk, g, acc, zb4, zpm);
     else resid_zk_epilogue<TN, MT, RB, false>(epi, mbase, nbase, blk, g, acc, zb4, zpm);
+    // second copy of the new rows in the MX3 format (the operand of the MX forms of the next qkv / fc1, gemm_mx.hip): the 128 x 192 tile only
+    // (48-column wave blocks; its launcher adds the 2 KB of exchange space behind the ring)
+    if constexpr (TN == 3 && WM == 1 && RB == MT) {
+      if (epi.zmx.hi != nullptr) {      // workgroup-uniform
+        const unsigned xch = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (unsigned)(NST * STAGE);
+        if (m0 + BM <= M) mx3_emit_wave48<MT, true>(epi.zmx, M, m0, n0 + wn * 48, g, r16, wave, xch, acc[0]);
+        else mx3_emit_wave48<MT, false>(epi.zmx, M, m0, n0 + wn * 48, g, r16, wave, xch, acc[0]);
+      }
+    }
   } else if constexpr (is_mx_out<Epi>::value) {
     static_assert(WM == 1 && TN == 2 && NB == 1, "the MX3-emitting GELU epilogue: 4 waves as 1 x 4 over a 128-wide tile");
     if (m0 + BM <= M) gelu_mx_epilogue<MT, true>(epi, m0 + r16, n0 + wn * 32, g, acc);
@@ -523,7 +532,8 @@ static bool launch_duo_impl(const GemmArgs& g, const Epi& epi, hipStream_t s, in
   constexpr int NST = BM == 256 ? 2 : 3;
   const int mtiles = (g.M + BM - 1) / BM;
   const int ntiles = gemm_padded_n(g.N) / BN;
-  const size_t lds = lds_pad ? (size_t)100 * 1024 : (size_t)NST * BM * ROWB;
+  // (+ 2 KB behind the ring where the epilogue may emit an MX3 copy: gemm_epi.h mx3_emit_wave48)
+  const size_t lds = lds_pad ? (size_t)100 * 1024 : (size_t)NST * BM * ROWB + ((is_zk<Epi>::value && TN == 3 && WM == 1) ? 2048 : 0);
   const uint16_t* wf = wf_for(g, s);
   if (wf == nullptr) return false;
   const dim3 grid(mtiles * ntiles), block(64 * NW);

@@ -2,6 +2,7 @@
 // (gemm_split16.hip: one 768-thread workgroup per CU; gemm_duo.hip: two 256-thread workgroups per CU).
 #pragma once
 #include <type_traits>
+#include <utility>
 
 #include "ribca_common.h"
 #include "ribca_kernels.h"
@@ -110,6 +111,10 @@ struct EpiResidZK {
   uint16_t* z; int ldz; const float* bias; int M, N;
   float2* part = nullptr;      // [N / (16 TN)][M] (mean, M2) per wave column block, or nullptr: no statistics wanted
   const float2* prev = nullptr; int prev_stride = 1;     // (rstd, mean) of the stored rows, or nullptr: no re-centring
+  // optional second copy of the NEW rows in the MX3 format (gemm_mx.hip): the operand the MX forms of the next qkv / fc1 read (3 bytes per
+  // element instead of 4, and fp16 hi * hi + block-scaled corrections instead of three fp16 passes); hi == nullptr: not wanted.  Only with
+  // 48-column wave blocks (TN = 3) and N % 192 == 0: a 32-column scale block then lies in one wave or is shared by a wave and its neighbour.
+  MxAct zmx = MxAct{nullptr, nullptr, nullptr, 0, 0};
   struct Ctx {};
   typedef NoRow RowS;
 };
@@ -398,6 +403,7 @@ __device__ __forceinline__ float g4_max(float v) {
   return fmaxf(c, d);
 }
 typedef short mx_s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
 // acc: the wave's MT x 2 tiles (lane: row r16 of every row tile, columns 4 g .. 4 g + 3 of both column tiles); n32 = first column of the
 // wave's 32-column block.  IN: every row of the tile is inside M (N is a multiple of the tile width by construction).
 template <int MT, bool IN>
@@ -465,6 +471,122 @@ __device__ __forceinline__ void gelu_mx_epilogue(const EpiGeluMx& epi, int mbase
   }
 }
 
+// ---- MX3 emission from a wave that owns MT row tiles x 3 column tiles (48 columns starting at a multiple of 48; lane: row r16 of every row
+// tile, columns 4 g .. 4 g + 3 of every column tile).  32-column scale blocks against 48-column wave blocks: an EVEN wave block owns its
+// columns 0 .. 31 (tiles 0, 1) and shares 32 .. 47 (tile 2) with tile 0 of the next (odd) wave block, which owns its columns 16 .. 47.  The
+// shared block's maximum goes through 2 KB of LDS (xch: [4 waves][128 rows] floats outside every ring slot) and ONE workgroup barrier:
+// EVERY wave of the workgroup must call this (the launchers take N % 192 == 0: no wave of a tile lies beyond N).
+// x: the values to emit, already clamped to the fp16 range.  The pair (g, g ^ 1) owns 8 consecutive columns of a tile: the even lane stores
+// their 8 hi halves (16 bytes, permuted plane), the odd lane their 8 lo bytes.
+template <int... Is, class F>
+__device__ __forceinline__ void epi_sfor_impl(std::integer_sequence<int, Is...>, F&& f) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void epi_sfor(F&& f) { epi_sfor_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// (inline asm with lambda-local operands does not compile inside a generic lambda: through functions)
+template <int OFF> __device__ __forceinline__ void epi_lds_wr32(unsigned addr, float v) {
+  asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF> __device__ __forceinline__ void epi_lds_rd32(float& dst, unsigned addr) {
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int CNT> __device__ __forceinline__ void epi_wait_lgkm2(float& v, float& w) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(v), "+v"(w) : "n"(CNT) : "memory");
+}
+
+template <int MT, bool IN>
+__device__ __forceinline__ void mx3_emit_wave48(const MxAct& out, int M, int m0, int ncol0, int g_in, int r16_in, int wave, unsigned xch_lds,
+                                                const f32x4 (&x)[MT][3]) {
+  // (opaque copies: everything below that derives from the lane's position is then formed HERE, not shared with the kernel's prologue and
+  // carried -- or spilled -- across the K loop)
+  int g = g_in, r16 = r16_in;
+  asm volatile("" : "+v"(g), "+v"(r16));
+  const bool odd = ((ncol0 / 48) & 1) != 0;
+  // the shared block's partial maxima change hands with the neighbour wave (wave ^ 1) through LDS; a wave reads its own back as well rather
+  // than keeping eight more values in registers across the barrier
+  const unsigned mine = xch_lds + (unsigned)((wave * 128 + r16) * 4), theirs = xch_lds + (unsigned)(((wave ^ 1) * 128 + r16) * 4);
+  // (a row's two exponent bytes are kept PACKED, four rows to a register: 4 registers instead of 16 beside the 96 values to emit)
+  static_assert(MT % 4 == 0, "exponent bytes are packed four rows to a register");
+  unsigned so_pk[MT / 4], ss_pk[MT / 4];
+#pragma unroll
+  for (int q = 0; q < MT / 4; ++q) so_pk[q] = ss_pk[q] = 0u;
+  __builtin_amdgcn_sched_barrier(0);      // (keeps the maxima out of the caller's last stores: registers)
+  epi_sfor<MT>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    float m3[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) m3[j] = fmaxf(fmaxf(fabsf(x[i][j][0]), fabsf(x[i][j][1])), fmaxf(fabsf(x[i][j][2]), fabsf(x[i][j][3])));
+    // exponent byte of a block from fp16(max |x|): rounding is monotone, so that is the largest |hi|
+    const float mo = g4_max(odd ? fmaxf(m3[1], m3[2]) : fmaxf(m3[0], m3[1]));
+    so_pk[i / 4] |= (unsigned)mx_sl_byte((int)(f16_bits(mo) >> 10)) << (8 * (i % 4));
+    asm volatile("" : "+v"(so_pk[i / 4]));      // (HERE: left to itself the end of the reduction sinks to its use and both halves stay live)
+    const float ms = g4_max(odd ? m3[0] : m3[2]);
+    if (g == 0) epi_lds_wr32<i * 64>(mine, ms);
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  epi_sfor<MT / 4>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    float mp[4], mq[4];
+    epi_sfor<4>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      epi_lds_rd32<(4 * q + i) * 64>(mp[i], theirs);
+      epi_lds_rd32<(4 * q + i) * 64>(mq[i], mine);
+    });
+    epi_sfor<4>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      epi_wait_lgkm2<2 * (3 - i)>(mp[i], mq[i]);
+      ss_pk[q] |= (unsigned)mx_sl_byte((int)(f16_bits(fmaxf(mp[i], mq[i])) >> 10)) << (8 * i);
+    });
+    asm volatile("" : "+v"(ss_pk[q]));
+  });
+  // Stores through descriptors over the tile's rows of the two data planes: ONE 32-bit offset register per column tile instead of a 64-bit
+  // address per (row tile, column tile) -- the scheduler otherwise forms all 48 of them up front, beside the 96 accumulators -- and rows
+  // beyond M are dropped by the range check.
+  const int Kp = out.Kp;
+  const int rows = IN ? 16 * MT : ((M - m0) < 16 * MT ? (M - m0) : 16 * MT);
+  const __amdgpu_buffer_rsrc_t hi_rsrc = __builtin_amdgcn_make_buffer_rsrc(out.hi + (size_t)m0 * Kp, 0, rows * Kp * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t l8_rsrc = __builtin_amdgcn_make_buffer_rsrc(out.l8 + (size_t)m0 * Kp, 0, rows * Kp, 0x00020000);
+  const int c8 = ncol0 + 8 * (g >> 1);      // + 16 j: the 8 columns the pair (g, g ^ 1) owns in column tile j
+  int hi_voff[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) hi_voff[j] = (r16 * Kp + mx_hi_pos(c8 + 16 * j)) * 2;
+  const int l8_voff = r16 * Kp + c8;
+  const int blk_own = (ncol0 + (odd ? 16 : 0)) >> 5, blk_sh = (ncol0 + (odd ? 0 : 32)) >> 5;      // 32-column block indices
+  unsigned char* sc_own = out.sc + ((size_t)(blk_own >> 2) * out.M + m0 + r16) * 4 + (blk_own & 3);
+  unsigned char* sc_sh = out.sc + ((size_t)(blk_sh >> 2) * out.M + m0 + r16) * 4 + (blk_sh & 3);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int sl_o = (int)((so_pk[i / 4] >> (8 * (i % 4))) & 0xffu), sl_s = (int)((ss_pk[i / 4] >> (8 * (i % 4))) & 0xffu);
+    const int row_soff = i * 16 * Kp;      // wave-uniform
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const bool shared = odd ? j == 0 : j == 2;
+      const float scale = e8m0_float(shared ? sl_s : sl_o);
+      uint2 hi;
+      hi.x = cvt_pk_f16(x[i][j][0], x[i][j][1]);
+      hi.y = cvt_pk_f16(x[i][j][2], x[i][j][3]);
+      mx_s16x2 r = {0, 0};
+      r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, f32_minus_f16lo(x[i][j][0], hi.x), f32_minus_f16hi(x[i][j][1], hi.x), scale, false);
+      r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, f32_minus_f16lo(x[i][j][2], hi.y), f32_minus_f16hi(x[i][j][3], hi.y), scale, true);
+      const unsigned l8 = __builtin_bit_cast(unsigned, r);
+      // even lane: own hi.x / hi.y and the partner's; odd lane: the partner's lo bytes and its own (the two operands of a swap differ on
+      // purpose: handed the same value twice hipcc folds the swap's two results into one, tools/swap_probe.hip)
+      const auto rx = __builtin_amdgcn_permlane16_swap(hi.x, l8, false, false);
+      const auto ry = __builtin_amdgcn_permlane16_swap(hi.y, l8, false, false);
+      if ((g & 1) == 0) __builtin_amdgcn_raw_buffer_store_b128(u32x4{rx[0], ry[0], rx[1], ry[1]}, hi_rsrc, hi_voff[j], row_soff * 2, 0);
+      else __builtin_amdgcn_raw_buffer_store_b64(u32x2s{rx[0], rx[1]}, l8_rsrc, l8_voff + 16 * j, row_soff, 0);
+    }
+    if ((IN || r16 + 16 * i < rows) && g == 0) {
+      sc_own[i * 64] = (unsigned char)sl_o;
+      if (!odd) sc_sh[i * 64] = (unsigned char)sl_s;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- EpiResidZK pieces shared by gemm_duo.hip and gemm_mx.hip
 // ---- EpiResidZK (gemm_epi.h): descriptor over the residual tile's rows, the four-lane sum and the load-free epilogue
 template <class Epi>
@@ -521,7 +643,7 @@ __device__ __forceinline__ void resid_zk_epilogue(const EpiResidZK& epi, int mba
     }
     sum[i] = tot.x + tot.y;
   }
-  if (epi.part == nullptr) return;
+  if (epi.part == nullptr) return;      // (acc keeps the new values x either way: the MX3 copy is emitted from it by the caller)
   constexpr float inv = 1.0f / (float)(16 * TN);
 #pragma unroll
   for (int i = 0; i < MT; ++i) sum[i] = g4_sum(sum[i]) * inv;      // block mean of the row
@@ -547,6 +669,41 @@ __device__ __forceinline__ void resid_zk_epilogue(const EpiResidZK& epi, int mba
       if (IN || m < epi.M) epi.part[(size_t)blk * epi.M + m] = float2{sum[i], q[i]};
     }
   }
+}
+
+// mlp.fc1 on the MX kernel (gemm_mx.hip: a wave owns MT x 3 tiles): LayerNorm fold + GELU in place, then the MX3 planes of the result
+template <int MT, bool IN>
+__device__ __forceinline__ void gelu_mx48_epilogue(const EpiGeluMx& epi, int m0, int ncol0, int g, int r16, int wave, unsigned xch_lds,
+                                                   f32x4 (&acc)[1][MT][3]) {
+  const int nb0 = ncol0 + 4 * g, mbase = m0 + r16;
+  float4 b4[3], c4[3];
+  LnRow rs[MT];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    b4[j] = *reinterpret_cast<const float4*>(epi.bias + nb0 + 16 * j);
+    c4[j] = *reinterpret_cast<const float4*>(epi.csum + nb0 + 16 * j);
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = mbase + 16 * i;
+    const float2 r = epi.rowstat[(size_t)(IN || m < epi.M ? m : epi.M - 1) * epi.rs_stride];
+    rs[i] = LnRow{r.x, -r.y * r.x};
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { settle(b4[j]); settle(c4[j]); }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) settle_row(rs[i]);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float4 f = ln_fold4<true>(acc[0][i][j], b4[j], c4[j], rs[i]);
+      const f32x2v u0 = gelu_erf2(f32x2v{f.x, f.y}), u1 = gelu_erf2(f32x2v{f.z, f.w});
+      acc[0][i][j] = f32x4{clamp_f16_range(u0.x), clamp_f16_range(u0.y), clamp_f16_range(u1.x), clamp_f16_range(u1.y)};
+      // (one tile at a time: interleaving the 24 erf evaluations costs more registers than the wave has beside its accumulators)
+      if ((j & 1) == 1 || j == 2) __builtin_amdgcn_sched_barrier(0);
+    }
+  mx3_emit_wave48<MT, IN>(epi.out, epi.M, m0, ncol0, g, r16, wave, xch_lds, acc[0]);
 }
 
 

@@ -37,6 +37,7 @@
 //     (lo, fp6 hi, scale from LDS) x 3 x 2 scaled MFMAs.
 // Two barriers per 128 k (the fp16x3 kernels: four).  The residual tile rides the ring behind the product's own steps exactly as in
 // gemm_duo.hip (EpiResidZK: identity fragments, exact), and the epilogue is that kernel's.
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -144,9 +145,10 @@ constexpr int kWxBase = 1024, kWxSc = 0, kWxL6b = 512, kWxL6a = 2048;
 size_t mx_wh_bytes(int Np, int Kp) { return (size_t)((Np + 191) / 192 * 4) * (Kp / 128) * kMxWhBytes; }
 size_t mx_wx_bytes(int Np, int Kp) { return (size_t)((Np + 191) / 192 * 4) * ((size_t)(Kp / 128) * kMxWxBytes + kMxWxHeader); }
 
-// packed-split weight [Np][2 Kp] (Kp % 128 == 0, rows n >= N read as zeros by the caller's padding) -> WH / WX; one thread per
+// packed-split weight [Np][>= 2 Ksrc] (rows n >= N read as zeros by the caller's padding; Kp = Ksrc rounded up to 128: zeros) -> WH / WX; one thread per
 // (output column, 32-k block); N48 = columns rounded up to whole 192-column tiles: columns beyond Np are written as zeros
-__global__ void mx_pack_w_kernel(const uint16_t* __restrict__ W, int ldw, int Np, int N48, int Kp, uint16_t* __restrict__ WH, unsigned char* __restrict__ WX) {
+__global__ void mx_pack_w_kernel(const uint16_t* __restrict__ W, int ldw, int Np, int N48, int Ksrc, int Kp, uint16_t* __restrict__ WH,
+                                 unsigned char* __restrict__ WX) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int nq = Kp / 32;
   if (idx >= (long long)N48 * nq) return;
@@ -155,7 +157,7 @@ __global__ void mx_pack_w_kernel(const uint16_t* __restrict__ W, int ldw, int Np
   h32 lv;
   unsigned mh = 0, ml = 0;
   uint4 hraw[4] = {};
-  if (n < Np) {
+  if (n < Np && 32 * q < Ksrc) {
     const uint16_t* src = W + (size_t)n * ldw + (size_t)q * 64;      // 4 PS groups of [hi 8 | lo 8]
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -195,10 +197,10 @@ __global__ void mx_pack_w_kernel(const uint16_t* __restrict__ W, int ldw, int Np
     if (b == 0) *reinterpret_cast<uint16_t*>(wxj + lane * 8 + 6) = 0;
   }
 }
-void launch_mx_pack_w(const uint16_t* W, int ldw, int Np, int Kp, uint16_t* WH, unsigned char* WX, hipStream_t s) {
+void launch_mx_pack_w(const uint16_t* W, int ldw, int Np, int Ksrc, int Kp, uint16_t* WH, unsigned char* WX, hipStream_t s) {
   const int N48 = (Np + 191) / 192 * 192;
   const long long total = (long long)N48 * (Kp / 32);
-  hipLaunchKernelGGL(mx_pack_w_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W, ldw, Np, N48, Kp, WH, WX);
+  hipLaunchKernelGGL(mx_pack_w_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W, ldw, Np, N48, Ksrc, Kp, WH, WX);
 }
 
 // packed-split activation rows [M][2 Kp] -> the three MX3 planes (Kp128 = Kp rounded up to 128: the pad reads as zeros).  The reference
@@ -256,7 +258,9 @@ void launch_mx_pack_act(const uint16_t* ps, int ldps, int M, int Kp, const MxAct
 namespace {
 constexpr int MX_BM = 128, MX_BN = 192, MX_MT = 8, MX_TN = 3;
 // LDS map: hi as two halves of 128 rows x 128 bytes (sub-steps 0-1 | 2-3), the fp6 rows, two scale slots, two lo slots
-constexpr int L_HI = 0, L_H6A = 32768, L_H6B = 40960, L_SC = 45056, L_SC_SLOT = 640, L_L8 = L_SC + 2 * L_SC_SLOT, L_TOTAL = L_L8 + 32768;
+constexpr int L_HI = 0, L_H6A = 32768, L_H6B = 40960, L_SC = 45056, L_SC_SLOT = 640, L_L8 = L_SC + 2 * L_SC_SLOT, L_XCH = L_L8 + 32768;
+// (L_XCH: 2 KB outside every ring slot for the MX3-emitting epilogues, gemm_epi.h mx3_emit_wave48)
+constexpr int L_TOTAL = L_XCH + 2048;
 static_assert(L_L8 % 16 == 0, "LDS-DMA destination alignment");
 __device__ __forceinline__ int mx_f4(int row) { return (4 - ((row >> 2) & 3)) & 3; }      // chunk swizzle of the 64-byte hi rows
 // chunk swizzle of the 128-byte lo rows: an fp8 operand's lane (row, g) holds k = 16 g .. + 15 and 64 + 16 g .. + 15 (tools/mx_kmap_probe.hip:
@@ -269,7 +273,9 @@ __device__ __forceinline__ int mx_f8(int row) { return (row >> 1) & 7; }
 template <class Epi, int ABL>
 __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint16_t* __restrict__ WH, const unsigned char* __restrict__ WX, int M, int nb,
                                                               int mtiles, int ntiles, Epi epi) {
-  static_assert(is_zk<Epi>::value, "the residual-through-the-ring epilogue");
+  // epilogues: EpiResidZK (proj / fc2: the residual tile through the ring, optionally a second copy of the new rows in MX3), EpiQKVLn,
+  // EpiGeluMx (fc1: GELU output in MX3)
+  constexpr bool ZK = is_zk<Epi>::value;
   constexpr int MT = MX_MT, TN = MX_TN, BM = MX_BM, BN = MX_BN, ZS = BN / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nblk = mtiles * ntiles;
@@ -298,7 +304,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
   const __amdgpu_buffer_rsrc_t sc_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.sc + (size_t)m0 * 4, 0, ((nb - 1) * A.M + (A.M - m0)) * 4, 0x00020000);
   // (a copy: naming epi inside a lambda that a generic lambda calls makes hipcc drop the kernel's HOST stub without a diagnostic -- the library
   // then fails to load with an undefined symbol)
-  const int ldz_ = epi.ldz;
+  int ldz_ = 0;
+  if constexpr (ZK) ldz_ = epi.ldz;
   int hi_voff, l8_voff, sc_voff;
   {
     const int hrow = wave * 8 + (lane >> 3);                       // + 32 i for the wave's other groups (same swizzle): 8 rows x 128 bytes per piece
@@ -501,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
     asm volatile("" ::: "memory");
     if constexpr (more) {
       issue_hi(b + 1);
-    } else {
+    } else if constexpr (ZK) {
       // the residual tile's first three 32-column units: two into the hi slots, one into the lo slot of the other parity
       issue_z(0, L_HI);
       issue_z(1, L_HI + 16384);
@@ -559,95 +566,124 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
   for (int b = 0; b + 1 < nb; ++b) step(std::true_type{}, b);
   step(std::false_type{}, nb - 1);
 
-  // everything the epilogue needs from memory: requested behind the last operand batch, in front of the residual units, whose six
-  // barriers cover the round trip (20 registers that the K loop does not have to carry)
-  float4 zb4[TN];
-  float zpm[MT];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * (16 * TN) + 16 * j + 4 * g;
-    zb4[j] = n < epi.N ? *reinterpret_cast<const float4*>(epi.bias + n) : float4{0.f, 0.f, 0.f, 0.f};
-  }
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int m = m0 + 16 * i + r16;
-    zpm[i] = (epi.prev != nullptr && m < M) ? epi.prev[(size_t)m * epi.prev_stride].y : 0.f;
-  }
-#ifndef MXDBG_NOZ
-  // ---- the residual tile: unit t holds columns n0 + 32 t .. + 31 of the stored rows (gemm_duo.hip, EpiResidZK)
-  {
-    const int last = nb - 1;
-    const unsigned rd_ps_hi = lds_base + (unsigned)lds_off(r16, 2 * g);      // packed-split rows: hi chunk 2 g, lo chunk at ^ 16
-    const int zslot[4] = {L_HI, L_HI + 16384, L_L8 + ((last + 1) & 1) * 16384, L_L8 + (last & 1) * 16384};
-    const int p8 = r16 & 7;
-    const unsigned one = (p8 & 1) ? 0x3C000000u : 0x00003C00u;
-    const u32x4 pat = {(p8 >> 1) == 0 ? one : 0u, (p8 >> 1) == 1 ? one : 0u, (p8 >> 1) == 2 ? one : 0u, (p8 >> 1) == 3 ? one : 0u};
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    const f16x8 id0 = __builtin_bit_cast(f16x8, g == (r16 >> 3) ? pat : zero4), id16 = __builtin_bit_cast(f16x8, g == 2 + (r16 >> 3) ? pat : zero4);
-    int zsel[TN];
-    f16x8 idj[TN];
+  // the lane's position again, from the hardware: r16 / g of the prologue then end with the address registers formed from them instead of
+  // occupying registers (or scratch) across the K loop for the epilogue's sake
+  int lane_e;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+  const int r16e = lane_e & 15, ge = lane_e >> 4;
+  const int mbase = m0 + r16e, nbase = n0 + wn * (16 * TN) + 4 * ge;
+  const unsigned xch = lds_base + L_XCH;
+  if constexpr (ZK) {
+    // everything the epilogue needs from memory: requested behind the last operand batch, in front of the residual units, whose six
+    // barriers cover the round trip (20 registers that the K loop does not have to carry)
+    float4 zb4[TN];
+    float zpm[MT];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int c0 = wn * (16 * TN) + 16 * j;
-      zsel[j] = n0 + c0 < epi.N ? (c0 >> 5) : -1;
-      idj[j] = (c0 & 16) ? id16 : id0;
+      const int n = n0 + wn * (16 * TN) + 16 * j + 4 * ge;
+      zb4[j] = n < epi.N ? *reinterpret_cast<const float4*>(epi.bias + n) : float4{0.f, 0.f, 0.f, 0.f};
     }
-    sfor<ZS>([&](auto t_c) {
-      constexpr int t = decltype(t_c)::value;
-      constexpr int younger = (ZS - 1 - t) < 2 ? (ZS - 1 - t) : 2;      // units requested behind unit t
-      wait_vmcnt<4 * younger>();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if constexpr (t + 3 < ZS) issue_z(t + 3, zslot[(t + 3) & 3]);
-      __builtin_amdgcn_sched_barrier(0);
-      bool mine = false;
 #pragma unroll
-      for (int j = 0; j < TN; ++j) mine = mine || zsel[j] == t;
-      if (mine) {      // wave-uniform
-        const unsigned a_hi_s = rd_ps_hi + (unsigned)zslot[t & 3], a_lo_s = a_hi_s ^ 16u;
-        f16x8 ah[2], al[2];
-        lds_rd128h<0>(ah[0], a_hi_s);
-        lds_rd128h<0>(al[0], a_lo_s);
-        sfor<MT>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          constexpr int cur = i & 1, nxt = cur ^ 1;
-          if constexpr (i + 1 < MT) {
-            lds_rd128h<(i + 1) * 2048>(ah[nxt], a_hi_s);
-            lds_rd128h<(i + 1) * 2048>(al[nxt], a_lo_s);
-            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[cur]), "+v"(al[cur])::"memory");
-          } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[cur]), "+v"(al[cur])::"memory");
-          }
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + 16 * i + r16e;
+      zpm[i] = (epi.prev != nullptr && m < M) ? epi.prev[(size_t)m * epi.prev_stride].y : 0.f;
+    }
+#ifndef MXDBG_NOZ
+    // ---- the residual tile: unit t holds columns n0 + 32 t .. + 31 of the stored rows (gemm_duo.hip, EpiResidZK)
+    {
+      const int last = nb - 1;
+      const unsigned rd_ps_hi = lds_base + (unsigned)lds_off(r16e, 2 * ge);      // packed-split rows: hi chunk 2 g, lo chunk at ^ 16
+      const int zslot[4] = {L_HI, L_HI + 16384, L_L8 + ((last + 1) & 1) * 16384, L_L8 + (last & 1) * 16384};
+      const int p8 = r16e & 7;
+      const unsigned one = (p8 & 1) ? 0x3C000000u : 0x00003C00u;
+      const u32x4 pat = {(p8 >> 1) == 0 ? one : 0u, (p8 >> 1) == 1 ? one : 0u, (p8 >> 1) == 2 ? one : 0u, (p8 >> 1) == 3 ? one : 0u};
+      const u32x4 zero4 = {0u, 0u, 0u, 0u};
+      const f16x8 id0 = __builtin_bit_cast(f16x8, ge == (r16e >> 3) ? pat : zero4), id16 = __builtin_bit_cast(f16x8, ge == 2 + (r16e >> 3) ? pat : zero4);
+      int zsel[TN];
+      f16x8 idj[TN];
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            if (zsel[j] == t) {
-              acc[0][i][j] = mfma_f16(idj[j], al[cur], acc[0][i][j]);
-              acc[0][i][j] = mfma_f16(idj[j], ah[cur], acc[0][i][j]);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        });
+      for (int j = 0; j < TN; ++j) {
+        const int c0 = wn * (16 * TN) + 16 * j;
+        zsel[j] = n0 + c0 < epi.N ? (c0 >> 5) : -1;
+        idj[j] = (c0 & 16) ? id16 : id0;
       }
-    });
-  }
-
+      sfor<ZS>([&](auto t_c) {
+        constexpr int t = decltype(t_c)::value;
+        constexpr int younger = (ZS - 1 - t) < 2 ? (ZS - 1 - t) : 2;      // units requested behind unit t
+        wait_vmcnt<4 * younger>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (t + 3 < ZS) issue_z(t + 3, zslot[(t + 3) & 3]);
+        __builtin_amdgcn_sched_barrier(0);
+        bool mine = false;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mine = mine || zsel[j] == t;
+        if (mine) {      // wave-uniform
+          const unsigned a_hi_s = rd_ps_hi + (unsigned)zslot[t & 3], a_lo_s = a_hi_s ^ 16u;
+          f16x8 ah[2], al[2];
+          lds_rd128h<0>(ah[0], a_hi_s);
+          lds_rd128h<0>(al[0], a_lo_s);
+          sfor<MT>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int cur = i & 1, nxt = cur ^ 1;
+            if constexpr (i + 1 < MT) {
+              lds_rd128h<(i + 1) * 2048>(ah[nxt], a_hi_s);
+              lds_rd128h<(i + 1) * 2048>(al[nxt], a_lo_s);
+              asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[cur]), "+v"(al[cur])::"memory");
+            } else {
+              asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[cur]), "+v"(al[cur])::"memory");
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              if (zsel[j] == t) {
+                acc[0][i][j] = mfma_f16(idj[j], al[cur], acc[0][i][j]);
+                acc[0][i][j] = mfma_f16(idj[j], ah[cur], acc[0][i][j]);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        }
+      });
+    }
 #endif
 #ifdef MXDBG_NOEPI
-  if (true) {
+    if (true) {
 #else
-  if (ABL & 1) {
+    if (ABL & 1) {
 #endif
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[0][i][j]));
-    return;
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[0][i][j]));
+      return;
+    }
+    if (n0 + wn * (16 * TN) >= epi.N) return;      // (never with an MX3 copy: its launcher takes whole tiles only)
+    const int blk = nt * 4 + wn;
+    const bool emit = epi.zmx.hi != nullptr;
+    if (m0 + BM <= M) {
+      resid_zk_epilogue<TN, MT, MT, true>(epi, mbase, nbase, blk, ge, acc, zb4, zpm);
+      if (emit) mx3_emit_wave48<MT, true>(epi.zmx, M, m0, n0 + wn * (16 * TN), ge, r16e, wave, xch, acc[0]);
+    } else {
+      resid_zk_epilogue<TN, MT, MT, false>(epi, mbase, nbase, blk, ge, acc, zb4, zpm);
+      if (emit) mx3_emit_wave48<MT, false>(epi.zmx, M, m0, n0 + wn * (16 * TN), ge, r16e, wave, xch, acc[0]);
+    }
+  } else {
+    // N is a multiple of the tile width for these (gemm_mx_supported + the launchers): only the rows need guards
+    if (ABL & 1) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[0][i][j]));
+      return;
+    }
+    if constexpr (is_mx_out<Epi>::value) {
+      if (m0 + BM <= M) gelu_mx48_epilogue<MT, true>(epi, m0, n0 + wn * (16 * TN), ge, r16e, wave, xch, acc);
+      else gelu_mx48_epilogue<MT, false>(epi, m0, n0 + wn * (16 * TN), ge, r16e, wave, xch, acc);
+    } else {
+      if (m0 + BM <= M) run_epilogue<TN, Epi, MT, true>(epi, mbase, nbase, acc[0]);
+      else run_epilogue<TN, Epi, MT>(epi, mbase, nbase, acc[0]);
+    }
   }
-  const int mbase = m0 + r16, nbase = n0 + wn * (16 * TN) + 4 * g;
-  if (n0 + wn * (16 * TN) >= epi.N) return;
-  const int blk = nt * 4 + wn;
-  if (m0 + BM <= M) resid_zk_epilogue<TN, MT, MT, true>(epi, mbase, nbase, blk, g, acc, zb4, zpm);
-  else resid_zk_epilogue<TN, MT, MT, false>(epi, mbase, nbase, blk, g, acc, zb4, zpm);
 }
 
 // ----------------------------------------------------------------------------------------------------------- host side
@@ -668,14 +704,35 @@ static void launch_mx_impl(const MxAct& A, const MxWeight& W, int M, int N, cons
 
 // z (packed-split) = (z - prev mean) + A W^T + bias with A in MX3, W in the mx_pack_w image; statistics per 48-column wave block
 ResidStatGeom launch_gemm_mx_resid(const MxAct& A, const MxWeight& W, int M, int N, const float* bias, uint16_t* z, int ldz, float2* part, const float2* prev,
-                                   int prev_stride, hipStream_t s, int abl) {
-  const EpiResidZK epi{z, ldz, bias, M, N, part, prev, prev_stride};
+                                   int prev_stride, hipStream_t s, int abl, const MxAct* zmx) {
+  EpiResidZK epi{z, ldz, bias, M, N, part, prev, prev_stride};
+  if (zmx != nullptr) {
+    // (whole 192-column tiles: every wave of a workgroup then reaches the barrier of the emission)
+    if (N % MX_BN != 0) { fprintf(stderr, "ribca: MX3 copy of the residual rows needs N %% 192 == 0\n"); abort(); }
+    epi.zmx = *zmx;
+  }
 #ifdef RIBCA_DIAG
   if (abl == 1) { launch_mx_impl<EpiResidZK, 1>(A, W, M, N, epi, s); return ResidStatGeom{N / 48, 48}; }
 #endif
   (void)abl;
   launch_mx_impl<EpiResidZK, 0>(A, W, M, N, epi, s);
   return ResidStatGeom{N / 48, 48};
+}
+
+// qkv with the LayerNorm fold (EpiQKVLn exactly as launch_gemm_qkv_ln builds it, gemm_split16.hip)
+void launch_gemm_mx_qkv_ln(const MxAct& A, const MxWeight& W, int M, int N, const float* bias, const float2* rowstat, const float* csum, uint16_t* q,
+                           uint16_t* k, uint16_t* vt, const AttnGeom& a, float scale, hipStream_t s) {
+  if (N % MX_BN != 0) { fprintf(stderr, "ribca: launch_gemm_mx_qkv_ln needs N %% 192 == 0\n"); abort(); }
+  const EpiQKVLn epi{q, k, vt, bias, a.D, a.hd, a.hdq, a.hdv, scale, M, N, a.T, a.TP, a.H, a.KP, 0,
+                     (unsigned)((0x100000000ull + (unsigned long long)a.T - 1) / (unsigned long long)a.T), rowstat, csum, attention_v_rowmajor(a) ? 1 : 0,
+                     0, 0, 1};
+  launch_mx_impl<EpiQKVLn, 0>(A, W, M, N, epi, s);
+}
+void launch_gemm_mx_gelu(const MxAct& A, const MxWeight& W, int M, int N, const float* bias, const float2* rowstat, const float* csum, const MxAct& out,
+                         hipStream_t s) {
+  if (N % MX_BN != 0 || out.Kp != N) { fprintf(stderr, "ribca: launch_gemm_mx_gelu needs N %% 192 == 0 and out.Kp == N\n"); abort(); }
+  const EpiGeluMx epi{out, bias, M, N, rowstat, csum, 1};
+  launch_mx_impl<EpiGeluMx, 0>(A, W, M, N, epi, s);
 }
 
 }  // namespace ribca

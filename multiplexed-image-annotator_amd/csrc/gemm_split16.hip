@@ -959,7 +959,7 @@ static bool resid_duo_pays(int N, int Kp) {
   return gemm_pick_bn(N) == 96 && Kp <= (N + 31) / 32 * 32;
 }
 ResidStatGeom launch_gemm_resid_ps(const GemmArgs& g, uint16_t* z, int ldz, float2* part, const float2* prev, int prev_stride, hipStream_t s,
-                                   bool force_duo) {
+                                   bool force_duo, const MxAct* zmx) {
   static const int no_touch = (getenv("RIBCA_GEMM_TOUCH") && atoi(getenv("RIBCA_GEMM_TOUCH")) == 0) ? 2 : 0;
   // proj / fc2 of the classifiers' full blocks: two workgroups per CU, residual through the ring, load-free epilogue (EpiResidZK).
   // RIBCA_RESID_DUO = 0: never, 1 (default): the shapes where it measured faster, 2: every shape it supports (A/B)
@@ -968,6 +968,15 @@ ResidStatGeom launch_gemm_resid_ps(const GemmArgs& g, uint16_t* z, int ldz, floa
   const bool want = force_duo || duo_mode == 2 || (duo_mode == 1 && resid_duo_pays(g.N, g.Kp));
   // (No threshold on M: this form is not bit-identical to the one-workgroup kernel -- the residual is added inside the accumulation,
   // the statistics are combined per wave block -- and a cell's result must not depend on the size of the chunk it was computed in.)
+  // zmx: the new rows also in the MX3 format (gemm_mx.hip) -- the 128 x 192 tile of the two-workgroups form emits it; the caller asks for
+  // it only where that form exists (N % 192 == 0, a fragment-order weight), and the choice is the model's, never the chunk's
+  if (zmx != nullptr) {
+    if (g.WF == nullptr || g.N % 192 != 0 || g_variant != 0) { fprintf(stderr, "ribca: MX3 copy of the residual rows asked of a shape without the 128 x 192 form\n"); abort(); }
+    EpiResidZK epi{z, ldz, g.bias, g.M, g.N, part, prev, prev_stride};
+    epi.zmx = *zmx;
+    if (!launch_duo<192, EpiResidZK>(g, epi, s, 0)) { fprintf(stderr, "ribca: launch_duo<192> refused\n"); abort(); }
+    return ResidStatGeom{g.N / 48, 48};
+  }
   if (want && g_variant == 0 && g.WF != nullptr && g.N % blk == 0 && g.N % 8 == 0) {
     const EpiResidZK epi{z, ldz, g.bias, g.M, g.N, part, prev, prev_stride};
     bool done = false;

@@ -86,6 +86,9 @@ struct BlockW {
   // mlp.fc2 in the MX weight image (gemm_mx.hip) where the width allows (4 D % 128 == 0, D % 48 == 0): fc1 then writes its GELU output in
   // the MX3 format and fc2 runs as fp16 hi * hi + two block-scaled corrections
   const uint16_t* fc2mxh = nullptr; const unsigned char* fc2mxx = nullptr;
+  // attn.qkv / mlp.fc1 (gamma o W) in the MX weight image, K padded to a multiple of 128, where the residual rows are kept in MX3 as well
+  // (mx_z_on): proj and fc2 then write the new rows twice -- packed-split for the residual tile of the next proj / fc2, MX3 for these
+  const uint16_t *qkvmxh = nullptr, *fc1mxh = nullptr; const unsigned char *qkvmxx = nullptr, *fc1mxx = nullptr;
 };
 
 // RIBCA_MX=0: the fp16x3 kernels everywhere (A/B).  The choice depends on the model's width alone, never on the chunk: a cell's bits must
@@ -93,6 +96,13 @@ struct BlockW {
 bool mx_on(int D) {
   static const bool on = !(getenv("RIBCA_MX") && atoi(getenv("RIBCA_MX")) == 0);
   return on && (4 * D) % 128 == 0 && gemm_mx_supported(D, 4 * D);
+}
+
+// RIBCA_MXZ=0: qkv / fc1 stay on the fp16x3 kernels (A/B).  D % 192 == 0: proj / fc2 emit the MX3 copy from 128 x 192 tiles only, and the
+// 32-column scale blocks need D % 96 == 0 (gemm_epi.h mx3_emit_wave48); 3 D and 4 D are then multiples of 192 as well.
+bool mx_z_on(int D) {
+  static const bool on = !(getenv("RIBCA_MXZ") && atoi(getenv("RIBCA_MXZ")) == 0);
+  return on && mx_on(D) && D % 192 == 0;
 }
 
 struct ribca_vit {
@@ -150,6 +160,11 @@ void layout_block(Carver& c, BlockW& L, int D, bool fold = false) {
   if (fold && mx_on(D)) {
     L.fc2mxh = c.take<uint16_t>(mx_wh_bytes(round_up(D, 16), H4) / 2);
     L.fc2mxx = c.take<unsigned char>(mx_wx_bytes(round_up(D, 16), H4));
+  }
+  if (fold && mx_z_on(D)) {
+    const int Kz = round_up(D, 128);
+    L.qkvmxh = c.take<uint16_t>(mx_wh_bytes(3 * D, Kz) / 2); L.qkvmxx = c.take<unsigned char>(mx_wx_bytes(3 * D, Kz));
+    L.fc1mxh = c.take<uint16_t>(mx_wh_bytes(4 * D, Kz) / 2); L.fc1mxx = c.take<unsigned char>(mx_wx_bytes(4 * D, Kz));
   }
 }
 
@@ -224,7 +239,12 @@ struct BlobReader {
     launch_pack_wf(L.fc1w, 2 * Dp, gemm_padded_n(4 * D), Dp, const_cast<uint16_t*>(L.fc1wf), s);
     pack(L.fc2w, D, 4 * D, 4 * D); copy(L.fc2b, D);
     if (fold) launch_pack_wf(L.fc2w, 2 * 4 * D, gemm_padded_n(D), 4 * D, const_cast<uint16_t*>(L.fc2wf), s);
-    if (L.fc2mxh) launch_mx_pack_w(L.fc2w, 2 * 4 * D, round_up(D, 16), 4 * D, const_cast<uint16_t*>(L.fc2mxh), const_cast<unsigned char*>(L.fc2mxx), s);
+    if (L.fc2mxh) launch_mx_pack_w(L.fc2w, 2 * 4 * D, round_up(D, 16), 4 * D, 4 * D, const_cast<uint16_t*>(L.fc2mxh), const_cast<unsigned char*>(L.fc2mxx), s);
+    if (L.qkvmxh) {
+      const int Kz = round_up(D, 128);
+      launch_mx_pack_w(L.qkvw, 2 * Dp, 3 * D, Dp, Kz, const_cast<uint16_t*>(L.qkvmxh), const_cast<unsigned char*>(L.qkvmxx), s);
+      launch_mx_pack_w(L.fc1w, 2 * Dp, 4 * D, Dp, Kz, const_cast<uint16_t*>(L.fc1mxh), const_cast<unsigned char*>(L.fc1mxx), s);
+    }
   }
 };
 int64_t block_params(int64_t d) { return 2 * d + 3 * d * d + 3 * d + d * d + d + 2 * d + 4 * d * d + 4 * d + 4 * d * d + d; }
@@ -236,6 +256,9 @@ struct BlockWs {
   // folded-LayerNorm blocks: residual stream packed-split [rows][2 * Dp], per-tile row statistics of the last residual GEMM and
   // the (rstd, -mean rstd) pairs the next qkv / fc1 epilogue reads
   uint16_t* zps = nullptr; float2* part = nullptr; float2* rs = nullptr;
+  // the residual rows again in MX3 (mx_z_on; Kp = D rounded up to 128, M set per chunk by the caller) and the bytes of its planes
+  MxAct zmx = MxAct{nullptr, nullptr, nullptr, 0, 0};
+  size_t zmx_rows = 0;
 };
 BlockWs carve_blocks(Carver& c, int cells, const AttnGeom& a, bool fold = false) {
   BlockWs w;
@@ -246,6 +269,14 @@ BlockWs carve_blocks(Carver& c, int cells, const AttnGeom& a, bool fold = false)
     w.zps = c.take<uint16_t>(Mc * 2 * Dp);
     w.part = c.take<float2>(Mc * gemm_resid_part_rows(a.D));
     w.rs = c.take<float2>(Mc);
+    if (mx_z_on(a.D)) {
+      const int Kz = round_up(a.D, 128);
+      w.zmx.hi = c.take<uint16_t>(Mc * Kz);
+      w.zmx.l8 = c.take<unsigned char>(Mc * Kz);
+      w.zmx.sc = c.take<unsigned char>(Mc * (Kz / 32));
+      w.zmx.Kp = Kz;
+      w.zmx_rows = Mc;
+    }
   } else {
     w.z = c.take<float>(Mc * a.D);
   }
@@ -268,6 +299,11 @@ int zero_pads(const BlockWs& w, hipStream_t s) {
   HIP_TRY(hipMemsetAsync(w.q, 0, w.qk_bytes, s));
   HIP_TRY(hipMemsetAsync(w.k, 0, w.qk_bytes, s));
   HIP_TRY(hipMemsetAsync(w.vt, 0, w.vt_bytes, s));
+  if (w.zmx.hi) {      // the K pad of the MX3 residual rows (D = 576: columns 576 .. 639) is never written either; scale byte 0 = 2^-127
+    HIP_TRY(hipMemsetAsync(w.zmx.hi, 0, w.zmx_rows * w.zmx.Kp * 2, s));
+    HIP_TRY(hipMemsetAsync(w.zmx.l8, 0, w.zmx_rows * w.zmx.Kp, s));
+    HIP_TRY(hipMemsetAsync(w.zmx.sc, 0, w.zmx_rows * (w.zmx.Kp / 32), s));
+  }
   return 0;
 }
 // one pre-LN block on z (cells*T rows): z += proj(attn(LN1 z)); z += fc2(gelu(fc1(LN2 z)))
@@ -346,24 +382,39 @@ bool cell_attn_on(const AttnGeom& a) {
   static const int v = getenv("RIBCA_CELL_ATTN") ? atoi(getenv("RIBCA_CELL_ATTN")) : 1;
   return v != 0 && cell_attention_supported(a.D, a.H, a.T);
 }
-void run_block_fold(const BlockW& L, const BlockWs& w, int cells, const AttnGeom& a, hipStream_t s, bool precise = false) {
+// next_full: the block after this one is a full block too (its qkv reads what this block's fc2 writes)
+void run_block_fold(const BlockW& L, const BlockWs& w, int cells, const AttnGeom& a, hipStream_t s, bool precise = false, bool next_full = true) {
   const int D = a.D, Dp = round_up(D, 32), ld_x = 2 * Dp, ld_h = 2 * 4 * D, Mc = cells * a.T;
   const float scale = 1.0f / sqrtf((float)a.hd);
-  if (cell_attn_on(a)) {
+  // the residual rows in MX3 beside the packed-split ones: qkv (where it is a GEMM of its own) and fc1 run on the MX kernel
+  const bool mz = w.zmx.hi != nullptr && L.fc1mxh != nullptr && !precise;
+  MxAct zmx = w.zmx;
+  zmx.M = Mc;
+  const bool fused_attn = cell_attn_on(a);
+  if (fused_attn) {
     ProfScope ps(P_CELL, s);
     launch_cell_qkv_attention(w.zps, ld_x, L.qkvw, ld_x, L.qkvb2, L.qkvc, w.rs, w.xa, ld_x, cells, D, scale, s);
   } else {
     {
       ProfScope ps(P_QKV, s);
-      GemmArgs g{w.zps, ld_x, L.qkvw, ld_x, Mc, 3 * D, Dp, L.qkvb2, L.qkvwf};
-      launch_gemm_qkv_ln(g, w.rs, L.qkvc, w.q, w.k, w.vt, a, scale, s);
+      if (mz) {
+        launch_gemm_mx_qkv_ln(zmx, MxWeight{L.qkvmxh, L.qkvmxx}, Mc, 3 * D, L.qkvb2, w.rs, L.qkvc, w.q, w.k, w.vt, a, scale, s);
+      } else {
+        GemmArgs g{w.zps, ld_x, L.qkvw, ld_x, Mc, 3 * D, Dp, L.qkvb2, L.qkvwf};
+        launch_gemm_qkv_ln(g, w.rs, L.qkvc, w.q, w.k, w.vt, a, scale, s);
+      }
     }
     { ProfScope ps(P_ATTN, s); launch_attention(w.q, w.k, w.vt, w.xa, ld_x, cells, a, s); }
   }
   {
     ProfScope ps(P_PROJ, s);
     GemmArgs g{w.xa, ld_x, L.projw, ld_x, Mc, D, Dp, L.projb, L.projwf};
-    resid_ps_and_stats(g, w, ld_x, D, true, 1, s);
+    if (mz) {
+      const ResidStatGeom sg = launch_gemm_resid_ps(g, w.zps, ld_x, w.part, w.rs, 1, s, false, &zmx);
+      launch_ln_finalize(w.part, sg.tiles, Mc, sg.bn, D, w.rs, s);
+    } else {
+      resid_ps_and_stats(g, w, ld_x, D, true, 1, s);
+    }
   }
   if (L.fc2mxh != nullptr && !precise) {
     // the MX pair: fc1's GELU epilogue emits the three-plane operand (3 bytes per element, carved out of the h buffer), fc2 multiplies it
@@ -372,12 +423,19 @@ void run_block_fold(const BlockW& L, const BlockWs& w, int cells, const AttnGeom
     const MxAct hmx{w.h, reinterpret_cast<unsigned char*>(w.h + hn), reinterpret_cast<unsigned char*>(w.h + hn) + hn, 4 * D, Mc};
     {
       ProfScope ps(P_FC1, s);
-      GemmArgs g{w.zps, ld_x, L.fc1w, ld_x, Mc, 4 * D, Dp, L.fc1b2, L.fc1wf};
-      (void)launch_gemm_gelu_mx(g, w.rs, L.fc1c, hmx, s);
+      if (mz) {
+        launch_gemm_mx_gelu(zmx, MxWeight{L.fc1mxh, L.fc1mxx}, Mc, 4 * D, L.fc1b2, w.rs, L.fc1c, hmx, s);
+      } else {
+        GemmArgs g{w.zps, ld_x, L.fc1w, ld_x, Mc, 4 * D, Dp, L.fc1b2, L.fc1wf};
+        (void)launch_gemm_gelu_mx(g, w.rs, L.fc1c, hmx, s);
+      }
     }
     {
       ProfScope ps(P_FC2, s);
-      const ResidStatGeom sg = launch_gemm_mx_resid(hmx, MxWeight{L.fc2mxh, L.fc2mxx}, Mc, D, L.fc2b, w.zps, ld_x, w.part, w.rs, 1, s);
+      // (the MX3 copy of the new rows is read by the next block's qkv GEMM: not wanted where that runs inside the fused per-cell kernel, which
+      // reads the packed-split rows, nor in front of the last block)
+      const bool emit = mz && !fused_attn && next_full;
+      const ResidStatGeom sg = launch_gemm_mx_resid(hmx, MxWeight{L.fc2mxh, L.fc2mxx}, Mc, D, L.fc2b, w.zps, ld_x, w.part, w.rs, 1, s, 0, emit ? &zmx : nullptr);
       launch_ln_finalize(w.part, sg.tiles, Mc, sg.bn, D, w.rs, s);
     }
     return;
@@ -437,6 +495,7 @@ int ribca_set_gemm_variant(int32_t v) { gemm_set_variant(v); return 0; }
 int ribca_set_gemm_stamps(void* dev_buffer, int64_t capacity_blocks) { return gemm_set_stamp_buffer(dev_buffer, capacity_blocks); }
 
 int32_t ribca_mx_enabled(int32_t D) { return mx_on(D) ? 1 : 0; }
+int32_t ribca_mxz_enabled(int32_t D) { return mx_z_on(D) ? 1 : 0; }
 
 int64_t ribca_vit_blob_len(int32_t D, int32_t C, int32_t K, int32_t depth) {
   const int64_t d = D;
@@ -536,7 +595,13 @@ static int vit_forward_impl(const ribca_vit_t* m, const float* patches, int32_t 
         launch_cls_rows_ps(w.zps, ld_z, m->cls, m->pos, D, bc, kTokens, s);
       }
       { ProfScope ps(P_LN, s); launch_row_stats_ps(w.zps, ld_z, bc * kTokens, D, w.rs, true, s); }
-      for (size_t li = 0; li + 1 < m->layers.size(); ++li) run_block_fold(m->layers[li], w, bc, geom, s, precise);
+      if (w.zmx.hi != nullptr && !precise && !cell_attn_on(geom) && m->layers.size() > 1) {      // the first block's qkv operand
+        ProfScope ps(P_OTHER, s);
+        MxAct zmx = w.zmx;
+        zmx.M = bc * kTokens;
+        launch_mx_pack_act(w.zps, ld_z, bc * kTokens, m->Dp, zmx, s);
+      }
+      for (size_t li = 0; li + 1 < m->layers.size(); ++li) run_block_fold(m->layers[li], w, bc, geom, s, precise, li + 2 < m->layers.size());
       run_last_block_cls_fold(m->layers.back(), w, bc, geom, s);
       {
         ProfScope ps(P_HEAD, s);
@@ -943,7 +1008,7 @@ int ribca_test_gemm_mx_resid(const uint16_t* A, int32_t lda, const uint16_t* W, 
   hipStream_t s = (hipStream_t)stream;
   const MxAct a{hi_out, l8_out, sc_out, Kp, M};
   launch_mx_pack_act(A, lda, M, Kp, a, s);
-  launch_mx_pack_w(W, ldw, (N + 15) / 16 * 16, Kp, wh_scratch, wx_scratch, s);
+  launch_mx_pack_w(W, ldw, (N + 15) / 16 * 16, Kp, Kp, wh_scratch, wx_scratch, s);
   const MxWeight w{wh_scratch, wx_scratch};
   const ResidStatGeom sg = launch_gemm_mx_resid(a, w, M, N, bias, z_ps, ldz, reinterpret_cast<float2*>(part), reinterpret_cast<const float2*>(prev), 1, s);
   if (rowstat) launch_ln_finalize(reinterpret_cast<const float2*>(part), sg.tiles, M, sg.bn, N, reinterpret_cast<float2*>(rowstat), s);
@@ -972,6 +1037,71 @@ int ribca_test_gemm_gelu_mx(const uint16_t* z_ps, int32_t lda, const uint16_t* W
   const MxAct out{hi_out, l8_out, sc_out, N, M};
   if (!launch_gemm_gelu_mx(g, reinterpret_cast<const float2*>(rowstat), csum, out, (hipStream_t)stream))
     return fail("ribca_test_gemm_gelu_mx: N must be a multiple of 128");
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+// mlp.fc1 on the MX kernel: z (packed-split, Kp columns) -> MX3 (a_*: scratch planes, Kp rounded up to 128) -> gelu(LN-folded product) in MX3
+int ribca_test_gemm_mx_fc1(const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp, const float* bias2,
+                           const float* csum, const float* rowstat, uint16_t* a_hi, uint8_t* a_l8, uint8_t* a_sc, uint16_t* wh_scratch,
+                           uint8_t* wx_scratch, uint16_t* hi_out, uint8_t* l8_out, uint8_t* sc_out, void* stream) {
+  if (!csum || !rowstat || !a_hi || !a_l8 || !a_sc || !wh_scratch || !wx_scratch) return fail("ribca_test_gemm_mx_fc1: NULL buffer");
+  if (N % 192 != 0 || Kp % 32 != 0) return fail("ribca_test_gemm_mx_fc1: N must be a multiple of 192 and Kp of 32");
+  hipStream_t s = (hipStream_t)stream;
+  const int Kz = round_up(Kp, 128);
+  const MxAct a{a_hi, a_l8, a_sc, Kz, M};
+  launch_mx_pack_act(z_ps, lda, M, Kp, a, s);
+  launch_mx_pack_w(W, ldw, N, Kp, Kz, wh_scratch, wx_scratch, s);
+  const MxAct out{hi_out, l8_out, sc_out, N, M};
+  launch_gemm_mx_gelu(a, MxWeight{wh_scratch, wx_scratch}, M, N, bias2, reinterpret_cast<const float2*>(rowstat), csum, out, s);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+// ribca_test_qkv_attention_fold with the qkv product on the MX kernel
+int ribca_test_qkv_attention_mx(const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t cells, int32_t D, int32_t Kp,
+                                const float* bias2, const float* csum, const float* rowstat, uint16_t* a_hi, uint8_t* a_l8, uint8_t* a_sc,
+                                uint16_t* wh_scratch, uint8_t* wx_scratch, uint16_t* q, uint16_t* k, uint16_t* vt, uint16_t* out, int32_t ldo,
+                                void* stream) {
+  if (!csum || !rowstat || !a_hi || !a_l8 || !a_sc || !wh_scratch || !wx_scratch) return fail("ribca_test_qkv_attention_mx: NULL buffer");
+  if ((3 * D) % 192 != 0 || Kp % 32 != 0) return fail("ribca_test_qkv_attention_mx: 3 D must be a multiple of 192 and Kp of 32");
+  hipStream_t s = (hipStream_t)stream;
+  const AttnGeom g = make_attn_geom(D, kHeads, kTokens);
+  const int M = cells * kTokens, Kz = round_up(Kp, 128);
+  const MxAct a{a_hi, a_l8, a_sc, Kz, M};
+  launch_mx_pack_act(z_ps, lda, M, Kp, a, s);
+  launch_mx_pack_w(W, ldw, 3 * D, Kp, Kz, wh_scratch, wx_scratch, s);
+  launch_gemm_mx_qkv_ln(a, MxWeight{wh_scratch, wx_scratch}, M, 3 * D, bias2, reinterpret_cast<const float2*>(rowstat), csum, q, k, vt, g,
+                        1.0f / sqrtf((float)g.hd), s);
+  launch_attention(q, k, vt, out, ldo, cells, g, s);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+// proj / fc2 writing the new rows a second time in MX3 (z_hi / z_l8 / z_sc, row pitch z_Kp).  kind 0: the packed-split operand on the
+// two-workgroups kernel (w_scratch: fragment-order copy of W; a_* and wx_scratch unused); kind 1: the MX kernel (a_*: MX3 image of A,
+// w_scratch / wx_scratch: the MX weight image)
+int ribca_test_gemm_resid_zmx(int32_t kind, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
+                              const float* bias, uint16_t* a_hi, uint8_t* a_l8, uint8_t* a_sc, uint16_t* w_scratch, uint8_t* wx_scratch,
+                              uint16_t* z_ps, int32_t ldz, float* part, float* rowstat, const float* prev, uint16_t* z_hi, uint8_t* z_l8,
+                              uint8_t* z_sc, int32_t z_Kp, void* stream) {
+  if (!w_scratch || !z_hi || !z_l8 || !z_sc || !part || !rowstat) return fail("ribca_test_gemm_resid_zmx: NULL buffer");
+  if (N % 192 != 0 || z_Kp % 128 != 0 || z_Kp < N) return fail("ribca_test_gemm_resid_zmx: N must be a multiple of 192, z_Kp of 128 and >= N");
+  hipStream_t s = (hipStream_t)stream;
+  const MxAct zmx{z_hi, z_l8, z_sc, z_Kp, M};
+  ResidStatGeom sg;
+  if (kind == 0) {
+    launch_pack_wf(W, ldw, gemm_padded_n(N), Kp, w_scratch, s);
+    GemmArgs g{A, lda, W, ldw, M, N, Kp, bias, w_scratch};
+    sg = launch_gemm_resid_ps(g, z_ps, ldz, reinterpret_cast<float2*>(part), reinterpret_cast<const float2*>(prev), 1, s, false, &zmx);
+  } else if (kind == 1) {
+    if (!a_hi || !a_l8 || !a_sc || !wx_scratch || Kp % 128 != 0) return fail("ribca_test_gemm_resid_zmx: kind 1 needs the MX3 scratch planes and Kp % 128 == 0");
+    const MxAct a{a_hi, a_l8, a_sc, Kp, M};
+    launch_mx_pack_act(A, lda, M, Kp, a, s);
+    launch_mx_pack_w(W, ldw, N, Kp, Kp, w_scratch, wx_scratch, s);
+    sg = launch_gemm_mx_resid(a, MxWeight{w_scratch, wx_scratch}, M, N, bias, z_ps, ldz, reinterpret_cast<float2*>(part), reinterpret_cast<const float2*>(prev), 1,
+                              s, 0, &zmx);
+  } else {
+    return fail("ribca_test_gemm_resid_zmx: kind must be 0 or 1");
+  }
+  launch_ln_finalize(reinterpret_cast<const float2*>(part), sg.tiles, M, sg.bn, N, reinterpret_cast<float2*>(rowstat), s);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1008,7 +1138,7 @@ int ribca_test_gemm_duo_gelu(const uint16_t* A, int32_t lda, const uint16_t* W, 
 }
 int ribca_test_cell_attention(const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t cells, int32_t D,
                               const float* bias2, const float* csum, const float* rowstat, uint16_t* out, int32_t ldo, void* stream) {
-  if (!cell_attention_supported(D, kHeads, kTokens)) return fail("ribca_test_cell_attention: D must be 144 or 288");
+  if (!cell_attention_supported(D, kHeads, kTokens)) return fail("ribca_test_cell_attention: D must be 144, 288 or 384");
   launch_cell_qkv_attention(z_ps, lda, W, ldw, bias2, csum, reinterpret_cast<const float2*>(rowstat), out, ldo, cells, D,
                             1.0f / sqrtf((float)(D / kHeads)), (hipStream_t)stream);
   HIP_TRY(hipGetLastError());

@@ -34,8 +34,12 @@ void launch_gemm_gelu(const GemmArgs& g, uint16_t* out, int ldo, hipStream_t s);
 // every shape it supports with force_duo -- and the statistics come per WAVE column block (16 / 32 / 48 columns) instead of per column
 // tile; ln_finalize takes either.  RIBCA_RESID_DUO = 0 / 1 / 2: never / where it pays (default) / wherever supported.
 struct ResidStatGeom { int tiles, bn; };
+// an activation matrix in the three-plane MX3 format (described with the MX GEMM below)
+struct MxAct { uint16_t* hi; unsigned char* l8; unsigned char* sc; int Kp; int M; };
+// zmx != nullptr: the new rows are ALSO written in the MX3 format (the operand of the MX forms of the next qkv / fc1); needs N % 192 == 0
+// and a fragment-order weight (the 128 x 192 tile of the two-workgroups form emits it), aborts otherwise
 ResidStatGeom launch_gemm_resid_ps(const GemmArgs& g, uint16_t* z, int ldz, float2* part, const float2* prev, int prev_stride, hipStream_t s,
-                                   bool force_duo = false);
+                                   bool force_duo = false, const MxAct* zmx = nullptr);
 int gemm_resid_tiles(int N);        // column tiles of an N-wide residual GEMM on the one-workgroup kernel
 int gemm_resid_bn(int N);           // their width
 int gemm_resid_part_rows(int N);    // rows `part` must have for either kernel (the finer of the two geometries)
@@ -68,20 +72,27 @@ void launch_gemm_rowmap(const GemmArgs& g, float* out, int ldo, const float* add
 // (hi fp16 permuted inside every 128 columns, lo as e4m3 bytes, one E8M0 scale byte per 32 columns -- see gemm_mx.hip), Kp % 128 == 0.
 // The scale plane is TRANSPOSED, [Kp / 128][M][4]: the 128 rows x 4 bytes a K step needs are 512 contiguous bytes (four lines), not 128
 // pieces of four bytes one row pitch apart.
-struct MxAct { uint16_t* hi; unsigned char* l8; unsigned char* sc; int Kp; int M; };
 struct MxWeight { const uint16_t* wh; const unsigned char* wx; };     // mx_pack_w image of a packed-split weight [Np][2 Kp]
 size_t mx_wh_bytes(int Np, int Kp);
 size_t mx_wx_bytes(int Np, int Kp);
 inline size_t mx_act_hi_elems(size_t M, int Kp128) { return M * (size_t)Kp128; }          // fp16 elements; l8: the same count of bytes; sc: / 32
-void launch_mx_pack_w(const uint16_t* W, int ldw, int Np, int Kp, uint16_t* WH, unsigned char* WX, hipStream_t s);
+// W: packed-split [Np][ldw] with Ksrc columns (a multiple of 32); Kp = Ksrc rounded up to 128 (the pad is written as zeros)
+void launch_mx_pack_w(const uint16_t* W, int ldw, int Np, int Ksrc, int Kp, uint16_t* WH, unsigned char* WX, hipStream_t s);
 // packed-split rows [M][2 Kp] -> MX3 (a.Kp = Kp rounded up to 128): the reference producer of the format
 void launch_mx_pack_act(const uint16_t* ps, int ldps, int M, int Kp, const MxAct& a, hipStream_t s);
 bool gemm_mx_supported(int N, int Kp);
 // out (MX3, out.Kp == g.N) = gelu(rstd acc + (-mean rstd csum + bias)): mlp.fc1 in front of an MX fc2 (gemm_duo.hip); false = not launched
 bool launch_gemm_gelu_mx(const GemmArgs& g, const float2* rowstat, const float* csum, const MxAct& out, hipStream_t s);
 // z_ps = (z_ps - prev mean) + A W^T + bias, statistics per 48-column wave block (as launch_gemm_resid_ps on the duo kernel)
+// zmx: as for launch_gemm_resid_ps (N % 192 == 0)
 ResidStatGeom launch_gemm_mx_resid(const MxAct& A, const MxWeight& W, int M, int N, const float* bias, uint16_t* z, int ldz, float2* part,
-                                   const float2* prev, int prev_stride, hipStream_t s, int abl = 0);
+                                   const float2* prev, int prev_stride, hipStream_t s, int abl = 0, const MxAct* zmx = nullptr);
+// attn.qkv / mlp.fc1 with the LayerNorm fold on the MX kernel: A = the residual rows in MX3 (N % 192 == 0); the fc1 form writes its GELU
+// output in MX3 (out.Kp == N).  Arguments as launch_gemm_qkv_ln / launch_gemm_gelu_mx.
+void launch_gemm_mx_qkv_ln(const MxAct& A, const MxWeight& W, int M, int N, const float* bias, const float2* rowstat, const float* csum, uint16_t* q,
+                           uint16_t* k, uint16_t* vt, const AttnGeom& a, float scale, hipStream_t s);
+void launch_gemm_mx_gelu(const MxAct& A, const MxWeight& W, int M, int N, const float* bias, const float2* rowstat, const float* csum, const MxAct& out,
+                         hipStream_t s);
 
 // ----- attention (attention.hip) ---------------------------------------------------------------------------
 // q,k: [cells][H][TP][2*hdq]  vt: V operand, layout per attention_v_rowmajor()  out: packed-split [cells*T][ldo]
