@@ -325,8 +325,9 @@ def main():
                                + f"{len(models)} ViT classifiers per cell (normalise + label table + crop/soft-mask + ViT + vote)",
                    "baseline_config": "configs[4] (one tile per GPU, imputation)" if args.impute else ("configs[2]" if world == 1 else "configs[3]"),
                    "cells": n_cells, "models": list(models), "chunk_cells": args.chunk, "segment_streams": args.streams,
-                   "precision": "fp16 hi+lo split operands, fp32 accumulate: 3 fp16 MFMA passes per product, or (mlp.fc2 where 4 D % 128 == 0) fp16 hi*hi + "
-                                "two block-scaled fp8/fp6 corrections = 1.75 matrix units (matrix_units_per_product)",
+                   "precision": "fp16 hi+lo split operands, fp32 accumulate: 3 fp16 MFMA passes per product, or (mlp.fc2 where 4 D % 128 == 0; attn.qkv as a GEMM "
+                                "of its own and mlp.fc1 where D % 192 == 0) fp16 hi*hi + two block-scaled fp8/fp6 corrections = 1.75 matrix units per 128 k "
+                                "(matrix_units_per_product: issued units per algorithmic product, K padding included)",
                    "parallelism": ("single GPU" if world == 1 else f"one tile per rank x {world} (replicas only)" if args.impute
                                    else f"cells sharded over {world} rank(s), one all-gather of per-cell probabilities")},
         "vit_gflop_per_cell": round(flops_cell / 1e9, 4),
@@ -360,10 +361,7 @@ def main():
         prof, per_model = {}, []
         # the per-cell fused qkv + attention kernel (D <= 384) belongs to the family: it carries the qkv product of those classifiers
         GEMM_OPS = ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2", "cell_qkv_attention")
-        try:      # as the library reads it (atoi)
-            fused_attn = int(os.environ.get("RIBCA_CELL_ATTN", "1")) != 0
-        except ValueError:
-            fused_attn = False
+        fused_attn = fused_attn_on()
         for name, model in models.items():
             ops.prof_enable(True)
             one_pass(streams=1, models_sel=[name])
@@ -377,11 +375,10 @@ def main():
             m_fl = n_local * ((model.depth - 1) * 24.0 * 101 * d * d + 6.0 * 101 * d * d + 18.0 * d * d)
             if fused_attn and d <= 384:      # its attention FLOPs run inside the family's kernel
                 m_fl += n_local * (model.depth - 1) * 4.0 * 101 * 101 * d
-            # A in + output out + z read / written, 4 B per element (the fused qkv + attention kernel writes D instead of 3 D columns);
-            # the MX pair moves h (4 D columns) at 3 B per element in both directions: 8 D bytes fewer per row and layer
+            # A in + output out + z read / written (gemm_bytes_per_row: 4 B per element packed-split, 3 B in MX3)
             units = matrix_units(d)
             mu = (3.0 * units["qkv"] + units["proj"] + 4.0 * units["fc1"] + 4.0 * units["fc2"]) / 12.0
-            m_by = n_local * 101 * (model.depth - 1) * ((64.0 if (fused_attn and d <= 384) else 72.0) - (8.0 if units["fc2"] < 3.0 else 0.0)) * d
+            m_by = n_local * 101 * (model.depth - 1) * gemm_bytes_per_row(d)
             ai = m_fl / m_by
             # ridge of the issued work: this classifier's matrix units per product against the 16-bit dense peak, HBM at 8 TB/s
             ridge = PEAK_BF16_DENSE_TFLOPS * 1e12 / mu / 8.0e12
@@ -426,10 +423,7 @@ def main():
         alg_bytes = 0.0
         for name, model in models.items():      # algorithmic bytes per pass of the four GEMMs: A read once, output written once, z RMW
             d = model.D
-            qkv_io = (1 + 1) if (fused_attn and d <= 384) else (1 + 3)      # fused with attention: z in, attention output out; else z in, q / k / v out
-            hb = 3.0 if matrix_units(d)["fc2"] < 3.0 else 4.0      # bytes per element of h (MX3: fp16 hi + e4m3 lo + scale bytes)
-            per_row = 4.0 * d * qkv_io + 4.0 * d * (1 + 2) + (4.0 * d + hb * 4 * d) + (hb * 4 * d + 4.0 * d * 2)      # qkv, proj, fc1, fc2
-            alg_bytes += n_local * 101 * (model.depth - 1) * per_row + 12.0 * d * d * 4.0 * model.depth * ((n_local + args.chunk - 1) // args.chunk)
+            alg_bytes += n_local * 101 * (model.depth - 1) * gemm_bytes_per_row(d) + 12.0 * d * d * 4.0 * model.depth * ((n_local + args.chunk - 1) // args.chunk)
         # the bound that binds most of the GEMM time: every classifier's GEMMs are priced against their own roofline (per_model_*),
         # the family's label is the time-weighted majority
         sustained = sustained_probe_tflops()
@@ -449,10 +443,11 @@ def main():
                            "bound_note": f"time-weighted over the classifiers: {t_mfma:.0f} ms of GEMMs MFMA-bound ({', '.join(m['model'] for m in per_model if m['bound'] == 'mfma')}), "
                                          f"{t_hbm:.0f} ms HBM-bound ({', '.join(m['model'] for m in per_model if m['bound'] == 'hbm')}); "
                                          "a classifier's side of the ridge follows its algorithmic FLOP per byte (per_model_flop_per_byte) against 2.5 PF / its matrix units per product / 8 TB/s",
-                           "kernel": "gemm_mx_duo_kernel (mlp.fc2 at D = 288 / 384 / 576: fp16 hi*hi + block-scaled fp8/fp6 corrections, 3-byte activations) + "
-                                     "gemm_ps_duo_kernel (fc1 -- its GELU epilogue writes the MX operand --, qkv at D = 576; proj at D = 144 / 288 / 576 and fc2 at D = 144 with the "
-                                     "residual tile through the operand ring) + gemm_ps_split_kernel (proj at D = 384, the last blocks' CLS rows) + cell_qkv_attention_kernel "
-                                     "(norm1 + qkv + attention, D <= 384), fp16x3", "achieved": round(achieved, 2),
+                           "kernel": "gemm_mx_duo_kernel (fp16 hi*hi + block-scaled fp8/fp6 corrections, 3-byte activations: mlp.fc2 at D = 288 / 384 / 576, "
+                                     "mlp.fc1 at D = 384 / 576, attn.qkv at D = 576) + gemm_ps_duo_kernel (fp16x3: attn.proj with the residual tile through the "
+                                     "operand ring -- writing the new rows in MX3 as well at D = 384 / 576 --, fc1 at D = 144 / 288, fc2 at D = 144) + "
+                                     "gemm_ps_split_kernel (the last blocks' CLS rows) + cell_qkv_attention_kernel (norm1 + qkv + attention, D <= 384, fp16x3)",
+                           "achieved": round(achieved, 2),
                            "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 5),
                            "traffic": traffic, "traffic_unit": f"bytes/launch (2*FETCH_SIZE + WRITE_SIZE, {traffic_src})",
                            "algorithmic_bytes_per_launch": round(alg_bytes / max(g_n, 1)),
@@ -488,12 +483,41 @@ def main():
         tdist.destroy_process_group()
 
 
+def fused_attn_on():
+    """RIBCA_CELL_ATTN as the library reads it (atoi)"""
+    try:
+        return int(os.environ.get("RIBCA_CELL_ATTN", "1")) != 0
+    except ValueError:
+        return False
+
+
 def matrix_units(d):
-    """matrix units (one unit = one pass of the 16-bit dense rate) issued per product of the four Linears of a full block at width d:
-    three fp16 passes, or 1.75 (4 x f16 + fp8 x fp6 at half rate + fp6 x fp6 at quarter rate per 128 k) where the MX pair runs"""
+    """matrix units (one unit = one pass of the 16-bit dense rate) ISSUED per algorithmic product of the four Linears of a full block at
+    width d: three fp16 passes, or 1.75 (4 x f16 + fp8 x fp6 at half rate + fp6 x fp6 at quarter rate per 128 k) on the MX kernel -- times
+    the K padding where the MX kernel pads D to a multiple of 128 (qkv / fc1 at D = 576: 640 / 576).  qkv inside the fused per-cell
+    kernel (D <= 384) stays at three passes."""
     from multiplexed_image_annotator_amd import _lib
     mx = bool(_lib.lib().ribca_mx_enabled(int(d)))
-    return {"qkv": 3.0, "proj": 3.0, "fc1": 3.0, "fc2": 1.75 if mx else 3.0}
+    mxz = bool(_lib.lib().ribca_mxz_enabled(int(d)))
+    pad = ((d + 127) // 128 * 128) / float(d)
+    qkv_own = not (fused_attn_on() and d <= 384)
+    return {"qkv": 1.75 * pad if (mxz and qkv_own) else 3.0, "proj": 3.0, "fc1": 1.75 * pad if mxz else 3.0, "fc2": 1.75 if mx else 3.0}
+
+
+def gemm_bytes_per_row(d):
+    """algorithmic bytes per token row and full block of the four Linears' launches: A read once, output written once, z read and written
+    by proj / fc2 (4 B per element packed-split, 3 B in MX3: fp16 hi + e4m3 lo + scale bytes)"""
+    from multiplexed_image_annotator_amd import _lib
+    mx = bool(_lib.lib().ribca_mx_enabled(int(d)))
+    mxz = bool(_lib.lib().ribca_mxz_enabled(int(d)))
+    qkv_own = not (fused_attn_on() and d <= 384)
+    hb = 3.0 if mx else 4.0                                        # bytes per element of h
+    zb = 3.0 if mxz else 4.0                                       # bytes per element of the residual rows qkv (own GEMM) / fc1 read
+    qkv = ((zb if qkv_own else 4.0) + (3 * 4.0 if qkv_own else 4.0)) * d      # fused with attention: z in, attention output out
+    proj = 4.0 * d * (1 + 2) + (3.0 * d if mxz else 0.0)            # + the MX3 copy of the new rows
+    fc1 = zb * d + hb * 4 * d
+    fc2 = hb * 4 * d + 4.0 * d * 2 + (3.0 * d if (mxz and qkv_own) else 0.0)
+    return qkv + proj + fc1 + fc2
 
 
 def avg_units(dims, depths):
