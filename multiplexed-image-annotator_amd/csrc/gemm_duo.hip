@@ -461,9 +461,11 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
     // (48-column wave blocks; its launcher adds the 2 KB of exchange space behind the ring)
     if constexpr (TN == 3 && WM == 1 && RB == MT) {
       if (epi.zmx.hi != nullptr) {      // workgroup-uniform
-        const unsigned xch = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (unsigned)(NST * STAGE);
-        if (m0 + BM <= M) mx3_emit_wave48<MT, true>(epi.zmx, M, m0, n0 + wn * 48, g, r16, wave, xch, acc[0]);
-        else mx3_emit_wave48<MT, false>(epi.zmx, M, m0, n0 + wn * 48, g, r16, wave, xch, acc[0]);
+        // (the launcher sized the LDS for it: the staging image over the ring -- no wave reads the ring once all have reached the emission's
+        // first barrier -- and the exchange space behind it)
+        const unsigned stg = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem, xch = stg + (unsigned)kMx3StageBytes;
+        if (m0 + BM <= M) mx3_emit_wave48<MT, true>(epi.zmx, M, m0, n0 + wn * 48, g, r16, wave, stg, xch, acc[0]);
+        else mx3_emit_wave48<MT, false>(epi.zmx, M, m0, n0 + wn * 48, g, r16, wave, stg, xch, acc[0]);
       }
     }
   } else if constexpr (is_mx_out<Epi>::value) {
@@ -532,8 +534,10 @@ static bool launch_duo_impl(const GemmArgs& g, const Epi& epi, hipStream_t s, in
   constexpr int NST = BM == 256 ? 2 : 3;
   const int mtiles = (g.M + BM - 1) / BM;
   const int ntiles = gemm_padded_n(g.N) / BN;
-  // (+ 2 KB behind the ring where the epilogue may emit an MX3 copy: gemm_epi.h mx3_emit_wave48)
-  const size_t lds = lds_pad ? (size_t)100 * 1024 : (size_t)NST * BM * ROWB + ((is_zk<Epi>::value && TN == 3 && WM == 1) ? 2048 : 0);
+  size_t lds = lds_pad ? (size_t)100 * 1024 : (size_t)NST * BM * ROWB;
+  if constexpr (is_zk<Epi>::value && TN == 3 && WM == 1) {      // an MX3 copy of the new rows: staging image + exchange space (gemm_epi.h mx3_emit_wave48)
+    if (epi.zmx.hi != nullptr && lds < (size_t)kMx3StageBytes + 2048) lds = (size_t)kMx3StageBytes + 2048;
+  }
   const uint16_t* wf = wf_for(g, s);
   if (wf == nullptr) return false;
   const dim3 grid(mtiles * ntiles), block(64 * NW);

@@ -471,13 +471,14 @@ __device__ __forceinline__ void gelu_mx_epilogue(const EpiGeluMx& epi, int mbase
   }
 }
 
-// ---- MX3 emission from a wave that owns MT row tiles x 3 column tiles (48 columns starting at a multiple of 48; lane: row r16 of every row
-// tile, columns 4 g .. 4 g + 3 of every column tile).  32-column scale blocks against 48-column wave blocks: an EVEN wave block owns its
-// columns 0 .. 31 (tiles 0, 1) and shares 32 .. 47 (tile 2) with tile 0 of the next (odd) wave block, which owns its columns 16 .. 47.  The
-// shared block's maximum goes through 2 KB of LDS (xch: [4 waves][128 rows] floats outside every ring slot) and ONE workgroup barrier:
+// ---- MX3 emission of a 128 x 192 workgroup tile whose four waves own 8 row tiles x 3 column tiles each (48 columns starting at a multiple
+// of 48; lane: row r16 of every row tile, columns 4 g .. 4 g + 3 of every column tile).  32-column scale blocks against 48-column wave
+// blocks: an EVEN wave block owns its columns 0 .. 31 (tiles 0, 1) and shares 32 .. 47 (tile 2) with tile 0 of the next (odd) wave block,
+// which owns its columns 16 .. 47.  The shared block's maximum goes through 2 KB of LDS (xch: [4 waves][128 rows] floats outside the
+// staging image) and a workgroup barrier; the converted pieces through the staging image (stg) and a second barrier.
 // EVERY wave of the workgroup must call this (the launchers take N % 192 == 0: no wave of a tile lies beyond N).
-// x: the values to emit, already clamped to the fp16 range.  The pair (g, g ^ 1) owns 8 consecutive columns of a tile: the even lane stores
-// their 8 hi halves (16 bytes, permuted plane), the odd lane their 8 lo bytes.
+// x: the values to emit, already clamped to the fp16 range.  The pair (g, g ^ 1) owns 8 consecutive columns of a tile: the even lane stages
+// their 8 hi halves (16 bytes), the odd lane their 8 lo bytes.
 template <int... Is, class F>
 __device__ __forceinline__ void epi_sfor_impl(std::integer_sequence<int, Is...>, F&& f) { (f(std::integral_constant<int, Is>{}), ...); }
 template <int N, class F>
@@ -494,9 +495,24 @@ template <int CNT> __device__ __forceinline__ void epi_wait_lgkm2(float& v, floa
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(v), "+v"(w) : "n"(CNT) : "memory");
 }
 
+template <int OFF> __device__ __forceinline__ void epi_lds_wr128(unsigned addr, const u32x4& v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF> __device__ __forceinline__ void epi_lds_wr64(unsigned addr, const u32x2s& v) {
+  asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF> __device__ __forceinline__ void epi_lds_rd128(u32x4& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int CNT> __device__ __forceinline__ void epi_wait_lgkm128(u32x4& v) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(CNT) : "memory"); }
+// staging image of a 128 x 192 tile's MX3 planes: hi rows of 24 chunks in plane order (384 bytes, pitch 400: the 16 rows a wave instruction
+// writes then fall into 16 different bank groups), lo rows of 192 bytes (pitch 208)
+constexpr int kMx3StageHiRow = 400, kMx3StageL8Row = 208, kMx3StageBytes = 128 * (kMx3StageHiRow + kMx3StageL8Row);
+
 template <int MT, bool IN>
-__device__ __forceinline__ void mx3_emit_wave48(const MxAct& out, int M, int m0, int ncol0, int g_in, int r16_in, int wave, unsigned xch_lds,
-                                                const f32x4 (&x)[MT][3]) {
+__device__ __forceinline__ void mx3_emit_wave48(const MxAct& out, int M, int m0, int ncol0, int g_in, int r16_in, int wave, unsigned stg_lds,
+                                                unsigned xch_lds, const f32x4 (&x)[MT][3]) {
+  static_assert(MT == 8, "the staging image is that of a 128-row tile");
   // (opaque copies: everything below that derives from the lane's position is then formed HERE, not shared with the kernel's prologue and
   // carried -- or spilled -- across the K loop)
   int g = g_in, r16 = r16_in;
@@ -542,27 +558,36 @@ __device__ __forceinline__ void mx3_emit_wave48(const MxAct& out, int M, int m0,
     });
     asm volatile("" : "+v"(ss_pk[q]));
   });
-  // Stores through descriptors over the tile's rows of the two data planes: ONE 32-bit offset register per column tile instead of a 64-bit
-  // address per (row tile, column tile) -- the scheduler otherwise forms all 48 of them up front, beside the 96 accumulators -- and rows
-  // beyond M are dropped by the range check.
+  // The converted pieces go through LDS (stg_lds: kMx3StageBytes that no wave reads any more once every wave has passed the barrier above -- the
+  // operand ring) and leave it as whole runs: stored straight from the accumulator layout a wave instruction writes 32 isolated 16-byte
+  // pieces of the permuted hi plane and 32 8-byte pieces of the lo plane -- the same bytes in contiguous runs take 4 of the 7 ms that the
+  // stores of 44 fc1 launches at D = 576 cost (profiles/r4/mx_emit_store_ablation.txt).
   const int Kp = out.Kp;
-  const int rows = IN ? 16 * MT : ((M - m0) < 16 * MT ? (M - m0) : 16 * MT);
-  const __amdgpu_buffer_rsrc_t hi_rsrc = __builtin_amdgcn_make_buffer_rsrc(out.hi + (size_t)m0 * Kp, 0, rows * Kp * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t l8_rsrc = __builtin_amdgcn_make_buffer_rsrc(out.l8 + (size_t)m0 * Kp, 0, rows * Kp, 0x00020000);
-  const int c8 = ncol0 + 8 * (g >> 1);      // + 16 j: the 8 columns the pair (g, g ^ 1) owns in column tile j
-  int hi_voff[3];
+  const int n0 = ncol0 / 192 * 192, wcol = ncol0 - n0;      // the tile's first column (a multiple of 192) and the wave's first column in it
+  const bool half_first = (n0 & 64) != 0;                   // the tile starts in the middle of a 128-column group of the hi plane
+  const int c8 = wcol + 8 * (g >> 1);                       // + 16 j: the 8 columns the pair (g, g ^ 1) owns in column tile j, relative to the tile
+  // slot (16-byte chunk of the staged 384-byte hi row) of an 8-column piece: the row's chunks in PLANE order -- a whole group is 16 chunks
+  // at the plane's positions, a half group its 8 pieces (sub-step s = 0 .. 3, two adjacent 8-column pieces each)
+  unsigned hi_st[3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) hi_voff[j] = (r16 * Kp + mx_hi_pos(c8 + 16 * j)) * 2;
-  const int l8_voff = r16 * Kp + c8;
+  for (int j = 0; j < 3; ++j) {
+    const int c = n0 + c8 + 16 * j, s_ = (c >> 3) & 3, gg = (c >> 5) & 3;
+    const bool in_first = (c >> 7) == (n0 >> 7);
+    int q;
+    if (!half_first) q = in_first ? 4 * s_ + gg : 16 + 2 * s_ + gg;      // whole group, then the first half (gg = 0, 1) of the next
+    else q = in_first ? 2 * s_ + gg - 2 : 8 + 4 * s_ + gg;               // second half (gg = 2, 3), then a whole group
+    hi_st[j] = stg_lds + (unsigned)(r16 * kMx3StageHiRow + q * 16);
+  }
+  const unsigned l8_st = stg_lds + (unsigned)(128 * kMx3StageHiRow + r16 * kMx3StageL8Row + c8);
+  const int rows = IN ? 16 * MT : ((M - m0) < 16 * MT ? (M - m0) : 16 * MT);
   const int blk_own = (ncol0 + (odd ? 16 : 0)) >> 5, blk_sh = (ncol0 + (odd ? 0 : 32)) >> 5;      // 32-column block indices
   unsigned char* sc_own = out.sc + ((size_t)(blk_own >> 2) * out.M + m0 + r16) * 4 + (blk_own & 3);
   unsigned char* sc_sh = out.sc + ((size_t)(blk_sh >> 2) * out.M + m0 + r16) * 4 + (blk_sh & 3);
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
+  epi_sfor<MT>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
     const int sl_o = (int)((so_pk[i / 4] >> (8 * (i % 4))) & 0xffu), sl_s = (int)((ss_pk[i / 4] >> (8 * (i % 4))) & 0xffu);
-    const int row_soff = i * 16 * Kp;      // wave-uniform
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    epi_sfor<3>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
       const bool shared = odd ? j == 0 : j == 2;
       const float scale = e8m0_float(shared ? sl_s : sl_o);
       uint2 hi;
@@ -576,14 +601,67 @@ __device__ __forceinline__ void mx3_emit_wave48(const MxAct& out, int M, int m0,
       // purpose: handed the same value twice hipcc folds the swap's two results into one, tools/swap_probe.hip)
       const auto rx = __builtin_amdgcn_permlane16_swap(hi.x, l8, false, false);
       const auto ry = __builtin_amdgcn_permlane16_swap(hi.y, l8, false, false);
-      if ((g & 1) == 0) __builtin_amdgcn_raw_buffer_store_b128(u32x4{rx[0], ry[0], rx[1], ry[1]}, hi_rsrc, hi_voff[j], row_soff * 2, 0);
-      else __builtin_amdgcn_raw_buffer_store_b64(u32x2s{rx[0], rx[1]}, l8_rsrc, l8_voff + 16 * j, row_soff, 0);
-    }
+      if ((g & 1) == 0) epi_lds_wr128<i * 16 * kMx3StageHiRow>(hi_st[j], u32x4{rx[0], ry[0], rx[1], ry[1]});
+      else epi_lds_wr64<i * 16 * kMx3StageL8Row + 16 * j>(l8_st, u32x2s{rx[0], rx[1]});
+    });
     if ((IN || r16 + 16 * i < rows) && g == 0) {
       sc_own[i * 64] = (unsigned char)sl_o;
       if (!odd) sc_sh[i * 64] = (unsigned char)sl_s;
     }
     __builtin_amdgcn_sched_barrier(0);
+  });
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  // ---- out of LDS in runs: rows beyond M are dropped by the descriptors' range check
+  const __amdgpu_buffer_rsrc_t hi_rsrc = __builtin_amdgcn_make_buffer_rsrc(out.hi + (size_t)m0 * Kp, 0, rows * Kp * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t l8_rsrc = __builtin_amdgcn_make_buffer_rsrc(out.l8 + (size_t)m0 * Kp, 0, rows * Kp, 0x00020000);
+  const int tid = wave * 64 + r16 + 16 * g;
+  {
+    // hi: 8 consecutive lanes take 8 consecutive chunks (128 bytes) of a row, three times per row (24 chunks), 32 rows per instruction
+    const int l8i = tid & 7, row0 = tid >> 3;
+    const int gbase = (n0 >> 7) * 128;      // first column of the 128-column group the tile starts in
+    int pos[3];                             // plane position (fp16 elements from the row start) of chunk q = l8i + 8 t
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int q = l8i + 8 * t;
+      if (!half_first) pos[t] = q < 16 ? gbase + 8 * q : gbase + 128 + 32 * ((q - 16) >> 1) + 8 * ((q - 16) & 1);
+      else pos[t] = q < 8 ? gbase + 32 * (q >> 1) + 8 * (2 + (q & 1)) : gbase + 128 + 8 * (q - 8);
+    }
+    const unsigned rd = stg_lds + (unsigned)(row0 * kMx3StageHiRow + l8i * 16);
+    const int voff = row0 * Kp * 2;
+    u32x4 v[12];
+    epi_sfor<4>([&](auto rc) {
+      constexpr int rr = decltype(rc)::value;
+      epi_sfor<3>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        epi_lds_rd128<rr * 32 * kMx3StageHiRow + t * 128>(v[rr * 3 + t], rd);
+      });
+    });
+    epi_sfor<12>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      epi_wait_lgkm128<11 - k>(v[k]);
+      __builtin_amdgcn_raw_buffer_store_b128(v[k], hi_rsrc, voff + pos[k % 3] * 2, (k / 3) * 32 * Kp * 2, 0);
+    });
+  }
+  {
+    // lo: a row is 192 bytes = 12 chunks; 4 consecutive lanes take 4 consecutive chunks, three times per row, 64 rows per instruction
+    const int l4 = tid & 3, row0 = tid >> 2;
+    const unsigned rd = stg_lds + (unsigned)(128 * kMx3StageHiRow + row0 * kMx3StageL8Row + l4 * 16);
+    const int voff = row0 * Kp + n0 + l4 * 16;
+    u32x4 v[6];
+    epi_sfor<2>([&](auto rc) {
+      constexpr int rr = decltype(rc)::value;
+      epi_sfor<3>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        epi_lds_rd128<rr * 64 * kMx3StageL8Row + t * 64>(v[rr * 3 + t], rd);
+      });
+    });
+    epi_sfor<6>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      epi_wait_lgkm128<5 - k>(v[k]);
+      __builtin_amdgcn_raw_buffer_store_b128(v[k], l8_rsrc, voff + (k % 3) * 64, (k / 3) * 64 * Kp, 0);
+    });
   }
 }
 
@@ -673,8 +751,8 @@ __device__ __forceinline__ void resid_zk_epilogue(const EpiResidZK& epi, int mba
 
 // mlp.fc1 on the MX kernel (gemm_mx.hip: a wave owns MT x 3 tiles): LayerNorm fold + GELU in place, then the MX3 planes of the result
 template <int MT, bool IN>
-__device__ __forceinline__ void gelu_mx48_epilogue(const EpiGeluMx& epi, int m0, int ncol0, int g, int r16, int wave, unsigned xch_lds,
-                                                   f32x4 (&acc)[1][MT][3]) {
+__device__ __forceinline__ void gelu_mx48_epilogue(const EpiGeluMx& epi, int m0, int ncol0, int g, int r16, int wave, unsigned stg_lds,
+                                                   unsigned xch_lds, f32x4 (&acc)[1][MT][3]) {
   const int nb0 = ncol0 + 4 * g, mbase = m0 + r16;
   float4 b4[3], c4[3];
   LnRow rs[MT];
@@ -698,12 +776,23 @@ __device__ __forceinline__ void gelu_mx48_epilogue(const EpiGeluMx& epi, int m0,
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const float4 f = ln_fold4<true>(acc[0][i][j], b4[j], c4[j], rs[i]);
+#ifdef MXDBG_NOGELU      // (timing ablation, tools/build_mx_variant.py)
+      const f32x2v u0 = f32x2v{f.x, f.y}, u1 = f32x2v{f.z, f.w};
+#else
       const f32x2v u0 = gelu_erf2(f32x2v{f.x, f.y}), u1 = gelu_erf2(f32x2v{f.z, f.w});
+#endif
       acc[0][i][j] = f32x4{clamp_f16_range(u0.x), clamp_f16_range(u0.y), clamp_f16_range(u1.x), clamp_f16_range(u1.y)};
       // (one tile at a time: interleaving the 24 erf evaluations costs more registers than the wave has beside its accumulators)
       if ((j & 1) == 1 || j == 2) __builtin_amdgcn_sched_barrier(0);
     }
-  mx3_emit_wave48<MT, IN>(epi.out, epi.M, m0, ncol0, g, r16, wave, xch_lds, acc[0]);
+#ifdef MXDBG_NOEMIT
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) asm volatile("" ::"v"(acc[0][i][j]));
+#else
+  mx3_emit_wave48<MT, IN>(epi.out, epi.M, m0, ncol0, g, r16, wave, stg_lds, xch_lds, acc[0]);
+#endif
 }
 
 

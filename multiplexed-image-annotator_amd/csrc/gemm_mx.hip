@@ -259,8 +259,9 @@ namespace {
 constexpr int MX_BM = 128, MX_BN = 192, MX_MT = 8, MX_TN = 3;
 // LDS map: hi as two halves of 128 rows x 128 bytes (sub-steps 0-1 | 2-3), the fp6 rows, two scale slots, two lo slots
 constexpr int L_HI = 0, L_H6A = 32768, L_H6B = 40960, L_SC = 45056, L_SC_SLOT = 640, L_L8 = L_SC + 2 * L_SC_SLOT, L_XCH = L_L8 + 32768;
-// (L_XCH: 2 KB outside every ring slot for the MX3-emitting epilogues, gemm_epi.h mx3_emit_wave48)
+// (L_XCH: 2 KB outside every ring slot for the MX3-emitting epilogues, gemm_epi.h mx3_emit_wave48; their staging image overlays the ring)
 constexpr int L_TOTAL = L_XCH + 2048;
+static_assert(kMx3StageBytes <= L_XCH, "the staging image of the MX3 emission must not reach the exchange space");
 static_assert(L_L8 % 16 == 0, "LDS-DMA destination alignment");
 __device__ __forceinline__ int mx_f4(int row) { return (4 - ((row >> 2) & 3)) & 3; }      // chunk swizzle of the 64-byte hi rows
 // chunk swizzle of the 128-byte lo rows: an fp8 operand's lane (row, g) holds k = 16 g .. + 15 and 64 + 16 g .. + 15 (tools/mx_kmap_probe.hip:
@@ -662,14 +663,18 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
     const bool emit = epi.zmx.hi != nullptr;
     if (m0 + BM <= M) {
       resid_zk_epilogue<TN, MT, MT, true>(epi, mbase, nbase, blk, ge, acc, zb4, zpm);
-      if (emit) mx3_emit_wave48<MT, true>(epi.zmx, M, m0, n0 + wn * (16 * TN), ge, r16e, wave, xch, acc[0]);
+      if (emit) mx3_emit_wave48<MT, true>(epi.zmx, M, m0, n0 + wn * (16 * TN), ge, r16e, wave, lds_base, xch, acc[0]);
     } else {
       resid_zk_epilogue<TN, MT, MT, false>(epi, mbase, nbase, blk, ge, acc, zb4, zpm);
-      if (emit) mx3_emit_wave48<MT, false>(epi.zmx, M, m0, n0 + wn * (16 * TN), ge, r16e, wave, xch, acc[0]);
+      if (emit) mx3_emit_wave48<MT, false>(epi.zmx, M, m0, n0 + wn * (16 * TN), ge, r16e, wave, lds_base, xch, acc[0]);
     }
   } else {
     // N is a multiple of the tile width for these (gemm_mx_supported + the launchers): only the rows need guards
+#ifdef MXDBG_NOEPI
+    if (true) {
+#else
     if (ABL & 1) {
+#endif
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -677,8 +682,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
       return;
     }
     if constexpr (is_mx_out<Epi>::value) {
-      if (m0 + BM <= M) gelu_mx48_epilogue<MT, true>(epi, m0, n0 + wn * (16 * TN), ge, r16e, wave, xch, acc);
-      else gelu_mx48_epilogue<MT, false>(epi, m0, n0 + wn * (16 * TN), ge, r16e, wave, xch, acc);
+      if (m0 + BM <= M) gelu_mx48_epilogue<MT, true>(epi, m0, n0 + wn * (16 * TN), ge, r16e, wave, lds_base, xch, acc);
+      else gelu_mx48_epilogue<MT, false>(epi, m0, n0 + wn * (16 * TN), ge, r16e, wave, lds_base, xch, acc);
     } else {
       if (m0 + BM <= M) run_epilogue<TN, Epi, MT, true>(epi, mbase, nbase, acc[0]);
       else run_epilogue<TN, Epi, MT>(epi, mbase, nbase, acc[0]);
