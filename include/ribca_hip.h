@@ -263,7 +263,7 @@ int ribca_test_qkv_attention_fold(const uint16_t* z_ps, int32_t lda, const uint1
 int ribca_test_gemm_duo_gelu(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
                              const float* bias, const float* csum, const float* rowstat, uint16_t* wf_scratch, uint16_t* out, int32_t ldo,
                              void* stream);
-/* norm1 -> attn.qkv -> attention of `cells` cells in ONE per-cell kernel (cell_attention.hip; D = 144 or 288): same inputs as
+/* norm1 -> attn.qkv -> attention of `cells` cells in ONE per-cell kernel (cell_attention.hip; D = 144, 288 or 384): same inputs as
  * ribca_test_qkv_attention_fold, q / k / v never leave the CU.  Non-zero return: geometry not supported. */
 int ribca_test_cell_attention(const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t cells, int32_t D,
                               const float* bias2, const float* csum, const float* rowstat, uint16_t* out, int32_t ldo, void* stream);

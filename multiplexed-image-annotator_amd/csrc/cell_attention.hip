@@ -346,12 +346,9 @@ void launch_cell_qkv_attention(const uint16_t* z, int ldz, const uint16_t* W, in
                                uint16_t* out, int ldo, int cells, int D, float scale, hipStream_t s) {
   if (cells <= 0) return;
   auto go = [&](auto kern, int lds) {
-    static bool attr_set[3] = {false, false, false};
+    static unsigned long long attr_done[3] = {0ull, 0ull, 0ull};      // per width (one kernel instantiation each) and device
     const int slot = D == 288 ? 1 : D == 384 ? 2 : 0;
-    if (!attr_set[slot]) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      attr_set[slot] = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done[slot]);
 #ifdef RIBCA_DIAG
     static const int dbg = getenv("RIBCA_CELL_DBG") ? atoi(getenv("RIBCA_CELL_DBG")) : 0;      // timing ablations of tools/bench_cell_attention.py
 #else

@@ -563,12 +563,8 @@ static bool launch_duo_impl(const GemmArgs& g, const Epi& epi, hipStream_t s, in
   const int mode_p = (mode & 0xef) | guarded | (panel << 8);
   auto go = [&](auto abl_c) {
     constexpr int ABL = decltype(abl_c)::value;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ps_duo_kernel<BM, NW, WM, TN, NWS, Epi, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(100 * 1024));
-      attr_set = true;
-    }
+    static unsigned long long attr_done = 0ull;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_ps_duo_kernel<BM, NW, WM, TN, NWS, Epi, ABL>), (int)(100 * 1024), attr_done);
     hipLaunchKernelGGL((gemm_ps_duo_kernel<BM, NW, WM, TN, NWS, Epi, ABL>), grid, block, lds, s, g.A, g.lda, wf, g.M, g.Kp, mtiles, ntiles, epi, mode_p, delay);
   };
   // the diagnostic forms (no epilogue / stamps) exist for the epilogues tools/bench_gemm.py and tools/stamp_duo.py drive

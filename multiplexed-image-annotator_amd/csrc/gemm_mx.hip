@@ -699,11 +699,8 @@ static void launch_mx_impl(const MxAct& A, const MxWeight& W, int M, int N, cons
   const int mtiles = (M + MX_BM - 1) / MX_BM, ntiles = (N + MX_BN - 1) / MX_BN;
   const int nb = A.Kp / 128;
   void (*kernel)(MxAct, const uint16_t*, const unsigned char*, int, int, int, int, Epi) = gemm_mx_duo_kernel<Epi, ABL>;
-  static bool attr_set = false;      // (one process per GPU: see launch_duo_impl)
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL);
-    attr_set = true;
-  }
+  static unsigned long long attr_done = 0ull;
+  ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), L_TOTAL, attr_done);
   kernel<<<dim3(mtiles * ntiles), dim3(256), L_TOTAL, s>>>(A, W.wh, W.wx, M, nb, mtiles, ntiles, epi);
 }
 

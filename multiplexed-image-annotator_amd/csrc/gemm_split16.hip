@@ -795,12 +795,8 @@ static void launch_split(const GemmArgs& g, const Epi& epi, hipStream_t s) {
   const int mtiles = (g.M + 255) / 256;
   const int ntiles = gemm_padded_n(g.N) / BN;
   const size_t lds = (size_t)3 * (256 + BN) * ROWB + ((Epi::kFold || std::is_same<Epi, EpiResidPS>::value) ? fold_lds_bytes<BN>() : 0);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ps_split_kernel<BN, Epi, ABL, STAG, LEPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set = true;
-  }
+  static unsigned long long attr_done = 0ull;
+  ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_ps_split_kernel<BN, Epi, ABL, STAG, LEPI>), (int)lds, attr_done);
   // tile time in 10 ns ticks: K steps of ~0.65/0.87/1.15 us (BN 64/96/128) + pipeline fill + epilogue
   int deph = 0;
   static const bool env_deph = getenv("RIBCA_GEMM_DEPH") != nullptr;

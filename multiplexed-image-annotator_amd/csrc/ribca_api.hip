@@ -376,7 +376,7 @@ void resid_ps_and_stats(const GemmArgs& g, const BlockWs& w, int ldz_rows, int D
   const ResidStatGeom sg = launch_gemm_resid_ps(g, w.zps, ldz_rows, want_stats ? w.part : nullptr, w.rs, prev_stride, s);
   if (want_stats) launch_ln_finalize(w.part, sg.tiles, g.M, sg.bn, D, w.rs, s);
 }
-// norm1 -> qkv -> attention of a whole block in ONE per-cell kernel (cell_attention.hip) where the geometry allows (D = 144, 288):
+// norm1 -> qkv -> attention of a whole block in ONE per-cell kernel (cell_attention.hip) where the geometry allows (D = 144, 288, 384):
 // 13.9 -> 14.4 k cells/s in a same-box A/B (profiles/r3/ab_cell_attention.txt).  RIBCA_CELL_ATTN=0: the unfused pair, for A/B.
 bool cell_attn_on(const AttnGeom& a) {
   static const int v = getenv("RIBCA_CELL_ATTN") ? atoi(getenv("RIBCA_CELL_ATTN")) : 1;

@@ -23,6 +23,24 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdio>
+#include <cstdlib>
+
+// Raises a kernel's dynamic-LDS limit, once per (call site, device): a flag per call site alone would leave the second device of a process
+// without the attribute (the launch would then fail with "invalid argument" -- or, worse, be dropped).  A failure is fatal: a launch that
+// silently does not happen leaves stale results behind.  `done`: one bit per device ordinal (< 64), owned by the call site.
+inline void ensure_dynamic_lds(const void* kernel, int bytes, unsigned long long& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (dev >= 0 && dev < 64 && ((done >> dev) & 1ull)) return;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    fprintf(stderr, "ribca: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed on device %d: %s\n", bytes, dev, hipGetErrorString(e));
+    abort();
+  }
+  if (dev >= 0 && dev < 64) done |= 1ull << dev;
+}
+
 
 namespace ribca {
 

@@ -100,7 +100,7 @@ void launch_gemm_mx_gelu(const MxAct& A, const MxWeight& W, int M, int N, const 
 void launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int ldo, int cells, const AttnGeom& a,
                       hipStream_t s, int q_tiles = 0);
 
-// ----- per-cell fusion norm1 -> qkv -> attention (cell_attention.hip): D = 144 / 288 (head dims 12 / 24), 101 tokens, 12 heads.
+// ----- per-cell fusion norm1 -> qkv -> attention (cell_attention.hip): D = 144 / 288 / 384 (head dims 12 / 24 / 32), 101 tokens, 12 heads.
 // z: packed-split residual rows, W / bias2 / csum: the folded qkv weight (row-major packed-split) and its vectors, rowstat: (rstd, mean)
 // per row; out: packed-split attention output rows.  Replaces launch_gemm_qkv_ln + launch_attention for whole blocks.
 bool cell_attention_supported(int D, int H, int T);

@@ -60,10 +60,46 @@ def read_image(path: str) -> np.ndarray:
 
 
 class TiffUnsupported(ValueError):
-    """a TIFF feature ``read_tiff`` does not implement (the caller falls back to PIL)"""
+    """a TIFF feature ``read_tiff`` does not implement, or a file it cannot make sense of (the caller falls back to PIL)"""
+
+
+class TiffStackError(ValueError):
+    """the file is a Z / T stack: not the (C, H, W) image the hot path takes (tifffile would return a 4-D / 5-D array, which
+    ``as_channel_planes`` rejects) -- never handed to a fallback reader that would flatten it into channels"""
 
 
 _TIFF_TYPES = {1: "B", 2: "c", 3: "H", 4: "I", 5: "II", 6: "b", 7: "B", 8: "h", 9: "i", 10: "ii", 11: "f", 12: "d", 13: "I", 16: "Q", 17: "q", 18: "Q"}
+
+
+def _stack_dims(description: str, path: str):
+    """(expected pages or None, images stored behind ONE IFD or None) from the first page's ImageDescription: OME-XML ``SizeC / SizeZ /
+    SizeT`` and ImageJ ``images= / channels= / slices= / frames=``.  A description that announces Z or T planes raises TiffStackError."""
+    import re
+    if not description:
+        return None, None
+    if "<OME" in description and "<Pixels" in description:
+        px = description[description.index("<Pixels"):]
+        px = px[:px.index(">") + 1] if ">" in px else px
+        dims = {}
+        for key in ("SizeC", "SizeZ", "SizeT"):
+            m = re.search(key + r'\s*=\s*"(\d+)"', px)
+            dims[key] = int(m.group(1)) if m else 1
+        if dims["SizeZ"] != 1 or dims["SizeT"] != 1:
+            raise TiffStackError(f"{path}: OME stack with SizeZ = {dims['SizeZ']}, SizeT = {dims['SizeT']}: expected one (C, H, W) image")
+        return dims["SizeC"], None
+    if description.startswith("ImageJ="):
+        kv = dict(line.split("=", 1) for line in description.splitlines() if "=" in line)
+
+        def num(key, default):
+            try:
+                return int(kv.get(key, default))
+            except ValueError:
+                return default
+        images, slices, frames = num("images", 1), num("slices", 1), num("frames", 1)
+        if slices != 1 or frames != 1:
+            raise TiffStackError(f"{path}: ImageJ hyperstack with slices = {slices}, frames = {frames}: expected one (C, H, W) image")
+        return images, images
+    return None, None
 
 
 def read_tiff(path: str) -> np.ndarray:
@@ -71,34 +107,60 @@ def read_tiff(path: str) -> np.ndarray:
 
     * little- or big-endian, classic (II*\0 / MM\0*) or BigTIFF (version 43);
     * every top-level page that is NOT a reduced-resolution image (NewSubfileType bit 0: pyramid levels of OME / QPTIFF exports are
-      skipped, SubIFDs are never followed) and has the first page's shape and dtype, stacked in file order: (pages, H, W);
+      skipped, SubIFDs are never followed) and has the first page's shape and dtype, in file order: (pages, H, W);
     * strips or tiles; compression none (1) or deflate (8 / 32946), optional horizontal differencing (Predictor 2);
     * 8 / 16 / 32-bit unsigned or signed integers and 32 / 64-bit floats; SamplesPerPixel S > 1 either planar
       (PlanarConfiguration 2 -> (S, H, W), the channel-first layout the hot path wants) or chunky ((H, W, S), as tifffile does);
-    * an OME-XML ImageDescription is accepted as is: with SizeZ = SizeT = 1 the page order is the channel order.
-    Anything else (LZW, JPEG, palette, sub-byte samples) raises ``TiffUnsupported``."""
+    * an OME-XML ImageDescription must say SizeZ = SizeT = 1 and its SizeC must be the number of planes found; an ImageJ description
+      must say slices = frames = 1, and its ``images=N`` planes may sit behind ONE IFD (contiguous, uncompressed: how ImageJ writes
+      large stacks).  Z / T stacks raise ``TiffStackError`` (a plain ValueError for the caller: they are not (C, H, W) images).
+    Anything else (LZW, JPEG, palette, sub-byte samples) and any file whose tags or strips cannot be decoded (truncated, missing
+    StripOffsets, corrupt deflate stream) raises ``TiffUnsupported``.
+    The file is memory-mapped and every page is decoded straight into the preallocated result: peak host memory is the image plus one
+    strip or tile."""
     import struct
     import zlib
-    with open(path, "rb") as f:
-        data = f.read()
-    if len(data) < 8 or data[:2] not in (b"II", b"MM"):
+    try:
+        return _read_tiff(path)
+    except (TiffUnsupported, TiffStackError):
+        raise
+    except (struct.error, zlib.error, KeyError, IndexError, ValueError, OverflowError, TypeError) as e:
+        raise TiffUnsupported(f"{path}: malformed or truncated TIFF ({type(e).__name__}: {e})") from e
+
+
+def _read_tiff(path: str) -> np.ndarray:
+    import struct
+    import zlib
+    if os.path.getsize(path) < 8:
         raise TiffUnsupported(f"{path}: not a TIFF file")
-    bo = "<" if data[:2] == b"II" else ">"
-    version = struct.unpack(bo + "H", data[2:4])[0]
+    data = np.memmap(path, dtype=np.uint8, mode="r")
+    size = data.shape[0]
+
+    def raw_bytes(o, n):
+        if o < 0 or n < 0 or o + n > size:
+            raise TiffUnsupported(f"{path}: bytes {o} .. {o + n} lie beyond the end of the file ({size})")
+        return data[o:o + n].tobytes()
+
+    head = raw_bytes(0, 8)
+    if head[:2] not in (b"II", b"MM"):
+        raise TiffUnsupported(f"{path}: not a TIFF file")
+    bo = "<" if head[:2] == b"II" else ">"
+    version = struct.unpack(bo + "H", head[2:4])[0]
     if version == 42:
-        big, off = False, struct.unpack(bo + "I", data[4:8])[0]
+        big, off = False, struct.unpack(bo + "I", head[4:8])[0]
     elif version == 43:
-        big, off = True, struct.unpack(bo + "Q", data[8:16])[0]
+        big, off = True, struct.unpack(bo + "Q", raw_bytes(8, 8))[0]
     else:
         raise TiffUnsupported(f"{path}: unknown TIFF version {version}")
 
     def read_ifd(o):
-        n = struct.unpack(bo + ("Q" if big else "H"), data[o:o + (8 if big else 2)])[0]
+        n = struct.unpack(bo + ("Q" if big else "H"), raw_bytes(o, 8 if big else 2))[0]
         o += 8 if big else 2
         esz, vsz = (20, 8) if big else (12, 4)
+        table = raw_bytes(o, n * esz + vsz)
         tags = {}
         for i in range(n):
-            e = data[o + i * esz:o + (i + 1) * esz]
+            e = table[i * esz:(i + 1) * esz]
             tag, typ = struct.unpack(bo + "HH", e[:4])
             cnt = struct.unpack(bo + ("Q" if big else "I"), e[4:4 + vsz])[0]
             fmt = _TIFF_TYPES.get(typ)
@@ -110,20 +172,20 @@ def read_tiff(path: str) -> np.ndarray:
                 raw = e[4 + vsz:4 + vsz + nbytes]
             else:
                 vo = struct.unpack(bo + ("Q" if big else "I"), e[4 + vsz:4 + 2 * vsz])[0]
-                raw = data[vo:vo + nbytes]
+                raw = raw_bytes(vo, nbytes)
             if typ == 2:
                 tags[tag] = raw.rstrip(b"\0").decode("latin-1")
             else:
-                vals = struct.unpack(bo + fmt * cnt, raw)
-                tags[tag] = vals
-        nxt = struct.unpack(bo + ("Q" if big else "I"), data[o + n * esz:o + n * esz + vsz])[0]
+                tags[tag] = struct.unpack(bo + fmt * cnt, raw)
+        nxt = struct.unpack(bo + ("Q" if big else "I"), table[n * esz:n * esz + vsz])[0]
         return tags, nxt
 
     def one(tags, tag, default=None):
         v = tags.get(tag)
         return default if v is None else v[0]
 
-    def page_array(tags):
+    def page_layout(tags):
+        """everything needed to decode a page, from its tags alone"""
         w, h = one(tags, 256), one(tags, 257)
         spp = one(tags, 277, 1)
         bits = tags.get(258, (1,))
@@ -131,7 +193,7 @@ def read_tiff(path: str) -> np.ndarray:
         comp = one(tags, 259, 1)
         planar = one(tags, 284, 1)
         pred = one(tags, 317, 1)
-        if w is None or h is None or len(set(bits)) != 1 or bits[0] not in (8, 16, 32, 64):
+        if not w or not h or len(set(bits)) != 1 or bits[0] not in (8, 16, 32, 64):
             raise TiffUnsupported(f"{path}: unsupported sample layout {bits}")
         if comp not in (1, 8, 32946):
             raise TiffUnsupported(f"{path}: compression {comp} is not implemented")
@@ -144,50 +206,91 @@ def read_tiff(path: str) -> np.ndarray:
         tiled = 322 in tags
         if tiled:
             tw, th = one(tags, 322), one(tags, 323)
-            offs, cnts = tags[324], tags[325]
+            offs, cnts = tags.get(324), tags.get(325)
         else:
-            tw, th = w, one(tags, 278, h)
-            th = min(th, h)
-            offs, cnts = tags[273], tags[279]
+            tw, th = w, min(one(tags, 278, h), h)
+            offs, cnts = tags.get(273), tags.get(279)
+        if offs is None or cnts is None or not tw or not th:
+            raise TiffUnsupported(f"{path}: a page without strip / tile offsets and byte counts")
         across, down = (w + tw - 1) // tw, (h + th - 1) // th
         planes = spp if planar == 2 else 1
         per_chunk = spp if planar == 1 else 1
-        if len(offs) != across * down * planes:
+        if len(offs) != across * down * planes or len(cnts) != len(offs):
             raise TiffUnsupported(f"{path}: {len(offs)} strips / tiles, expected {across * down * planes}")
-        out = np.zeros((planes, h, w, per_chunk), dtype=dt.newbyteorder("="))
-        for idx, (o, c) in enumerate(zip(offs, cnts)):
-            pl, rem = divmod(idx, across * down)
-            ty, tx = divmod(rem, across)
-            buf = data[o:o + c]
-            if comp != 1:
-                buf = zlib.decompress(buf)
-            rows = th if tiled else min(th, h - ty * th)
-            chunk = np.frombuffer(buf, dtype=dt, count=rows * tw * per_chunk).reshape(rows, tw, per_chunk)
-            if pred == 2:
-                chunk = np.cumsum(chunk.astype(dt.newbyteorder("=")), axis=1, dtype=dt.newbyteorder("="))
+        if planar == 2 and spp > 1:
+            shape = (spp, h, w)
+        elif spp > 1:
+            shape = (h, w, spp)
+        else:
+            shape = (h, w)
+        return dict(w=w, h=h, spp=spp, comp=comp, planar=planar, pred=pred, dt=dt, tiled=tiled, tw=tw, th=th, offs=offs, cnts=cnts,
+                    across=across, down=down, planes=planes, per_chunk=per_chunk, shape=shape)
+
+    def decode_into(L, dst):
+        """dst: the page's slot of the result, shape L['shape'], native byte order"""
+        dt, nat = L["dt"], L["dt"].newbyteorder("=")
+        h, w, tw, th = L["h"], L["w"], L["tw"], L["th"]
+        view = dst.reshape((L["planes"], h, w, L["per_chunk"])) if L["planar"] == 2 or L["spp"] == 1 else dst.reshape((1, h, w, L["spp"]))
+        for idx, (o, c) in enumerate(zip(L["offs"], L["cnts"])):
+            pl, rem = divmod(idx, L["across"] * L["down"])
+            ty, tx = divmod(rem, L["across"])
+            rows = th if L["tiled"] else min(th, h - ty * th)
+            want = rows * tw * L["per_chunk"]
+            if L["comp"] != 1:
+                buf = zlib.decompress(raw_bytes(o, c))
+                if len(buf) < want * dt.itemsize:
+                    raise TiffUnsupported(f"{path}: a strip / tile decompresses to {len(buf)} bytes, expected {want * dt.itemsize}")
+                chunk = np.frombuffer(buf, dtype=dt, count=want)
+            else:
+                if c < want * dt.itemsize or o + want * dt.itemsize > size:
+                    raise TiffUnsupported(f"{path}: a strip / tile of {c} bytes at {o}, expected {want * dt.itemsize} inside the file")
+                chunk = data[o:o + want * dt.itemsize].view(dt)
+            chunk = chunk.reshape(rows, tw, L["per_chunk"])
+            if L["pred"] == 2:
+                chunk = np.cumsum(chunk.astype(nat), axis=1, dtype=nat)
             y0, x0 = ty * th, tx * tw
             y1, x1 = min(y0 + rows, h), min(x0 + tw, w)
-            out[pl, y0:y1, x0:x1] = chunk[:y1 - y0, :x1 - x0]
-        if planar == 2 and spp > 1:
-            return out[..., 0]                       # (S, H, W)
-        if spp > 1:
-            return out[0]                            # (H, W, S)
-        return out[0, :, :, 0]
+            view[pl, y0:y1, x0:x1] = chunk[:y1 - y0, :x1 - x0]
 
-    pages, seen = [], set()
-    while off and off not in seen and off + 2 <= len(data):
+    layouts, seen, description = [], set(), None
+    while off and off not in seen and off + 2 <= size:
         seen.add(off)
         tags, off = read_ifd(off)
+        if description is None:
+            description = tags.get(270, "") if isinstance(tags.get(270, ""), str) else ""
         if one(tags, 254, 0) & 1:                    # reduced-resolution page of a pyramid
             continue
-        pages.append(page_array(tags))
-    if not pages:
+        layouts.append(page_layout(tags))
+    if not layouts:
         raise TiffUnsupported(f"{path}: no image pages")
-    first = pages[0]
-    same = [pg for pg in pages if pg.shape == first.shape and pg.dtype == first.dtype]
+    expect, behind_one_ifd = _stack_dims(description or "", path)
+    first = layouts[0]
+    same = [L for L in layouts if L["shape"] == first["shape"] and L["dt"] == first["dt"]]
+    nat = first["dt"].newbyteorder("=")
+    if behind_one_ifd and behind_one_ifd > 1 and len(same) == 1:
+        # ImageJ's contiguous stack: one IFD, `images` planes of the first page's size following its first strip
+        n = behind_one_ifd
+        plane = int(np.prod(first["shape"])) * first["dt"].itemsize
+        if first["comp"] != 1 or first["tiled"] or first["spp"] != 1:
+            raise TiffUnsupported(f"{path}: ImageJ stack of {n} images behind one IFD, not plain uncompressed strips")
+        o = first["offs"][0]
+        if o + n * plane > size:
+            raise TiffUnsupported(f"{path}: ImageJ stack of {n} images does not fit the file")
+        out = np.empty((n,) + first["shape"], dtype=nat)
+        out[...] = data[o:o + n * plane].view(first["dt"]).reshape(out.shape)
+        return out
+    if expect is not None:
+        planes_found = len(same) * (first["spp"] if first["spp"] > 1 else 1)
+        if planes_found != expect:
+            raise TiffUnsupported(f"{path}: the description announces {expect} channel planes, the file holds {planes_found}")
     if len(same) == 1:
-        return same[0]
-    return np.stack(same, axis=0)
+        out = np.zeros(first["shape"], dtype=nat)
+        decode_into(first, out)
+        return out
+    out = np.zeros((len(same),) + first["shape"], dtype=nat)
+    for k, L in enumerate(same):
+        decode_into(L, out[k])
+    return out
 
 
 def as_channel_planes(image: np.ndarray, path: str = "") -> np.ndarray:

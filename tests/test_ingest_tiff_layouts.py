@@ -182,3 +182,117 @@ def test_pil_written_files_agree_with_native_reader(tmp_path):
     ims = [PIL.fromarray(p) for p in planes]
     ims[0].save(path, save_all=True, append_images=ims[1:])
     np.testing.assert_array_equal(pp.read_tiff(path), np.stack(planes))
+
+
+# ---- what a description announces, and files that cannot be decoded (stacks must not become channels, decode errors must
+# reach the fallback reader as TiffUnsupported)
+def _ome(c, z=1, t=1):
+    return (f'<?xml version="1.0"?><OME xmlns="http://www.openmicroscopy.org/Schemas/OME/2016-06"><Image ID="Image:0"><Pixels ID="Pixels:0" '
+            f'DimensionOrder="XYCZT" Type="uint16" SizeX="24" SizeY="20" SizeC="{c}" SizeZ="{z}" SizeT="{t}"></Pixels></Image></OME>')
+
+
+def test_ome_description_with_z_planes_is_rejected(tmp_path):
+    """an OME stack with SizeZ = 2 is 6 pages that are NOT 6 channels: TiffStackError (a ValueError), not a (6, H, W) image"""
+    planes = [_rand((20, 24), np.uint16, 100 + i) for i in range(6)]
+    path = str(tmp_path / "z.ome.tif")
+    write_tiff(path, planes, descriptions=[_ome(3, z=2)] + [None] * 5)
+    with pytest.raises(pp.TiffStackError):
+        pp.read_tiff(path)
+    with pytest.raises(ValueError):
+        pp.read_image(path)                       # and read_image does not hand the file to a reader that would flatten it
+    path_t = str(tmp_path / "t.ome.tif")
+    write_tiff(path_t, planes, descriptions=[_ome(2, t=3)] + [None] * 5)
+    with pytest.raises(pp.TiffStackError):
+        pp.read_tiff(path_t)
+
+
+def test_ome_channel_count_must_match_the_pages(tmp_path):
+    planes = [_rand((20, 24), np.uint16, 110 + i) for i in range(4)]
+    ok = str(tmp_path / "c4.ome.tif")
+    write_tiff(ok, planes, descriptions=[_ome(4)] + [None] * 3)
+    np.testing.assert_array_equal(pp.read_tiff(ok), np.stack(planes))
+    bad = str(tmp_path / "c5.ome.tif")
+    write_tiff(bad, planes, descriptions=[_ome(5)] + [None] * 3)
+    with pytest.raises(pp.TiffUnsupported):
+        pp.read_tiff(bad)
+
+
+def test_imagej_stack_behind_one_ifd(tmp_path):
+    """ImageJ writes large stacks as ONE IFD followed by images=N contiguous planes: (N, H, W) like tifffile, not the first plane alone"""
+    planes = [_rand((20, 24), np.uint16, 120 + i) for i in range(5)]
+    path = str(tmp_path / "ij.tif")
+    # one page whose single strip covers the image, then the other planes appended right behind the file (the writer puts the IFD after
+    # the pixel data, so the stack is rebuilt here: header + all planes + IFD of plane 0)
+    write_tiff(path, [planes[0]], descriptions=["ImageJ=1.53t\nimages=5\nchannels=5\nhyperstack=true\n"])
+    with pytest.raises(pp.TiffUnsupported):
+        pp.read_tiff(path)                                 # announces 5 images, holds 1: does not fit
+    # a real contiguous stack: strips of plane 0 are 16 rows each and contiguous from offset 8; put the other planes where the writer
+    # put the IFD by writing a file whose "first page" is the whole stack as one tall image, then patching ImageLength
+    tall = np.concatenate(planes, axis=0)
+    write_tiff(path, [tall], descriptions=["ImageJ=1.53t\nimages=5\nchannels=5\nhyperstack=true\n"])
+    raw = bytearray(open(path, "rb").read())
+    ifd = struct.unpack("<I", raw[4:8])[0]
+    n = struct.unpack("<H", raw[ifd:ifd + 2])[0]
+    for i in range(n):
+        e = ifd + 2 + 12 * i
+        tag = struct.unpack("<H", raw[e:e + 2])[0]
+        if tag == 257:                                     # ImageLength: one plane
+            raw[e + 8:e + 12] = struct.pack("<I", 20)
+        if tag == 278:                                     # RowsPerStrip: the plane in one strip
+            raw[e + 8:e + 12] = struct.pack("<I", 20)
+        if tag in (273, 279):                              # one strip: first offset / one plane of bytes, stored in line
+            cnt, typ = struct.unpack("<I", raw[e + 4:e + 8])[0], struct.unpack("<H", raw[e + 2:e + 4])[0]
+            first = struct.unpack("<I", raw[struct.unpack("<I", raw[e + 8:e + 12])[0]:][:4])[0] if cnt > 1 else struct.unpack("<I", raw[e + 8:e + 12])[0]
+            raw[e + 4:e + 8] = struct.pack("<I", 1)
+            raw[e + 8:e + 12] = struct.pack("<I", first if tag == 273 else 20 * 24 * 2)
+    open(path, "wb").write(bytes(raw))
+    got = pp.read_tiff(path)
+    assert got.shape == (5, 20, 24)
+    np.testing.assert_array_equal(got, np.stack(planes))
+
+
+def test_imagej_hyperstack_with_slices_is_rejected(tmp_path):
+    planes = [_rand((20, 24), np.uint16, 130 + i) for i in range(6)]
+    path = str(tmp_path / "ij_z.tif")
+    write_tiff(path, planes, descriptions=["ImageJ=1.53t\nimages=6\nchannels=2\nslices=3\nhyperstack=true\n"] + [None] * 5)
+    with pytest.raises(pp.TiffStackError):
+        pp.read_tiff(path)
+
+
+@pytest.mark.parametrize("deflate", [False, True])
+def test_truncated_and_corrupt_files_are_declined_not_crashed(tmp_path, deflate):
+    """struct / zlib / key / buffer-size errors of a damaged file surface as TiffUnsupported (so that read_image can try the next reader),
+    never as struct.error, zlib.error, KeyError or a numpy buffer ValueError"""
+    planes = [_rand((40, 24), np.uint16, 140 + i) for i in range(3)]
+    path = str(tmp_path / "whole.tif")
+    write_tiff(path, planes, deflate=deflate)
+    raw = open(path, "rb").read()
+    np.testing.assert_array_equal(pp.read_tiff(path), np.stack(planes))
+    ifd = struct.unpack("<I", raw[4:8])[0]
+    for cut in (6, 100, ifd + 1, len(raw) // 2, len(raw) - 3):
+        part = str(tmp_path / f"cut{cut}.tif")
+        open(part, "wb").write(raw[:cut])
+        try:
+            got = pp.read_tiff(part)                       # a cut behind the last byte that matters may still decode ...
+            assert got.shape[-2:] == (40, 24)
+        except pp.TiffUnsupported:
+            pass                                           # ... everything else is declined with the one exception type
+    # a strip pointing into garbage
+    bad = bytearray(raw)
+    bad[8:40] = b"\xff" * 32
+    p2 = str(tmp_path / "garbage.tif")
+    open(p2, "wb").write(bytes(bad))
+    if deflate:
+        with pytest.raises(pp.TiffUnsupported):
+            pp.read_tiff(p2)
+    # StripOffsets removed (tag renamed to a private one)
+    miss = bytearray(raw)
+    n = struct.unpack("<H", miss[ifd:ifd + 2])[0]
+    for i in range(n):
+        e = ifd + 2 + 12 * i
+        if struct.unpack("<H", miss[e:e + 2])[0] == 273:
+            miss[e:e + 2] = struct.pack("<H", 65000)
+    p3 = str(tmp_path / "nooffsets.tif")
+    open(p3, "wb").write(bytes(miss))
+    with pytest.raises(pp.TiffUnsupported):
+        pp.read_tiff(p3)
