@@ -55,10 +55,10 @@ def counter_by_shape(sub, counter):
 
 fetch = counter_sums("fetch", "FETCH_SIZE")
 write = counter_sums("write", "WRITE_SIZE")
-gemm = [k for k in fetch if "gemm_ps_split_kernel" in k or "gemm_ps_duo_kernel" in k or "cell_qkv_attention_kernel" in k]
+gemm = [k for k in fetch if "gemm_ps_split_kernel" in k or "gemm_ps_duo_kernel" in k or "gemm_mx_duo_kernel" in k or "cell_qkv_attention_kernel" in k]
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 0 "
                  "--no-cpu-baseline --no-roofline --cells 8000 --size 1280 (chunk 1024)",
-       "kernel_family": "gemm_ps_split_kernel + gemm_ps_duo_kernel + cell_qkv_attention_kernel (all instantiations)",
+       "kernel_family": "gemm_mx_duo_kernel + gemm_ps_duo_kernel + gemm_ps_split_kernel + cell_qkv_attention_kernel (all instantiations)",
        "correction": "gfx950: FETCH_SIZE tallies 128-B requests at 64 B -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact; "
                      "unit KB = 1024 B",
        "note": "counts L2 misses served by the Infinity Cache as well as HBM; per-launch figure (M = 103424 rows for full chunks)"}
@@ -94,7 +94,7 @@ try:
 except Exception:
     res["kernel_source_sha256"] = None
 # every kernel of the ViT forward (GEMMs, attention, statistics / LayerNorm, embed, head): counter bytes per CELL of the reduced pass
-vit = [k for k in fetch if "ribca::" in k and any(t in k for t in ("gemm_ps_", "attention", "cell_qkv", "layernorm", "row_stats", "ln_finalize", "embed_f32", "head_softmax", "cls_rows"))]
+vit = [k for k in fetch if "ribca::" in k and any(t in k for t in ("gemm_ps_", "gemm_mx_", "mx_pack_act", "attention", "cell_qkv", "layernorm", "row_stats", "ln_finalize", "embed_f32", "head_softmax", "cls_rows"))]
 n_cells_line = None
 try:
     n_cells_line = json.load(open(os.path.join(out, "fetch.json")))["config"]["cells"]
