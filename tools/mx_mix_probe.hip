@@ -9,7 +9,11 @@
 //        acc += mfma_scale(W lo [fp6 e2m3], A h' [fp6 e2m3])       A h' made IN REGISTERS from the 16 dwords of Ah by v_cvt_scalef32_pk32_fp6_f16
 //      against (i) a host emulation of exactly these roundings (pins formats, k order, scale direction, op_sel bytes: must agree to
 //      fp32 summation noise) and (ii) the fp64 product (the error the scheme really has);
-//   B. v_cvt_scalef32_pk_fp8_f32 (what a producing epilogue uses for the lo byte): RNE(x / scale) onto e4m3, saturating, word select;
+//      (Part A multiplies fp8 x fp8 and fp6 x fp6, where both operands of an instruction share one lane map, so any consistent k order
+//      passes.  The production kernel MIXES an fp6 and an fp8 operand in one instruction; their lane maps differ -- an fp8 operand's lane
+//      (r, g) holds k = 16 g .. + 15 and 64 + 16 g .. + 15 -- which tools/mx_kmap_probe.hip pinned after the first kernel was 3.5e-5 off.)
+//   B. v_cvt_scalef32_pk_fp8_f32 (what a producing epilogue uses for the lo byte): RNE(x / scale) onto e4m3, word select; measured: it does
+//      NOT saturate (|x / scale| > 448 gives the NaN code 0x7f / 0xff: 2 of 256 probe values), hence the format's scale rule (lo / scale <= 256);
 //   C. issue cost of one wave-step (8 row tiles x 3 column tiles x 128 k) for the candidate mixes, 1 and 2 waves per SIMD, whole chip,
 //      random operands: today's 12 f16 MFMAs per tile; 4 f16 + 2 fp6; 4 f16 + fp8 + fp6; the same with the 8 (A) and 11 (A + W) in-loop
 //      pk32 conversions; the bf8-by-v_perm alternative for A h'.
