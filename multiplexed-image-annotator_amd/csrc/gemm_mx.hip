@@ -410,6 +410,12 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
   issue_hi(0);
   issue_wx(0);
 
+#ifdef MXDBG_STAMP      // timing variant (tools/build_mx_variant.py): shader-clock cycles per phase, summed over the K loop, per wave
+  unsigned long long st_prev = __builtin_amdgcn_s_memtime(), st_b1 = 0, st_f16 = 0, st_cv = 0, st_b2 = 0, st_mx = 0;
+#define MX_STAMP(acc_) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc_ += t_ - st_prev; st_prev = t_; }
+#else
+#define MX_STAMP(acc_)
+#endif
   // one 128-deep step
   // (the last step is its own instance: "more" is a compile-time constant, so no phase is cut into basic blocks by the requests for the next step)
   auto step = [&](auto more_c, int b) {
@@ -418,6 +424,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
     wait_vmcnt<NWX>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    MX_STAMP(st_b1)
     // the fp6 image of this step's W hi, from the four resident fragment sets (they are refilled for the next step right behind their last use,
     // so now is the moment); scale byte = the packer's sh of the tile, which travelled with the PREVIOUS block's words (wsh)
 #pragma unroll
@@ -472,6 +479,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
     // the next step's lo and scale units (their slot was last read in the MX phase of step b - 1, which every wave left before B1)
     if constexpr (more) issue_l8(b + 1);
     __builtin_amdgcn_sched_barrier(0);
+    MX_STAMP(st_f16)
 #ifndef MXDBG_NOCONV
     // ---- conversion: this wave turns the hi rows of row tiles 2 w, 2 w + 1 into fp6 for everybody
     {
@@ -502,11 +510,13 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
     // landed before the MX phase reads them: only the requests made during this step's f16 phase are younger -- 4 x 3 W hi fragments and
     // the 5 pieces of the next lo / scale unit; none in the last step.  (A first version of the four-set W hi schedule had dropped the
     // wait that used to cover them: tests/test_gpu_e2e.py::test_classifier_bitwise_repeatable caught it.)
+    MX_STAMP(st_cv)
     if constexpr (more) wait_vmcnt<4 * TN + 5>();
     else wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    MX_STAMP(st_b2)
     if constexpr (more) {
       issue_hi(b + 1);
     } else if constexpr (ZK) {
@@ -562,6 +572,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
     asm volatile("" : "+v"(wsh));
     if constexpr (more) issue_wx(b + 1);
     __builtin_amdgcn_sched_barrier(0);
+    MX_STAMP(st_mx)
   };
 
   for (int b = 0; b + 1 < nb; ++b) step(std::true_type{}, b);
@@ -660,6 +671,15 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
     }
     if (n0 + wn * (16 * TN) >= epi.N) return;      // (never with an MX3 copy: its launcher takes whole tiles only)
     const int blk = nt * 4 + wn;
+#ifdef MXDBG_STAMP
+    if (epi.part != nullptr && lane_e == 0) {      // behind the statistics: [N / 48][M] pairs, then 4 pairs per wave of every workgroup
+      float2* o = epi.part + (size_t)(epi.N / 48) * epi.M + ((size_t)blockIdx.x * 4 + wave) * 4;
+      o[0] = float2{(float)st_b1, (float)st_f16};
+      o[1] = float2{(float)st_cv, (float)st_b2};
+      o[2] = float2{(float)st_mx, (float)nb};
+      o[3] = float2{(float)(__builtin_amdgcn_s_memtime() - st_prev), 0.f};      // everything behind the K loop
+    }
+#endif
     const bool emit = epi.zmx.hi != nullptr;
     if (m0 + BM <= M) {
       resid_zk_epilogue<TN, MT, MT, true>(epi, mbase, nbase, blk, ge, acc, zb4, zpm);
