@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
-"""A second build of the library that differs in gemm_mx.hip only (timing ablations of the MX kernel: -DMXDBG_NOA / NOW / NOCONV / NOMX / NOF16 /
-NOZ / NOEPI, results wrong on purpose): python tools/build_mx_variant.py libribca_mx_noa.so -DMXDBG_NOA ; then RIBCA_LIB=libribca_mx_noa.so"""
+"""A second build of the library that differs in gemm_mx.hip only: timing ablations of the MX kernel, results wrong on purpose.
+  python tools/build_mx_variant.py libribca_mx_noa.so -DMXDBG_NOA ; then RIBCA_LIB=libribca_mx_noa.so python tools/bench_mx_only.py
+Switches (gemm_mx.hip / gemm_epi.h): MXDBG_NOA / MXDBG_NOW (no A / W requests), MXDBG_NOCONV (no hi -> fp6 conversion), MXDBG_NOF16 (no f16
+MFMAs), MXDBG_NOZ (no residual K steps), MXDBG_NOEPI (no epilogue), MXDBG_NOGELU, MXDBG_NOEMIT (fc1 epilogue without GELU / without the MX3
+emission), MXDBG_PF=<n> (LDS prefetch depth of the f16 phase), MXDBG_STAMP (phase cycle sums behind the statistics: tools/stamp_mx.py).
+DO NOT build -DMXDBG_NOMX: with the scaled MFMAs gone the compiler treats the registers the inline-asm loads fill as dead and reuses them
+while the loads are in flight -- the variant faulted on the GPU (round 4); the switch is only left in the source as a marker."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
