@@ -493,7 +493,7 @@ def fused_attn_on():
 
 def matrix_units(d):
     """matrix units (one unit = one pass of the 16-bit dense rate) ISSUED per algorithmic product of the four Linears of a full block at
-    width d: three fp16 passes, or 1.75 (4 x f16 + fp8 x fp6 at half rate + fp6 x fp6 at quarter rate per 128 k) on the MX kernel -- times
+    width d: three fp16 passes, or 1.75 (per 128 k: 4 x f16 = one unit, fp8 x fp6 = half a unit, fp6 x fp6 = a quarter) on the MX kernel -- times
     the K padding where the MX kernel pads D to a multiple of 128 (qkv / fc1 at D = 576: 640 / 576).  qkv inside the fused per-cell
     kernel (D <= 384) stays at three passes."""
     from multiplexed_image_annotator_amd import _lib
