@@ -214,7 +214,9 @@ def main():
     stage_events = []      # per timed pass: [(stage, start event, end event)] on the current stream (the ViT's segment streams join it)
     STAGES = ("normalise", "label_table", "crop", "imputer", "vit", "all_gather", "vote", "d2h")
 
-    def one_pass(streams=None, models_sel=None, record=False):
+    def one_pass(streams=None, models_sel=None, record=False, gather=True):
+        # gather=False: no collective (the profiled per-classifier passes of the roofline block run on rank 0 ALONE -- a collective there
+        # would wait for ranks that have already left); the vote then runs on this rank's shard
         streams = args.streams if streams is None else streams
         marks = []
 
@@ -257,7 +259,7 @@ def main():
                 continue
             with stage("vit"):
                 probs[name] = model.predict_proba(patches, srcs[name], chunk_cells=args.chunk, streams=streams, recheck=RECHECK)
-        if sharded:         # ONE all-gather per tile: the five models' probability columns side by side (33 floats per cell)
+        if sharded and gather:         # ONE all-gather per tile: the five models' probability columns side by side (33 floats per cell)
             names = list(probs)
             widths = [probs[k].shape[1] for k in names]
             local_rows = torch.cat([probs[k] for k in names], dim=1)
@@ -364,7 +366,7 @@ def main():
         fused_attn = fused_attn_on()
         for name, model in models.items():
             ops.prof_enable(True)
-            one_pass(streams=1, models_sel=[name])
+            one_pass(streams=1, models_sel=[name], gather=False)
             torch.cuda.synchronize()
             pm = ops.prof_read()
             ops.prof_enable(False)

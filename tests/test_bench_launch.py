@@ -67,3 +67,17 @@ def test_rank_count_mismatch_is_an_error():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_rank0_only_passes_issue_no_collective():
+    """The roofline block runs profiled passes on rank 0 ALONE, after the other ranks have printed nothing and left: a collective inside
+    them hangs or dies ("Connection closed by peer": found by the 2-rank rehearsal of round 4 -- rounds 2 and 3 shipped it).  Static
+    check: every one_pass(...) call of that block says gather=False, and one_pass honours it."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    start = src.index("if not args.no_roofline and rank == 0:")
+    end = src.index("if not args.no_dropin and rank == 0", start)
+    block = src[start:end]
+    calls = [block[i:block.index(")", i) + 1] for i in range(len(block)) if block.startswith("one_pass(", i)]
+    assert calls, "the roofline block no longer calls one_pass: update this test"
+    assert all("gather=False" in c for c in calls), calls
+    assert "if sharded and gather:" in src
