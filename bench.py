@@ -482,6 +482,9 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        # the other ranks wait here while rank 0 runs its profiled passes: every rank then tears the group down together (a communicator
+        # destroyed on some ranks while another still holds it is the kind of exit RCCL may not take quietly)
+        tdist.barrier()
         tdist.destroy_process_group()
 
 
