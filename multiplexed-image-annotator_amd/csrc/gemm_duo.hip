@@ -619,7 +619,10 @@ bool launch_duo(const GemmArgs& g, const Epi& epi, hipStream_t s, int abl) {
 // block per wave and row).  N % 128 == 0 and a fragment-order weight are required.
 bool launch_gemm_gelu_mx(const GemmArgs& g, const float2* rowstat, const float* csum, const MxAct& out, hipStream_t s) {
   if (g.N % 128 != 0 || g.WF == nullptr || out.Kp != g.N) return false;
-  const EpiGeluMx epi{out, g.bias, g.M, g.N, rowstat, csum, 1};
+  // RIBCA_MX_NT bit 2 (default off): the MX3 planes of h stored non-temporal from THIS kernel (fc1 at D = 288).  The MX kernel's fc1
+  // (D = 384 / 576, bit 1, gemm_mx.hip) gains 2-5 % from it; here it measured nothing (profiles/r4/ab_mx_nt_stores.txt)
+  static const int mx_nt = getenv("RIBCA_MX_NT") ? atoi(getenv("RIBCA_MX_NT")) : 2;
+  const EpiGeluMx epi{out, g.bias, g.M, g.N, rowstat, csum, 1, (mx_nt >> 2) & 1};
   return launch_duo_impl<192, 4, 1, 3, 128, EpiGeluMx>(g, epi, s, 0);
 }
 

@@ -388,6 +388,7 @@ struct EpiGeluMx {
   static constexpr bool kTouch = false, kFold = true, kMxOut = true;
   MxAct out; const float* bias; int M, N;
   const float2* rowstat; const float* csum; int rs_stride = 1;
+  int nt = 0;      // 1: the emitted planes are stored non-temporal (A/B switch RIBCA_MX_NT: h is read once, by the next launch)
   struct Ctx {};
   typedef LnRow RowS;
 };
@@ -464,8 +465,15 @@ __device__ __forceinline__ void gelu_mx_epilogue(const EpiGeluMx& epi, int mbase
     const auto ry = __builtin_amdgcn_permlane16_swap(hi[0].y, hi[1].y, false, false);
     const auto rl = __builtin_amdgcn_permlane16_swap(l8[0], l8[1], false, false);
     if (ok) {
-      *reinterpret_cast<u32x4*>(epi.out.hi + (size_t)m * Kp + hpos) = u32x4{rx[0], ry[0], rx[1], ry[1]};
-      *reinterpret_cast<uint2*>(epi.out.l8 + (size_t)m * Kp + c8) = uint2{rl[0], rl[1]};
+      u32x4* hp = reinterpret_cast<u32x4*>(epi.out.hi + (size_t)m * Kp + hpos);
+      u32x2s* lp = reinterpret_cast<u32x2s*>(epi.out.l8 + (size_t)m * Kp + c8);
+      if (epi.nt) {      // h is read once, by the next launch: stores that do not displace the weight from the L2 (RIBCA_MX_NT)
+        __builtin_nontemporal_store(u32x4{rx[0], ry[0], rx[1], ry[1]}, hp);
+        __builtin_nontemporal_store(u32x2s{rl[0], rl[1]}, lp);
+      } else {
+        *hp = u32x4{rx[0], ry[0], rx[1], ry[1]};
+        *lp = u32x2s{rl[0], rl[1]};
+      }
       if (g == 0) epi.out.sc[((size_t)(n32 >> 7) * epi.out.M + m) * 4 + ((n32 >> 5) & 3)] = (unsigned char)sl;
     }
   }
@@ -511,7 +519,7 @@ constexpr int kMx3StageHiRow = 400, kMx3StageL8Row = 208, kMx3StageBytes = 128 *
 
 template <int MT, bool IN>
 __device__ __forceinline__ void mx3_emit_wave48(const MxAct& out, int M, int m0, int ncol0, int g_in, int r16_in, int wave, unsigned stg_lds,
-                                                unsigned xch_lds, const f32x4 (&x)[MT][3]) {
+                                                unsigned xch_lds, const f32x4 (&x)[MT][3], bool nt = false) {
   static_assert(MT == 8, "the staging image is that of a 128-row tile");
   // (opaque copies: everything below that derives from the lane's position is then formed HERE, not shared with the kernel's prologue and
   // carried -- or spilled -- across the K loop)
@@ -641,7 +649,8 @@ __device__ __forceinline__ void mx3_emit_wave48(const MxAct& out, int M, int m0,
     epi_sfor<12>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
       epi_wait_lgkm128<11 - k>(v[k]);
-      __builtin_amdgcn_raw_buffer_store_b128(v[k], hi_rsrc, voff + pos[k % 3] * 2, (k / 3) * 32 * Kp * 2, 0);
+      if (nt) __builtin_amdgcn_raw_buffer_store_b128(v[k], hi_rsrc, voff + pos[k % 3] * 2, (k / 3) * 32 * Kp * 2, 2);
+      else __builtin_amdgcn_raw_buffer_store_b128(v[k], hi_rsrc, voff + pos[k % 3] * 2, (k / 3) * 32 * Kp * 2, 0);
     });
   }
   {
@@ -660,7 +669,8 @@ __device__ __forceinline__ void mx3_emit_wave48(const MxAct& out, int M, int m0,
     epi_sfor<6>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
       epi_wait_lgkm128<5 - k>(v[k]);
-      __builtin_amdgcn_raw_buffer_store_b128(v[k], l8_rsrc, voff + (k % 3) * 64, (k / 3) * 64 * Kp, 0);
+      if (nt) __builtin_amdgcn_raw_buffer_store_b128(v[k], l8_rsrc, voff + (k % 3) * 64, (k / 3) * 64 * Kp, 2);
+      else __builtin_amdgcn_raw_buffer_store_b128(v[k], l8_rsrc, voff + (k % 3) * 64, (k / 3) * 64 * Kp, 0);
     });
   }
 }
@@ -791,7 +801,7 @@ __device__ __forceinline__ void gelu_mx48_epilogue(const EpiGeluMx& epi, int m0,
 #pragma unroll
     for (int j = 0; j < 3; ++j) asm volatile("" ::"v"(acc[0][i][j]));
 #else
-  mx3_emit_wave48<MT, IN>(epi.out, epi.M, m0, ncol0, g, r16, wave, stg_lds, xch_lds, acc[0]);
+  mx3_emit_wave48<MT, IN>(epi.out, epi.M, m0, ncol0, g, r16, wave, stg_lds, xch_lds, acc[0], epi.nt != 0);
 #endif
 }
 

@@ -273,7 +273,7 @@ __device__ __forceinline__ int mx_f8(int row) { return (row >> 1) & 7; }
 // ABL (diagnostic library only): 1 = no epilogue (results dropped)
 template <class Epi, int ABL>
 __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint16_t* __restrict__ WH, const unsigned char* __restrict__ WX, int M, int nb,
-                                                              int mtiles, int ntiles, Epi epi) {
+                                                              int mtiles, int ntiles, Epi epi, int panel) {
   // epilogues: EpiResidZK (proj / fc2: the residual tile through the ring, optionally a second copy of the new rows in MX3), EpiQKVLn,
   // EpiGeluMx (fc1: GELU output in MX3)
   constexpr bool ZK = is_zk<Epi>::value;
@@ -282,11 +282,34 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
   const int nblk = mtiles * ntiles;
   int bid = blockIdx.x;
   {
-    // blocks b, b + 8, ... run on one XCD (one L2): XCD x walks a contiguous tile range with n fastest (as gemm_duo.hip)
+    // blocks b, b + 8, ... run on one XCD (one L2): XCD x walks a contiguous tile range with n fastest (as gemm_duo.hip).  panel > 0
+    // (n-tiles per panel, chosen by the launcher where the weight image is larger than an XCD's L2 can keep beside the A and output
+    // streams): the whole m-tile rows of the range are walked panel by panel -- every m-tile's n-tiles of panel 0, then of panel 1, ... --
+    // so a panel of W stays resident while the A rows stream past it (A is then fetched once per panel); the partial rows at the two
+    // ends of the range keep the plain order.
     const int xcd = bid & 7, loc = bid >> 3;
     const int q = nblk >> 3, r = nblk & 7;
     const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int cnt = xcd < r ? q + 1 : q;
     bid = first + loc;
+    if (panel > 0 && panel < ntiles) {
+      const int r0 = (first + ntiles - 1) / ntiles, r1 = (first + cnt) / ntiles;     // whole m-tile rows [r0, r1)
+      const int head = r0 * ntiles - first;
+      if (r1 > r0 && loc >= head) {
+        int l = loc - head;
+        const int rows = r1 - r0;
+        if (l < rows * ntiles) {
+          int p0 = 0, w = panel;
+          while (l >= rows * w) {          // at most ntiles / panel iterations, uniform over the workgroup
+            l -= rows * w;
+            p0 += w;
+            w = ntiles - p0 < panel ? ntiles - p0 : panel;
+          }
+          const int rr = l / w;
+          bid = (r0 + rr) * ntiles + p0 + (l - rr * w);
+        }
+      }
+    }
   }
   const int mt = bid / ntiles, nt = bid - mt * ntiles;
   const int m0 = mt * BM, n0 = nt * BN;
@@ -718,10 +741,24 @@ template <class Epi, int ABL>
 static void launch_mx_impl(const MxAct& A, const MxWeight& W, int M, int N, const Epi& epi, hipStream_t s) {
   const int mtiles = (M + MX_BM - 1) / MX_BM, ntiles = (N + MX_BN - 1) / MX_BN;
   const int nb = A.Kp / 128;
-  void (*kernel)(MxAct, const uint16_t*, const unsigned char*, int, int, int, int, Epi) = gemm_mx_duo_kernel<Epi, ABL>;
+  void (*kernel)(MxAct, const uint16_t*, const unsigned char*, int, int, int, int, Epi, int) = gemm_mx_duo_kernel<Epi, ABL>;
   static unsigned long long attr_done = 0ull;
   ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), L_TOTAL, attr_done);
-  kernel<<<dim3(mtiles * ntiles), dim3(256), L_TOTAL, s>>>(A, W.wh, W.wx, M, nb, mtiles, ntiles, epi);
+  // W-panel walk (see the kernel's tile map): RIBCA_MX_PANEL_KB = the most weight image (KB) a panel may hold, applied only where the
+  // whole image is larger (qkv / fc1 at D = 576: 3.1 / 4.2 MB against the XCD's 4 MB L2); 0 = off
+  static const int panel_kb = getenv("RIBCA_MX_PANEL_KB") ? atoi(getenv("RIBCA_MX_PANEL_KB")) : 0;
+  int panel = 0;
+  {
+    const size_t tile_bytes = (size_t)4 * nb * (kMxWhBytes + kMxWxBytes), w_bytes = tile_bytes * ntiles;
+    if (panel_kb > 0 && w_bytes > (size_t)panel_kb * 1024) {
+      const int fit = (int)((size_t)panel_kb * 1024 / tile_bytes);
+      if (fit >= 1) {
+        const int np = (ntiles + fit - 1) / fit;
+        panel = (ntiles + np - 1) / np;
+      }
+    }
+  }
+  kernel<<<dim3(mtiles * ntiles), dim3(256), L_TOTAL, s>>>(A, W.wh, W.wx, M, nb, mtiles, ntiles, epi, panel);
 }
 
 // z (packed-split) = (z - prev mean) + A W^T + bias with A in MX3, W in the mx_pack_w image; statistics per 48-column wave block
@@ -745,7 +782,9 @@ ResidStatGeom launch_gemm_mx_resid(const MxAct& A, const MxWeight& W, int M, int
 void launch_gemm_mx_qkv_ln(const MxAct& A, const MxWeight& W, int M, int N, const float* bias, const float2* rowstat, const float* csum, uint16_t* q,
                            uint16_t* k, uint16_t* vt, const AttnGeom& a, float scale, hipStream_t s) {
   if (N % MX_BN != 0) { fprintf(stderr, "ribca: launch_gemm_mx_qkv_ln needs N %% 192 == 0\n"); abort(); }
-  const EpiQKVLn epi{q, k, vt, bias, a.D, a.hd, a.hdq, a.hdv, scale, M, N, a.T, a.TP, a.H, a.KP, 0,
+  // RIBCA_MX_NT: bit 0 = the q / k / v rows stored non-temporal (A/B: no effect measured), bit 1 = the MX3 planes of h (default on, below)
+  static const int mx_nt = getenv("RIBCA_MX_NT") ? atoi(getenv("RIBCA_MX_NT")) : 2;
+  const EpiQKVLn epi{q, k, vt, bias, a.D, a.hd, a.hdq, a.hdv, scale, M, N, a.T, a.TP, a.H, a.KP, mx_nt & 1,
                      (unsigned)((0x100000000ull + (unsigned long long)a.T - 1) / (unsigned long long)a.T), rowstat, csum, attention_v_rowmajor(a) ? 1 : 0,
                      0, 0, 1};
   launch_mx_impl<EpiQKVLn, 0>(A, W, M, N, epi, s);
@@ -753,7 +792,11 @@ void launch_gemm_mx_qkv_ln(const MxAct& A, const MxWeight& W, int M, int N, cons
 void launch_gemm_mx_gelu(const MxAct& A, const MxWeight& W, int M, int N, const float* bias, const float2* rowstat, const float* csum, const MxAct& out,
                          hipStream_t s) {
   if (N % MX_BN != 0 || out.Kp != N) { fprintf(stderr, "ribca: launch_gemm_mx_gelu needs N %% 192 == 0 and out.Kp == N\n"); abort(); }
-  const EpiGeluMx epi{out, bias, M, N, rowstat, csum, 1};
+  // The emitted planes of h (715 MB per launch at D = 576) are read once, by the next launch: stored non-temporal they do not displace
+  // the weight image from the XCD's L2 -- fetch 1689 -> 1125 MB per launch, fc1 -2 %, fc2 -1 % (profiles/r4/ab_mx_nt_stores.txt).
+  // RIBCA_MX_NT bit 1 = 0 for A/B.
+  static const int mx_nt = getenv("RIBCA_MX_NT") ? atoi(getenv("RIBCA_MX_NT")) : 2;
+  const EpiGeluMx epi{out, bias, M, N, rowstat, csum, 1, (mx_nt >> 1) & 1};
   launch_mx_impl<EpiGeluMx, 0>(A, W, M, N, epi, s);
 }
 
