@@ -115,6 +115,7 @@ struct EpiResidZK {
   // element instead of 4, and fp16 hi * hi + block-scaled corrections instead of three fp16 passes); hi == nullptr: not wanted.  Only with
   // 48-column wave blocks (TN = 3) and N % 192 == 0: a 32-column scale block then lies in one wave or is shared by a wave and its neighbour.
   MxAct zmx = MxAct{nullptr, nullptr, nullptr, 0, 0};
+  int nt = 0;      // A/B switch (RIBCA_MX_NT bit 3): the new rows -- both copies -- stored non-temporal
   struct Ctx {};
   typedef NoRow RowS;
 };
@@ -727,7 +728,11 @@ __device__ __forceinline__ void resid_zk_epilogue(const EpiResidZK& epi, int mba
       const auto ry = __builtin_amdgcn_permlane16_swap(hi.y, lo.y, false, false);
       const u32x4 o = {rx[0], ry[0], rx[1], ry[1]};      // even g: 8 x hi, odd g: 8 x lo
       const int k = nbase + 16 * j;
-      if (ok) *reinterpret_cast<u32x4*>(zr + ps_off(k & ~7) + ((k & 4) ? 8 : 0)) = o;
+      if (ok) {
+        u32x4* zp = reinterpret_cast<u32x4*>(zr + ps_off(k & ~7) + ((k & 4) ? 8 : 0));
+        if (epi.nt) __builtin_nontemporal_store(o, zp);
+        else *zp = o;
+      }
     }
     sum[i] = tot.x + tot.y;
   }

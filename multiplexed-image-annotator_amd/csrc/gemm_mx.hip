@@ -706,10 +706,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
     const bool emit = epi.zmx.hi != nullptr;
     if (m0 + BM <= M) {
       resid_zk_epilogue<TN, MT, MT, true>(epi, mbase, nbase, blk, ge, acc, zb4, zpm);
-      if (emit) mx3_emit_wave48<MT, true>(epi.zmx, M, m0, n0 + wn * (16 * TN), ge, r16e, wave, lds_base, xch, acc[0]);
+      if (emit) mx3_emit_wave48<MT, true>(epi.zmx, M, m0, n0 + wn * (16 * TN), ge, r16e, wave, lds_base, xch, acc[0], epi.nt != 0);
     } else {
       resid_zk_epilogue<TN, MT, MT, false>(epi, mbase, nbase, blk, ge, acc, zb4, zpm);
-      if (emit) mx3_emit_wave48<MT, false>(epi.zmx, M, m0, n0 + wn * (16 * TN), ge, r16e, wave, lds_base, xch, acc[0]);
+      if (emit) mx3_emit_wave48<MT, false>(epi.zmx, M, m0, n0 + wn * (16 * TN), ge, r16e, wave, lds_base, xch, acc[0], epi.nt != 0);
     }
   } else {
     // N is a multiple of the tile width for these (gemm_mx_supported + the launchers): only the rows need guards
@@ -765,6 +765,8 @@ static void launch_mx_impl(const MxAct& A, const MxWeight& W, int M, int N, cons
 ResidStatGeom launch_gemm_mx_resid(const MxAct& A, const MxWeight& W, int M, int N, const float* bias, uint16_t* z, int ldz, float2* part, const float2* prev,
                                    int prev_stride, hipStream_t s, int abl, const MxAct* zmx) {
   EpiResidZK epi{z, ldz, bias, M, N, part, prev, prev_stride};
+  static const int mx_nt = getenv("RIBCA_MX_NT") ? atoi(getenv("RIBCA_MX_NT")) : 2;
+  epi.nt = (mx_nt >> 3) & 1;
   if (zmx != nullptr) {
     // (whole 192-column tiles: every wave of a workgroup then reaches the barrier of the emission)
     if (N % MX_BN != 0) { fprintf(stderr, "ribca: MX3 copy of the residual rows needs N %% 192 == 0\n"); abort(); }
