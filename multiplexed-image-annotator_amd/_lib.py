@@ -16,9 +16,12 @@ LIB_PATH = os.path.join(HERE, "libribca_hip_diag.so" if os.environ.get("RIBCA_DI
 if os.environ.get("RIBCA_LIB"):
     LIB_PATH = os.environ["RIBCA_LIB"] if os.path.isabs(os.environ["RIBCA_LIB"]) else os.path.join(HERE, os.environ["RIBCA_LIB"])
 
-_lib = None
+TEST_LIB_PATH = LIB_PATH[:-3] + "_test.so"
 
-#: name -> (restype, argtypes); must list every function declared in include/ribca_hip.h
+_lib = None
+_test_lib = None
+
+#: name -> (restype, argtypes); must list every function declared in include/ribca_hip.h (the product ABI)
 SIGNATURES = {
     "ribca_version": (c_int32, []),
     "ribca_last_error": (c_char_p, []),
@@ -52,9 +55,16 @@ SIGNATURES = {
     "ribca_mae_impute": (c_int32, [c_void_p, c_void_p, POINTER(c_int32), c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p]),
     "ribca_vote": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_float, c_int32, c_void_p, c_void_p,
                              c_void_p]),
+    "ribca_mx_enabled": (c_int32, [c_int32]),
+    "ribca_mxz_enabled": (c_int32, [c_int32]),
     "ribca_prof_enable": (c_int32, [c_int32]),
     "ribca_prof_read": (c_int32, [POINTER(c_double), POINTER(c_int64)]),
     "ribca_prof_name": (c_char_p, [c_int32]),
+}
+
+#: the kernel-level hooks of include/ribca_hip_test.h: libribca_hip_test.so, loaded on first use by tests/ and tools/ only -- the package
+#: itself never names one of them (tests/test_abi.py checks that)
+TEST_SIGNATURES = {
     "ribca_test_pack_weight": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
     "ribca_test_layernorm": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "ribca_test_gemm": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
@@ -78,7 +88,6 @@ SIGNATURES = {
                                                   c_void_p, c_void_p, c_void_p, c_void_p]),
     "ribca_test_gemm_gelu_mx": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p]),
-    "ribca_mx_enabled": (c_int32, [c_int32]),
     "ribca_test_gemm_mx_fc1": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ribca_test_qkv_attention_mx": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -86,7 +95,6 @@ SIGNATURES = {
     "ribca_test_gemm_resid_zmx": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_int32, c_void_p]),
-    "ribca_mxz_enabled": (c_int32, [c_int32]),
     "ribca_test_gemm_fold": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_int32, c_void_p]),
     "ribca_test_qkv_attention_fold": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
@@ -106,7 +114,45 @@ class RibcaError(RuntimeError):
     pass
 
 
-def lib() -> ctypes.CDLL:
+class _Library:
+    """The product library; a name of TEST_SIGNATURES resolves (and loads, once) the separate test-hook library instead."""
+
+    def __init__(self, handle):
+        self._handle = handle
+
+    def __getattr__(self, name):
+        if name in SIGNATURES:
+            fn = getattr(self._handle, name)
+        elif name in TEST_SIGNATURES:
+            fn = getattr(_load_test_lib(), name)
+        else:
+            raise AttributeError(f"{name} is declared neither in include/ribca_hip.h nor in include/ribca_hip_test.h")
+        setattr(self, name, fn)
+        return fn
+
+
+def _bind(handle, table):
+    for name, (res, args) in table.items():
+        fn = getattr(handle, name)
+        fn.restype = res
+        fn.argtypes = args
+
+
+def _load_test_lib():
+    global _test_lib
+    if _test_lib is None:
+        if not os.path.exists(TEST_LIB_PATH):
+            raise RibcaError(f"{TEST_LIB_PATH} not found: build it with `python -m multiplexed_image_annotator_amd.build`")
+        lib()      # the product library first: the hooks call its launchers
+        handle = ctypes.CDLL(TEST_LIB_PATH)
+        _bind(handle, TEST_SIGNATURES)
+        _test_lib = handle
+        if os.environ.get("RIBCA_GEMM_VARIANT"):
+            handle.ribca_set_gemm_variant(int(os.environ["RIBCA_GEMM_VARIANT"]))
+    return _test_lib
+
+
+def lib() -> _Library:
     """Load (once) and return the shared library; raises if it has not been built."""
     global _lib
     if _lib is None:
@@ -118,13 +164,10 @@ def lib() -> ctypes.CDLL:
         # second runtime from /opt/rocm and the two do not share device state
         import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(handle, name)
-            fn.restype = res
-            fn.argtypes = args
-        _lib = handle
+        _bind(handle, SIGNATURES)
+        _lib = _Library(handle)
         if os.environ.get("RIBCA_GEMM_VARIANT"):
-            handle.ribca_set_gemm_variant(int(os.environ["RIBCA_GEMM_VARIANT"]))
+            _load_test_lib()
     return _lib
 
 

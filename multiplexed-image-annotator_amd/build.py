@@ -14,8 +14,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libribca_hip.so")
 LIB_DIAG = os.path.join(HERE, "libribca_hip_diag.so")
+# kernel-level hooks of tests/ and tools/ (include/ribca_hip_test.h): a library of their own, linked against the product library -- the same
+# launchers and kernels, none of them exported by libribca_hip.so itself
+LIB_TEST = os.path.join(HERE, "libribca_hip_test.so")
+LIB_TEST_DIAG = os.path.join(HERE, "libribca_hip_diag_test.so")
+TEST_SOURCES = ["ribca_test_api.hip"]
 SOURCES = ["gemm_split16.hip", "gemm_duo.hip", "gemm_mx.hip", "attention.hip", "cell_attention.hip", "vit_misc.hip", "preprocess.hip", "preprocess_scaled.hip", "vote.hip", "colorize.hip", "knn.hip", "normalize.hip", "ribca_api.hip"]
-HEADERS = ["ribca_common.h", "ribca_kernels.h", "gemm_epi.h", os.path.join("..", "..", "include", "ribca_hip.h")]
+HEADERS = ["ribca_common.h", "ribca_kernels.h", "ribca_status.h", "gemm_epi.h", os.path.join("..", "..", "include", "ribca_hip.h"),
+           os.path.join("..", "..", "include", "ribca_hip_test.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
@@ -25,7 +31,7 @@ def source_fingerprint() -> str:
     committed counter files are stamped with this instead; bench.py compares it with the tree it runs from.)"""
     import hashlib
     h = hashlib.sha256()
-    for name in sorted(SOURCES) + sorted(HEADERS):
+    for name in sorted(SOURCES + TEST_SOURCES) + sorted(HEADERS):
         path = os.path.normpath(os.path.join(CSRC, name))
         h.update(os.path.basename(path).encode() + b"\0")
         with open(path, "rb") as f:
@@ -51,7 +57,7 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = True, diag: bool = False) -> str:
     """diag=True builds libribca_hip_diag.so with -DRIBCA_DIAG: the product kernels plus the A/B / timing-ablation / stamp forms that
     tools/ drive (select it at run time with RIBCA_DIAG=1).  The product library carries none of them."""
-    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    srcs = [s for s in SOURCES + TEST_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objdir = os.path.join(HERE, "build_diag" if diag else "build")
     lib_path = LIB_DIAG if diag else LIB
@@ -74,9 +80,17 @@ def build(force: bool = False, verbose: bool = True, diag: bool = False) -> str:
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         res = list(ex.map(compile_one, srcs))
-    objs = [o for o, _ in res]
-    if force or any(ch for _, ch in res) or _stale(lib_path, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
+    objs = [o for (o, _), src in zip(res, srcs) if src not in TEST_SOURCES]
+    test_objs = [o for (o, _), src in zip(res, srcs) if src in TEST_SOURCES]
+    if force or _stale(lib_path, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-soname," + os.path.basename(lib_path), "-o", lib_path] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    test_path = LIB_TEST_DIAG if diag else LIB_TEST
+    if force or _stale(test_path, test_objs + [lib_path]):
+        libname = os.path.basename(lib_path)[3:-3]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", test_path] + test_objs + ["-L" + HERE, "-l" + libname, "-Wl,-rpath,$ORIGIN"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))

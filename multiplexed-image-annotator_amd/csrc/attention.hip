@@ -362,7 +362,7 @@ void launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, 
 #define RIBCA_ATT(HD_, NT_) \
   hipLaunchKernelGGL((attention_kernel<HD_, NT_>), grid, block, 0, s, q, k, vt, out, ldo, pairs, a.H, a.T, q_tiles)
   if (a.NT == 1 && a.hd == 64) RIBCA_ATT(64, 1);
-  else abort();   // geometry is validated by the C ABI before any launch
+  else launch_error("launch_attention: no kernel for %d tokens x head dim %d (attention_supported() says which exist)", a.T, a.hd);
 #undef RIBCA_ATT
 }
 

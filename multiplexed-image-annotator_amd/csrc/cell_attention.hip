@@ -348,7 +348,7 @@ void launch_cell_qkv_attention(const uint16_t* z, int ldz, const uint16_t* W, in
   auto go = [&](auto kern, int lds) {
     static unsigned long long attr_done[3] = {0ull, 0ull, 0ull};      // per width (one kernel instantiation each) and device
     const int slot = D == 288 ? 1 : D == 384 ? 2 : 0;
-    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done[slot]);
+    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done[slot])) return;
 #ifdef RIBCA_DIAG
     static const int dbg = getenv("RIBCA_CELL_DBG") ? atoi(getenv("RIBCA_CELL_DBG")) : 0;      // timing ablations of tools/bench_cell_attention.py
 #else

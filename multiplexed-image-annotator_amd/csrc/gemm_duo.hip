@@ -564,7 +564,7 @@ static bool launch_duo_impl(const GemmArgs& g, const Epi& epi, hipStream_t s, in
   auto go = [&](auto abl_c) {
     constexpr int ABL = decltype(abl_c)::value;
     static unsigned long long attr_done = 0ull;
-    ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_ps_duo_kernel<BM, NW, WM, TN, NWS, Epi, ABL>), (int)(100 * 1024), attr_done);
+    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_ps_duo_kernel<BM, NW, WM, TN, NWS, Epi, ABL>), (int)(100 * 1024), attr_done)) return;
     hipLaunchKernelGGL((gemm_ps_duo_kernel<BM, NW, WM, TN, NWS, Epi, ABL>), grid, block, lds, s, g.A, g.lda, wf, g.M, g.Kp, mtiles, ntiles, epi, mode_p, delay);
   };
   // the diagnostic forms (no epilogue / stamps) exist for the epilogues tools/bench_gemm.py and tools/stamp_duo.py drive

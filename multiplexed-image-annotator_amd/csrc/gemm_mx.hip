@@ -743,7 +743,7 @@ static void launch_mx_impl(const MxAct& A, const MxWeight& W, int M, int N, cons
   const int nb = A.Kp / 128;
   void (*kernel)(MxAct, const uint16_t*, const unsigned char*, int, int, int, int, Epi, int) = gemm_mx_duo_kernel<Epi, ABL>;
   static unsigned long long attr_done = 0ull;
-  ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), L_TOTAL, attr_done);
+  if (!ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), L_TOTAL, attr_done)) return;
   // W-panel walk (see the kernel's tile map): RIBCA_MX_PANEL_KB = the most weight image (KB) a panel may hold, applied only where the
   // whole image is larger (qkv / fc1 at D = 576: 3.1 / 4.2 MB against the XCD's 4 MB L2); 0 = off
   static const int panel_kb = getenv("RIBCA_MX_PANEL_KB") ? atoi(getenv("RIBCA_MX_PANEL_KB")) : 0;
@@ -769,7 +769,7 @@ ResidStatGeom launch_gemm_mx_resid(const MxAct& A, const MxWeight& W, int M, int
   epi.nt = (mx_nt >> 3) & 1;
   if (zmx != nullptr) {
     // (whole 192-column tiles: every wave of a workgroup then reaches the barrier of the emission)
-    if (N % MX_BN != 0) { fprintf(stderr, "ribca: MX3 copy of the residual rows needs N %% 192 == 0\n"); abort(); }
+    if (N % MX_BN != 0) { launch_error("launch_gemm_mx_resid: an MX3 copy of the residual rows needs N %% 192 == 0 (N = %d)", N); return ResidStatGeom{N / 48, 48}; }
     epi.zmx = *zmx;
   }
 #ifdef RIBCA_DIAG
@@ -783,7 +783,7 @@ ResidStatGeom launch_gemm_mx_resid(const MxAct& A, const MxWeight& W, int M, int
 // qkv with the LayerNorm fold (EpiQKVLn exactly as launch_gemm_qkv_ln builds it, gemm_split16.hip)
 void launch_gemm_mx_qkv_ln(const MxAct& A, const MxWeight& W, int M, int N, const float* bias, const float2* rowstat, const float* csum, uint16_t* q,
                            uint16_t* k, uint16_t* vt, const AttnGeom& a, float scale, hipStream_t s) {
-  if (N % MX_BN != 0) { fprintf(stderr, "ribca: launch_gemm_mx_qkv_ln needs N %% 192 == 0\n"); abort(); }
+  if (N % MX_BN != 0) { launch_error("launch_gemm_mx_qkv_ln needs N %% 192 == 0 (N = %d)", N); return; }
   // RIBCA_MX_NT: bit 0 = the q / k / v rows stored non-temporal (A/B: no effect measured), bit 1 = the MX3 planes of h (default on, below)
   static const int mx_nt = getenv("RIBCA_MX_NT") ? atoi(getenv("RIBCA_MX_NT")) : 2;
   const EpiQKVLn epi{q, k, vt, bias, a.D, a.hd, a.hdq, a.hdv, scale, M, N, a.T, a.TP, a.H, a.KP, mx_nt & 1,
@@ -793,7 +793,7 @@ void launch_gemm_mx_qkv_ln(const MxAct& A, const MxWeight& W, int M, int N, cons
 }
 void launch_gemm_mx_gelu(const MxAct& A, const MxWeight& W, int M, int N, const float* bias, const float2* rowstat, const float* csum, const MxAct& out,
                          hipStream_t s) {
-  if (N % MX_BN != 0 || out.Kp != N) { fprintf(stderr, "ribca: launch_gemm_mx_gelu needs N %% 192 == 0 and out.Kp == N\n"); abort(); }
+  if (N % MX_BN != 0 || out.Kp != N) { launch_error("launch_gemm_mx_gelu needs N %% 192 == 0 and out.Kp == N (N = %d, out.Kp = %d)", N, out.Kp); return; }
   // The emitted planes of h (715 MB per launch at D = 576) are read once, by the next launch: stored non-temporal they do not displace
   // the weight image from the XCD's L2 -- fetch 1689 -> 1125 MB per launch, fc1 -2 %, fc2 -1 % (profiles/r4/ab_mx_nt_stores.txt).
   // RIBCA_MX_NT bit 1 = 0 for A/B.

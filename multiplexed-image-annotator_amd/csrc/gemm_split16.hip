@@ -796,7 +796,7 @@ static void launch_split(const GemmArgs& g, const Epi& epi, hipStream_t s) {
   const int ntiles = gemm_padded_n(g.N) / BN;
   const size_t lds = (size_t)3 * (256 + BN) * ROWB + ((Epi::kFold || std::is_same<Epi, EpiResidPS>::value) ? fold_lds_bytes<BN>() : 0);
   static unsigned long long attr_done = 0ull;
-  ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_ps_split_kernel<BN, Epi, ABL, STAG, LEPI>), (int)lds, attr_done);
+  if (!ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_ps_split_kernel<BN, Epi, ABL, STAG, LEPI>), (int)lds, attr_done)) return;
   // tile time in 10 ns ticks: K steps of ~0.65/0.87/1.15 us (BN 64/96/128) + pipeline fill + epilogue
   int deph = 0;
   static const bool env_deph = getenv("RIBCA_GEMM_DEPH") != nullptr;
@@ -967,10 +967,14 @@ ResidStatGeom launch_gemm_resid_ps(const GemmArgs& g, uint16_t* z, int ldz, floa
   // zmx: the new rows also in the MX3 format (gemm_mx.hip) -- the 128 x 192 tile of the two-workgroups form emits it; the caller asks for
   // it only where that form exists (N % 192 == 0, a fragment-order weight), and the choice is the model's, never the chunk's
   if (zmx != nullptr) {
-    if (g.WF == nullptr || g.N % 192 != 0 || g_variant != 0) { fprintf(stderr, "ribca: MX3 copy of the residual rows asked of a shape without the 128 x 192 form\n"); abort(); }
+    if (g.WF == nullptr || g.N % 192 != 0 || g_variant != 0) {
+      launch_error("launch_gemm_resid_ps: an MX3 copy of the residual rows needs the 128 x 192 form (N %% 192 == 0, a fragment-order weight, "
+                   "gemm variant 0): N = %d, WF %s, variant %d", g.N, g.WF ? "given" : "missing", g_variant);
+      return ResidStatGeom{g.N / 48, 48};
+    }
     EpiResidZK epi{z, ldz, g.bias, g.M, g.N, part, prev, prev_stride};
     epi.zmx = *zmx;
-    if (!launch_duo<192, EpiResidZK>(g, epi, s, 0)) { fprintf(stderr, "ribca: launch_duo<192> refused\n"); abort(); }
+    if (!launch_duo<192, EpiResidZK>(g, epi, s, 0)) launch_error("launch_gemm_resid_ps: the 128 x 192 two-workgroups form refused N = %d, Kp = %d", g.N, g.Kp);
     return ResidStatGeom{g.N / 48, 48};
   }
   if (want && g_variant == 0 && g.WF != nullptr && g.N % blk == 0 && g.N % 8 == 0) {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdarg>
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
@@ -12,23 +13,15 @@
 #include "../../include/ribca_hip.h"
 #include "ribca_common.h"
 #include "ribca_kernels.h"
+#include "ribca_status.h"
 
 using namespace ribca;
 
 namespace {
 
-thread_local std::string g_err;
-
-int fail(const std::string& msg) {
-  g_err = msg;
-  return 1;
-}
-int hip_fail(hipError_t e, const char* what) { return fail(std::string(what) + ": " + hipGetErrorString(e)); }
-#define HIP_TRY(expr)                                   \
-  do {                                                  \
-    hipError_t e_ = (expr);                             \
-    if (e_ != hipSuccess) return hip_fail(e_, #expr);   \
-  } while (0)
+// (status plumbing: ribca_status.h -- shared with the test-hook library)
+int fail(const std::string& msg) { return api_fail(msg.c_str()); }
+int hip_fail(hipError_t e, const char* what) { return api_hip_fail(e, what); }
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -71,6 +64,40 @@ void prof_drain() {
 }
 
 }  // namespace
+
+namespace ribca {
+namespace {
+thread_local std::string g_err;
+// what a launcher recorded with launch_error() since the calling thread's last api_finish() (the first record wins: later ones are
+// usually its consequences)
+thread_local std::string g_launch_err;
+}  // namespace
+void launch_error(const char* fmt, ...) {
+  if (!g_launch_err.empty()) return;
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_launch_err = buf;
+}
+int api_fail(const char* msg) {
+  g_err = msg ? msg : "unknown error";
+  g_launch_err.clear();
+  return 1;
+}
+int api_hip_fail(hipError_t e, const char* what) { return api_fail((std::string(what) + ": " + hipGetErrorString(e)).c_str()); }
+int api_finish() {
+  if (!g_launch_err.empty()) {
+    const std::string m = g_launch_err;
+    (void)hipGetLastError();
+    return api_fail(m.c_str());
+  }
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : api_hip_fail(e, "kernel launch");
+}
+const char* api_last_error() { return g_err.c_str(); }
+}  // namespace ribca
 
 // ----------------------------------------------------------------------------------------------- model handles
 // weights of one pre-LN transformer block (timm Block): fp32 vectors + packed-split matrices
@@ -489,10 +516,7 @@ void run_last_block_cls_fold(const BlockW& L, const BlockWs& w, int cells, const
 extern "C" {
 
 int ribca_version(void) { return 100; }
-const char* ribca_last_error(void) { return g_err.c_str(); }
-int32_t ribca_gemm_padded_n(int32_t N) { return gemm_padded_n(N); }
-int ribca_set_gemm_variant(int32_t v) { gemm_set_variant(v); return 0; }
-int ribca_set_gemm_stamps(void* dev_buffer, int64_t capacity_blocks) { return gemm_set_stamp_buffer(dev_buffer, capacity_blocks); }
+const char* ribca_last_error(void) { return api_last_error(); }
 
 int32_t ribca_mx_enabled(int32_t D) { return mx_on(D) ? 1 : 0; }
 int32_t ribca_mxz_enabled(int32_t D) { return mx_z_on(D) ? 1 : 0; }
@@ -533,6 +557,7 @@ int ribca_vit_create(const float* blob, int64_t blob_len, int32_t D, int32_t C, 
   r.copy(m->head_w, (size_t)K * D); r.copy(m->head_b, K);
   e = r.err != hipSuccess ? r.err : hipGetLastError();
   if (e != hipSuccess) { ribca_vit_destroy(m); return hip_fail(e, "weight packing"); }
+  if (api_finish() != 0) { ribca_vit_destroy(m); return 1; }
   *out = m;
   return 0;
 }
@@ -624,7 +649,7 @@ static int vit_forward_impl(const ribca_vit_t* m, const float* patches, int32_t 
       launch_head_softmax(w.z, D, m->norm_w, m->norm_b, m->head_w, m->head_b, probs + (size_t)c0 * m->K, D, m->K, bc, s);
     }
   }
-  HIP_TRY(hipGetLastError());
+  RIBCA_FINISH();
   return 0;
 }
 
@@ -664,6 +689,7 @@ int ribca_mae_create(const float* blob, int64_t blob_len, int32_t L, int32_t enc
   r.copy(m->pred_b, kTokPix);
   e = r.err != hipSuccess ? r.err : hipGetLastError();
   if (e != hipSuccess) { ribca_mae_destroy(m); return hip_fail(e, "imputer weight packing"); }
+  if (api_finish() != 0) { ribca_mae_destroy(m); return 1; }
   *out = m;
   return 0;
 }
@@ -754,7 +780,7 @@ int ribca_mae_impute(const ribca_mae_t* m, float* patches, const int32_t* presen
       launch_gemm_rowmap(g, pch, kTokPix, nullptr, 0, t_missing, t_missing, Mi, L, s);
     }
   }
-  HIP_TRY(hipGetLastError());
+  RIBCA_FINISH();
   return 0;
 }
 
@@ -762,7 +788,7 @@ int ribca_mae_impute(const ribca_mae_t* m, float* patches, const int32_t* presen
 int ribca_mask_minmax(const int32_t* mask, int64_t n, int32_t* out2, void* stream) {
   if (!out2 || (n > 0 && !mask)) return fail("ribca_mask_minmax: NULL buffer");
   launch_mask_max(mask, n, out2, (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
+  RIBCA_FINISH();
   return 0;
 }
 
@@ -772,7 +798,7 @@ int ribca_label_table(const int32_t* mask, int32_t H, int32_t W, int32_t L, int3
   hipStream_t s = (hipStream_t)stream;
   launch_label_table_init(tab_i32, (unsigned long long*)tab_u64, L, s);
   launch_label_table(mask, H, W, L, tab_i32, (unsigned long long*)tab_u64, s);
-  HIP_TRY(hipGetLastError());
+  RIBCA_FINISH();
   return 0;
 }
 
@@ -780,7 +806,7 @@ int ribca_channel_min(const float* image, int32_t C, int64_t hw, float* out_min,
   if (!image || !out_min) return fail("ribca_channel_min: NULL buffer");
   if (C <= 0 || C > 64) return fail("ribca_channel_min: C must be in [1, 64]");
   launch_channel_min(image, C, hw, out_min, (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
+  RIBCA_FINISH();
   return 0;
 }
 
@@ -792,7 +818,7 @@ int ribca_extract_patches(const float* image, int32_t C, int32_t H, int32_t W, c
   if (C <= 0 || H <= 0 || W <= 0 || n < 0) return fail("ribca_extract_patches: bad sizes");
   PatchArgs a{image, C, H, W, mask, chan_min, cell_id, bbox, taps, patches, avg, n};
   launch_extract_patches(a, (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
+  RIBCA_FINISH();
   return 0;
 }
 
@@ -807,7 +833,7 @@ int ribca_extract_patches_scaled(const float* image, int32_t C, int32_t H, int32
   PatchArgs a{image, C, H, W, mask, chan_min, cell_id, bbox, taps, patches, avg, n};
   if (launch_extract_patches_scaled(a, patch_size, aa_taps, aa_radius, src_index, (hipStream_t)stream) != 0)
     return fail("ribca_extract_patches_scaled: patch_size must be in [4, 90] (cell_size up to 67) and aa_radius in [0, 15]");
-  HIP_TRY(hipGetLastError());
+  RIBCA_FINISH();
   return 0;
 }
 
@@ -819,7 +845,7 @@ int ribca_vote(const float* p_a, int32_t k_a, const int8_t* map_a, const float* 
   if (k_a <= 0 || k_a > 16 || (p_b && (k_b <= 0 || k_b > 16))) return fail("ribca_vote: class counts must be in [1, 16]");
   VoteArgs a{p_a, k_a, map_a, p_b, k_b, map_b, type_conf, conf, n, label, out_conf};
   launch_vote(a, (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
+  RIBCA_FINISH();
   return 0;
 }
 
@@ -832,7 +858,7 @@ int ribca_colorize(const int32_t* mask, int64_t n_pixels, const int32_t* label_t
   if (n_pixels < 0 || L <= 0) return fail("ribca_colorize: bad sizes");
   launch_colorize(mask, n_pixels, label_to_cell, L, cell_type_rgb, cell_conf_rgb, cell_type_idx, out_type_rgb, out_conf_rgb, out_type_idx,
                   (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
+  RIBCA_FINISH();
   return 0;
 }
 
@@ -843,7 +869,7 @@ int ribca_knn_cooccurrence(const double* x, const double* y, const int32_t* cell
   if (n_neighbors > n_cells) return fail("ribca_knn_cooccurrence: n_neighbors exceeds the number of cells");
   if (launch_knn_cooccurrence(x, y, cell_type, n_cells, n_neighbors, n_types, reinterpret_cast<unsigned long long*>(matrix), (hipStream_t)stream))
     return fail("ribca_knn_cooccurrence: n_neighbors must be in [1, 32] and n_types in [1, 32]");
-  HIP_TRY(hipGetLastError());
+  RIBCA_FINISH();
   return 0;
 }
 
@@ -861,7 +887,7 @@ int ribca_knn_compositions(const double* x, const double* y, const int32_t* cell
   if (k > n_cells) return fail("ribca_knn_compositions: more neighbours requested than cells");
   if (launch_knn_compositions(x, y, cell_type, n_cells, k, n_types, n_sizes, sizes, counts, (hipStream_t)stream))
     return fail("ribca_knn_compositions: needs max(sizes) <= 255 and n_types <= 32");
-  HIP_TRY(hipGetLastError());
+  RIBCA_FINISH();
   return 0;
 }
 
@@ -869,7 +895,7 @@ int ribca_knn_compositions(const double* x, const double* y, const int32_t* cell
 int ribca_u16_to_f32(const uint16_t* in, float* out, int64_t n, void* stream) {
   if (n > 0 && (!in || !out)) return fail("ribca_u16_to_f32: NULL buffer");
   launch_u16_to_f32(in, out, n, (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
+  RIBCA_FINISH();
   return 0;
 }
 int ribca_gauss1d(const float* in, float* out, int32_t planes, int32_t H, int32_t W, int32_t axis, const double* taps, int32_t R,
@@ -878,19 +904,19 @@ int ribca_gauss1d(const float* in, float* out, int32_t planes, int32_t H, int32_
   if (in == out) return fail("ribca_gauss1d: in-place filtering is not supported");
   if (axis < 0 || axis > 1 || mode < 0 || mode > 1 || R < 0) return fail("ribca_gauss1d: bad axis/mode/radius");
   launch_gauss1d(in, out, planes, H, W, axis, taps, R, mode, (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
+  RIBCA_FINISH();
   return 0;
 }
 int ribca_bg_subtract(float* x, const float* bg, int64_t n, float cap, void* stream) {
   if (n > 0 && (!x || !bg)) return fail("ribca_bg_subtract: NULL buffer");
   launch_bg_subtract(x, bg, n, cap, (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
+  RIBCA_FINISH();
   return 0;
 }
 int ribca_plane_max(const float* x, int32_t planes, int64_t hw, float* out, void* stream) {
   if (!x || !out) return fail("ribca_plane_max: NULL buffer");
   launch_plane_max(x, planes, hw, out, (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
+  RIBCA_FINISH();
   return 0;
 }
 int ribca_radix_hist(const float* x, int32_t planes, int64_t hw, const uint32_t* prefix, uint32_t mask_hi, int32_t shift, int32_t bits,
@@ -898,13 +924,13 @@ int ribca_radix_hist(const float* x, int32_t planes, int64_t hw, const uint32_t*
   if (!x || !prefix || !hist) return fail("ribca_radix_hist: NULL buffer");
   if (bits < 1 || bits > 11 || shift < 0 || shift + bits > 32) return fail("ribca_radix_hist: bad shift/bits");
   launch_radix_hist(x, planes, hw, prefix, mask_hi, shift, bits, hist, (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
+  RIBCA_FINISH();
   return 0;
 }
 int ribca_norm_finalize(float* x, int32_t planes, int64_t hw, const int32_t* mode, const float* clip, const float* denom, void* stream) {
   if (!x || !mode || !clip || !denom) return fail("ribca_norm_finalize: NULL buffer");
   launch_norm_finalize(x, planes, hw, mode, clip, denom, (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
+  RIBCA_FINISH();
   return 0;
 }
 
@@ -924,241 +950,5 @@ int ribca_prof_read(double* ms_out10, int64_t* count_out10) {
   return 0;
 }
 const char* ribca_prof_name(int32_t cls) { return (cls >= 0 && cls < P_COUNT) ? kProfNames[cls] : ""; }
-
-// ------------------------------------------------------------------------------------------- test hooks
-int ribca_test_pack_weight(const float* w, int32_t N, int32_t K, uint16_t* out, int32_t Np, int32_t Kp, void* stream) {
-  launch_pack_weight(w, N, K, out, Np, Kp, (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-int ribca_test_layernorm(const float* z, int32_t ldz, const float* gamma, const float* beta, uint16_t* out, int32_t ldo, int32_t M,
-                         int32_t D, void* stream) {
-  launch_layernorm_ps(z, ldz, gamma, beta, out, ldo, M, D, (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-int ribca_test_gemm(int32_t kind, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
-                    const float* bias, void* out, int32_t ldo, void* stream) {
-  GemmArgs g{A, lda, W, ldw, M, N, Kp, bias};
-  if (kind == 0) launch_gemm_resid(g, (float*)out, ldo, (hipStream_t)stream);
-  else if (kind == 1) launch_gemm_gelu(g, (uint16_t*)out, ldo, (hipStream_t)stream);
-  else return fail("ribca_test_gemm: kind must be 0 or 1");
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-int ribca_test_fold_weight(const float* w, int32_t N, int32_t K, const float* gamma, const float* beta, const float* bias, uint16_t* out,
-                           int32_t Np, int32_t Kp, float* csum, float* bias2, void* stream) {
-  if (Np != gemm_padded_n(N)) return fail("ribca_test_fold_weight: Np must be ribca_gemm_padded_n(N)");
-  launch_pack_weight_fold(w, N, K, gamma, beta, bias, out, Np, Kp, csum, bias2, (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-int ribca_test_row_stats(uint16_t* z_ps, int32_t ldz, int32_t M, int32_t D, float* rowstat, int32_t recentre, void* stream) {
-  launch_row_stats_ps(z_ps, ldz, M, D, reinterpret_cast<float2*>(rowstat), recentre != 0, (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-int32_t ribca_test_resid_tiles(int32_t N) { return gemm_resid_tiles(N); }
-int ribca_test_gemm_resid_ps(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
-                             const float* bias, uint16_t* z_ps, int32_t ldz, float* part, float* rowstat, const float* prev, void* stream) {
-  if (N % 8 != 0) return fail("ribca_test_gemm_resid_ps: N must be a multiple of 8");
-  if ((rowstat != nullptr) != (part != nullptr)) return fail("ribca_test_gemm_resid_ps: part and rowstat go together");
-  GemmArgs g{A, lda, W, ldw, M, N, Kp, bias};
-  const ResidStatGeom sg = launch_gemm_resid_ps(g, z_ps, ldz, reinterpret_cast<float2*>(part), reinterpret_cast<const float2*>(prev), 1, (hipStream_t)stream);
-  if (rowstat) launch_ln_finalize(reinterpret_cast<const float2*>(part), sg.tiles, M, sg.bn, N, reinterpret_cast<float2*>(rowstat), (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-int32_t ribca_test_resid_part_rows(int32_t N) { return gemm_resid_part_rows(N); }
-// the same update on the two-workgroups-per-CU kernel with the residual tile riding the A ring (EpiResidZK): what the classifiers' full
-// blocks run for proj / fc2 where it measured faster (any M: the choice depends on the shape of the weight alone).  part needs ribca_test_resid_part_rows(N) x M pairs; wf_scratch the size of the packed weight.
-int ribca_test_gemm_resid_ps_duo(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
-                                 const float* bias, uint16_t* wf_scratch, uint16_t* z_ps, int32_t ldz, float* part, float* rowstat,
-                                 const float* prev, void* stream) {
-  if (!wf_scratch) return fail("ribca_test_gemm_resid_ps_duo: wf_scratch is NULL");
-  if (N % 8 != 0) return fail("ribca_test_gemm_resid_ps_duo: N must be a multiple of 8");
-  if ((rowstat != nullptr) != (part != nullptr)) return fail("ribca_test_gemm_resid_ps_duo: part and rowstat go together");
-  launch_pack_wf(W, ldw, gemm_padded_n(N), Kp, wf_scratch, (hipStream_t)stream);
-  GemmArgs g{A, lda, W, ldw, M, N, Kp, bias, wf_scratch};
-  const ResidStatGeom sg = launch_gemm_resid_ps(g, z_ps, ldz, reinterpret_cast<float2*>(part), reinterpret_cast<const float2*>(prev), 1, (hipStream_t)stream,
-                                                true);
-  if (sg.bn == gemm_resid_bn(N))      // the duo kernel's wave blocks are 16 / 32 / 48 columns wide, never a tile width
-    return fail("ribca_test_gemm_resid_ps_duo: the two-workgroups-per-CU kernel did not take this shape");
-  if (rowstat) launch_ln_finalize(reinterpret_cast<const float2*>(part), sg.tiles, M, sg.bn, N, reinterpret_cast<float2*>(rowstat), (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-int64_t ribca_test_mx_weight_bytes(int32_t N, int32_t Kp, int32_t which) {
-  const int Np = (N + 15) / 16 * 16;
-  return (int64_t)(which == 0 ? mx_wh_bytes(Np, Kp) : mx_wx_bytes(Np, Kp));
-}
-int ribca_test_mx_pack_act(const uint16_t* A, int32_t lda, int32_t M, int32_t Kp, uint16_t* hi_out, uint8_t* l8_out, uint8_t* sc_out, void* stream) {
-  if (!A || !hi_out || !l8_out || !sc_out) return fail("ribca_test_mx_pack_act: NULL buffer");
-  if (Kp % 32 != 0) return fail("ribca_test_mx_pack_act: Kp must be a multiple of 32");
-  const MxAct a{hi_out, l8_out, sc_out, round_up(Kp, 128), M};
-  launch_mx_pack_act(A, lda, M, Kp, a, (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-int ribca_test_gemm_mx_resid(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp, const float* bias,
-                             uint16_t* hi_out, uint8_t* l8_out, uint8_t* sc_out, uint16_t* wh_scratch, uint8_t* wx_scratch, uint16_t* z_ps,
-                             int32_t ldz, float* part, float* rowstat, const float* prev, void* stream) {
-  if (!gemm_mx_supported(N, Kp)) return fail("ribca_test_gemm_mx_resid: N must be a multiple of 48 and Kp of 128");
-  if ((rowstat != nullptr) != (part != nullptr)) return fail("ribca_test_gemm_mx_resid: part and rowstat go together");
-  hipStream_t s = (hipStream_t)stream;
-  const MxAct a{hi_out, l8_out, sc_out, Kp, M};
-  launch_mx_pack_act(A, lda, M, Kp, a, s);
-  launch_mx_pack_w(W, ldw, (N + 15) / 16 * 16, Kp, Kp, wh_scratch, wx_scratch, s);
-  const MxWeight w{wh_scratch, wx_scratch};
-  const ResidStatGeom sg = launch_gemm_mx_resid(a, w, M, N, bias, z_ps, ldz, reinterpret_cast<float2*>(part), reinterpret_cast<const float2*>(prev), 1, s);
-  if (rowstat) launch_ln_finalize(reinterpret_cast<const float2*>(part), sg.tiles, M, sg.bn, N, reinterpret_cast<float2*>(rowstat), s);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-int ribca_test_gemm_mx_resid_packed(const uint16_t* hi, const uint8_t* l8, const uint8_t* sc, int32_t Kp, const uint16_t* wh, const uint8_t* wx,
-                                    int32_t M, int32_t N, const float* bias, uint16_t* z_ps, int32_t ldz, float* part, float* rowstat,
-                                    const float* prev, void* stream) {
-  if (!gemm_mx_supported(N, Kp)) return fail("ribca_test_gemm_mx_resid_packed: N must be a multiple of 48 and Kp of 128");
-  if ((rowstat != nullptr) != (part != nullptr)) return fail("ribca_test_gemm_mx_resid_packed: part and rowstat go together");
-  hipStream_t s = (hipStream_t)stream;
-  const MxAct a{const_cast<uint16_t*>(hi), const_cast<uint8_t*>(l8), const_cast<uint8_t*>(sc), Kp, M};
-  const MxWeight w{wh, wx};
-  const ResidStatGeom sg = launch_gemm_mx_resid(a, w, M, N, bias, z_ps, ldz, reinterpret_cast<float2*>(part), reinterpret_cast<const float2*>(prev), 1, s);
-  if (rowstat) launch_ln_finalize(reinterpret_cast<const float2*>(part), sg.tiles, M, sg.bn, N, reinterpret_cast<float2*>(rowstat), s);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-int ribca_test_gemm_gelu_mx(const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp, const float* bias2,
-                            const float* csum, const float* rowstat, uint16_t* wf_scratch, uint16_t* hi_out, uint8_t* l8_out, uint8_t* sc_out,
-                            void* stream) {
-  if (!wf_scratch || !csum || !rowstat) return fail("ribca_test_gemm_gelu_mx: NULL buffer");
-  launch_pack_wf(W, ldw, gemm_padded_n(N), Kp, wf_scratch, (hipStream_t)stream);
-  GemmArgs g{z_ps, lda, W, ldw, M, N, Kp, bias2, wf_scratch};
-  const MxAct out{hi_out, l8_out, sc_out, N, M};
-  if (!launch_gemm_gelu_mx(g, reinterpret_cast<const float2*>(rowstat), csum, out, (hipStream_t)stream))
-    return fail("ribca_test_gemm_gelu_mx: N must be a multiple of 128");
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-// mlp.fc1 on the MX kernel: z (packed-split, Kp columns) -> MX3 (a_*: scratch planes, Kp rounded up to 128) -> gelu(LN-folded product) in MX3
-int ribca_test_gemm_mx_fc1(const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp, const float* bias2,
-                           const float* csum, const float* rowstat, uint16_t* a_hi, uint8_t* a_l8, uint8_t* a_sc, uint16_t* wh_scratch,
-                           uint8_t* wx_scratch, uint16_t* hi_out, uint8_t* l8_out, uint8_t* sc_out, void* stream) {
-  if (!csum || !rowstat || !a_hi || !a_l8 || !a_sc || !wh_scratch || !wx_scratch) return fail("ribca_test_gemm_mx_fc1: NULL buffer");
-  if (N % 192 != 0 || Kp % 32 != 0) return fail("ribca_test_gemm_mx_fc1: N must be a multiple of 192 and Kp of 32");
-  hipStream_t s = (hipStream_t)stream;
-  const int Kz = round_up(Kp, 128);
-  const MxAct a{a_hi, a_l8, a_sc, Kz, M};
-  launch_mx_pack_act(z_ps, lda, M, Kp, a, s);
-  launch_mx_pack_w(W, ldw, N, Kp, Kz, wh_scratch, wx_scratch, s);
-  const MxAct out{hi_out, l8_out, sc_out, N, M};
-  launch_gemm_mx_gelu(a, MxWeight{wh_scratch, wx_scratch}, M, N, bias2, reinterpret_cast<const float2*>(rowstat), csum, out, s);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-// ribca_test_qkv_attention_fold with the qkv product on the MX kernel
-int ribca_test_qkv_attention_mx(const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t cells, int32_t D, int32_t Kp,
-                                const float* bias2, const float* csum, const float* rowstat, uint16_t* a_hi, uint8_t* a_l8, uint8_t* a_sc,
-                                uint16_t* wh_scratch, uint8_t* wx_scratch, uint16_t* q, uint16_t* k, uint16_t* vt, uint16_t* out, int32_t ldo,
-                                void* stream) {
-  if (!csum || !rowstat || !a_hi || !a_l8 || !a_sc || !wh_scratch || !wx_scratch) return fail("ribca_test_qkv_attention_mx: NULL buffer");
-  if ((3 * D) % 192 != 0 || Kp % 32 != 0) return fail("ribca_test_qkv_attention_mx: 3 D must be a multiple of 192 and Kp of 32");
-  hipStream_t s = (hipStream_t)stream;
-  const AttnGeom g = make_attn_geom(D, kHeads, kTokens);
-  const int M = cells * kTokens, Kz = round_up(Kp, 128);
-  const MxAct a{a_hi, a_l8, a_sc, Kz, M};
-  launch_mx_pack_act(z_ps, lda, M, Kp, a, s);
-  launch_mx_pack_w(W, ldw, 3 * D, Kp, Kz, wh_scratch, wx_scratch, s);
-  launch_gemm_mx_qkv_ln(a, MxWeight{wh_scratch, wx_scratch}, M, 3 * D, bias2, reinterpret_cast<const float2*>(rowstat), csum, q, k, vt, g,
-                        1.0f / sqrtf((float)g.hd), s);
-  launch_attention(q, k, vt, out, ldo, cells, g, s);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-// proj / fc2 writing the new rows a second time in MX3 (z_hi / z_l8 / z_sc, row pitch z_Kp).  kind 0: the packed-split operand on the
-// two-workgroups kernel (w_scratch: fragment-order copy of W; a_* and wx_scratch unused); kind 1: the MX kernel (a_*: MX3 image of A,
-// w_scratch / wx_scratch: the MX weight image)
-int ribca_test_gemm_resid_zmx(int32_t kind, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
-                              const float* bias, uint16_t* a_hi, uint8_t* a_l8, uint8_t* a_sc, uint16_t* w_scratch, uint8_t* wx_scratch,
-                              uint16_t* z_ps, int32_t ldz, float* part, float* rowstat, const float* prev, uint16_t* z_hi, uint8_t* z_l8,
-                              uint8_t* z_sc, int32_t z_Kp, void* stream) {
-  if (!w_scratch || !z_hi || !z_l8 || !z_sc || !part || !rowstat) return fail("ribca_test_gemm_resid_zmx: NULL buffer");
-  if (N % 192 != 0 || z_Kp % 128 != 0 || z_Kp < N) return fail("ribca_test_gemm_resid_zmx: N must be a multiple of 192, z_Kp of 128 and >= N");
-  hipStream_t s = (hipStream_t)stream;
-  const MxAct zmx{z_hi, z_l8, z_sc, z_Kp, M};
-  ResidStatGeom sg;
-  if (kind == 0) {
-    launch_pack_wf(W, ldw, gemm_padded_n(N), Kp, w_scratch, s);
-    GemmArgs g{A, lda, W, ldw, M, N, Kp, bias, w_scratch};
-    sg = launch_gemm_resid_ps(g, z_ps, ldz, reinterpret_cast<float2*>(part), reinterpret_cast<const float2*>(prev), 1, s, false, &zmx);
-  } else if (kind == 1) {
-    if (!a_hi || !a_l8 || !a_sc || !wx_scratch || Kp % 128 != 0) return fail("ribca_test_gemm_resid_zmx: kind 1 needs the MX3 scratch planes and Kp % 128 == 0");
-    const MxAct a{a_hi, a_l8, a_sc, Kp, M};
-    launch_mx_pack_act(A, lda, M, Kp, a, s);
-    launch_mx_pack_w(W, ldw, N, Kp, Kp, w_scratch, wx_scratch, s);
-    sg = launch_gemm_mx_resid(a, MxWeight{w_scratch, wx_scratch}, M, N, bias, z_ps, ldz, reinterpret_cast<float2*>(part), reinterpret_cast<const float2*>(prev), 1,
-                              s, 0, &zmx);
-  } else {
-    return fail("ribca_test_gemm_resid_zmx: kind must be 0 or 1");
-  }
-  launch_ln_finalize(reinterpret_cast<const float2*>(part), sg.tiles, M, sg.bn, N, reinterpret_cast<float2*>(rowstat), s);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-int ribca_test_gemm_fold(int32_t kind, const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
-                         const float* bias2, const float* csum, const float* rowstat, void* out, int32_t ldo, void* stream) {
-  if (kind != 1) return fail("ribca_test_gemm_fold: kind must be 1");
-  GemmArgs g{z_ps, lda, W, ldw, M, N, Kp, bias2};
-  launch_gemm_gelu_ln(g, reinterpret_cast<const float2*>(rowstat), csum, (uint16_t*)out, ldo, (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-int ribca_test_qkv_attention_fold(const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t cells, int32_t D, int32_t Kp,
-                                  const float* bias2, const float* csum, const float* rowstat, uint16_t* q, uint16_t* k, uint16_t* vt,
-                                  uint16_t* out, int32_t ldo, void* stream) {
-  const AttnGeom a = make_attn_geom(D, kHeads, kTokens);
-  GemmArgs g{z_ps, lda, W, ldw, cells * kTokens, 3 * D, Kp, bias2};
-  launch_gemm_qkv_ln(g, reinterpret_cast<const float2*>(rowstat), csum, q, k, vt, a, 1.0f / sqrtf((float)a.hd), (hipStream_t)stream);
-  launch_attention(q, k, vt, out, ldo, cells, a, (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-int ribca_test_gemm_duo_gelu(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t M, int32_t N, int32_t Kp,
-                             const float* bias, const float* csum, const float* rowstat, uint16_t* wf_scratch, uint16_t* out, int32_t ldo,
-                             void* stream) {
-  if (M < 4096) return fail("ribca_test_gemm_duo_gelu: the forward uses this kernel for M >= 4096 only");
-  if (!wf_scratch) return fail("ribca_test_gemm_duo_gelu: wf_scratch is NULL");
-  if ((csum != nullptr) != (rowstat != nullptr)) return fail("ribca_test_gemm_duo_gelu: csum and rowstat go together");
-  launch_pack_wf(W, ldw, gemm_padded_n(N), Kp, wf_scratch, (hipStream_t)stream);
-  GemmArgs g{A, lda, W, ldw, M, N, Kp, bias, wf_scratch};
-  if (csum) launch_gemm_gelu_ln(g, reinterpret_cast<const float2*>(rowstat), csum, out, ldo, (hipStream_t)stream);
-  else launch_gemm_gelu(g, out, ldo, (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-int ribca_test_cell_attention(const uint16_t* z_ps, int32_t lda, const uint16_t* W, int32_t ldw, int32_t cells, int32_t D,
-                              const float* bias2, const float* csum, const float* rowstat, uint16_t* out, int32_t ldo, void* stream) {
-  if (!cell_attention_supported(D, kHeads, kTokens)) return fail("ribca_test_cell_attention: D must be 144, 288 or 384");
-  launch_cell_qkv_attention(z_ps, lda, W, ldw, bias2, csum, reinterpret_cast<const float2*>(rowstat), out, ldo, cells, D,
-                            1.0f / sqrtf((float)(D / kHeads)), (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-int ribca_is_diag_build(void) {
-#ifdef RIBCA_DIAG
-  return 1;
-#else
-  return 0;
-#endif
-}
-int ribca_test_qkv_attention(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, int32_t cells, int32_t D, int32_t Kp,
-                             const float* bias, uint16_t* q, uint16_t* k, uint16_t* vt, uint16_t* out, int32_t ldo, void* stream) {
-  const AttnGeom a = make_attn_geom(D, kHeads, kTokens);
-  GemmArgs g{A, lda, W, ldw, cells * kTokens, 3 * D, Kp, bias};
-  launch_gemm_qkv(g, q, k, vt, a, 1.0f / sqrtf((float)a.hd), (hipStream_t)stream);
-  launch_attention(q, k, vt, out, ldo, cells, a, (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
 
 }  // extern "C"

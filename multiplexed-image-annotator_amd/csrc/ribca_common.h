@@ -26,19 +26,30 @@
 #include <cstdio>
 #include <cstdlib>
 
+// Launch errors.  A host-side launcher that cannot run its kernel (a shape it has no form for, an attribute the runtime refuses) launches
+// NOTHING and records why with launch_error(); the exported entry point that called it turns the record into a non-zero status whose text
+// ribca_last_error() returns (ribca_api.hip: RIBCA_FINISH).  The library never ends the process itself: it is loaded into the caller's process
+// (a napari worker, a Python interpreter), and the reference's own convention for a bad request is an exception the caller can catch
+// (cell_type_annotation/model.py:636, 770), not process death.
+namespace ribca {
+void launch_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+}
+
 // Raises a kernel's dynamic-LDS limit, once per (call site, device): a flag per call site alone would leave the second device of a process
-// without the attribute (the launch would then fail with "invalid argument" -- or, worse, be dropped).  A failure is fatal: a launch that
-// silently does not happen leaves stale results behind.  `done`: one bit per device ordinal (< 64), owned by the call site.
-inline void ensure_dynamic_lds(const void* kernel, int bytes, unsigned long long& done) {
+// without the attribute (the launch would then fail with "invalid argument" -- or, worse, be dropped).  false = the runtime refused (recorded
+// with launch_error): the caller must not launch -- a launch that silently does not happen leaves stale results behind, so the entry point
+// reports the failure instead.  `done`: one bit per device ordinal (< 64), owned by the call site.
+[[nodiscard]] inline bool ensure_dynamic_lds(const void* kernel, int bytes, unsigned long long& done) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-  if (dev >= 0 && dev < 64 && ((done >> dev) & 1ull)) return;
+  if (dev >= 0 && dev < 64 && ((done >> dev) & 1ull)) return true;
   const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) {
-    fprintf(stderr, "ribca: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed on device %d: %s\n", bytes, dev, hipGetErrorString(e));
-    abort();
+    ribca::launch_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed on device %d: %s", bytes, dev, hipGetErrorString(e));
+    return false;
   }
   if (dev >= 0 && dev < 64) done |= 1ull << dev;
+  return true;
 }
 
 

@@ -18,6 +18,12 @@ Schemes (x = h + l:  h = round16(x), l = x - h;  h' = low-precision copy of h us
     f16_fp8     same, h' = e4m3(h) l8 = e4m3(2^12 l)
     f16_fp6     same, h' and l as MX e2m3 with one power-of-two scale per 32 k                                 1 + 2 x 1/4
     f16_fp6t    fp6 l, h' = high byte (e5m2 truncation)  -- mixed fp8 x fp6 MFMA (fp8 rate)
+Round 5 (spend the confidence headroom) -- the MX mix of csrc/gemm_mx.hip and its one-correction reductions; a = activation,
+w = weight; the attention products and every linear not named by --linears stay f16x3:
+    mx175       ah.wh + al8.wh6 + ah6.wl6   al8 = e4m3 of l under the MX3 block scale, ?6 = MX e2m3             1 + 1/2 + 1/4   (production)
+    mx150       ah.wh + al8.wh6             no W lo image at all (weights rounded to fp16)                       1 + 1/2
+    mx125       ah.wh + ah6.wl6             no A lo plane at all (activations rounded to fp16: 2 bytes / element) 1 + 1/4
+    mx100       ah.wh                       one fp16 pass                                                        1
 """
 from __future__ import annotations
 
@@ -140,8 +146,44 @@ def mm_alloc(a, b, ta, tb):
     return torch.cat(aa, dim=-1) @ torch.cat(bb, dim=-1).transpose(-2, -1)
 
 
+def mx3_lo(x, h, block=32):
+    """e4m3 image of l = x - h under the MX3 scale rule of csrc/gemm_mx.hip: per 32 k, scale 2^(E - 19) with E the exponent of the block's
+    largest |h| (lo / scale <= 256 < 448)"""
+    k = x.shape[-1]
+    pad = (-k) % block
+    l = x - h
+    hp, lp = (F.pad(h, (0, pad)), F.pad(l, (0, pad))) if pad else (h, l)
+    hb, lb = hp.reshape(*hp.shape[:-1], -1, block), lp.reshape(*lp.shape[:-1], -1, block)
+    amax = hb.abs().amax(dim=-1, keepdim=True)
+    e = torch.floor(torch.log2(torch.where(amax > 0, amax, torch.full_like(amax, 2.0 ** -14)))).clamp(min=-14.0)
+    scale = torch.exp2(e - 19.0)
+    out = (r_e4m3(lb / scale) * scale).reshape(*hp.shape)
+    return out[..., :k] if pad else out
+
+
+MX_TERMS = {"mx175": (True, True), "mx150": (True, False), "mx125": (False, True), "mx100": (False, False)}
+LINEARS = {"wqkv", "wproj", "w1", "w2"}      # --linears: which weights take an mx* scheme (the others: f16x3)
+
+
+def mm_mx(a, b, scheme):
+    use_al, use_wl = MX_TERMS[scheme]
+    ah, bh = r_f16(a), r_f16(b)
+    aa, bb = [ah], [bh]
+    if use_al:
+        aa.append(mx3_lo(a, ah))
+        bb.append(mx_e2m3(bh))
+    if use_wl:
+        aa.append(mx_e2m3(ah))
+        bb.append(mx_e2m3(r_f16(b - bh)))
+    return torch.cat(aa, dim=-1) @ torch.cat(bb, dim=-1).transpose(-2, -1)
+
+
 def mm(a, b, scheme, ta=None, tb=None):
     """a (.., m, k) . b (.., n, k)^T under ``scheme``."""
+    if scheme in MX_TERMS:
+        if tb in LINEARS:
+            return mm_mx(a, b, scheme)
+        scheme = "f16x3"
     if scheme.startswith("alloc"):
         return mm_alloc(a, b, ta, tb)
     if scheme == "fp32":
@@ -159,7 +201,7 @@ def mm(a, b, scheme, ta=None, tb=None):
 def logits_scheme(sd, x, scheme, attn_scheme=None):
     """oracle.ref_vit.logits with every block product under ``scheme`` (patch embedding and head stay fp32 as in the kernels:
     embed_f32_kernel / head_softmax_kernel)."""
-    attn_scheme = attn_scheme or scheme
+    attn_scheme = attn_scheme or ("f16x3" if scheme in MX_TERMS else scheme)
     heads = ref_vit.HEADS
     b = x.shape[0]
     d = sd["cls_token"].shape[-1]
@@ -198,7 +240,10 @@ def main():
     ap.add_argument("--models", nargs="+", default=["immune_base", "immune_full"])
     ap.add_argument("--schemes", nargs="+", default=["bf16x3", "f16", "f16_bf8t", "f16_bf8r", "f16_fp8", "f16_fp6"])
     ap.add_argument("--seed", type=int, default=synth.SEED_BASE + 7)
+    ap.add_argument("--linears", nargs="+", default=["wqkv", "wproj", "w1", "w2"], help="weights that take an mx* scheme (others: f16x3)")
     args = ap.parse_args()
+    LINEARS.clear()
+    LINEARS.update(args.linears)
     torch.set_num_threads(os.cpu_count() or 1)
     for name in args.models:
         sd = synth.make_vit_state_dict(name, args.seed)

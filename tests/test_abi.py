@@ -8,10 +8,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "ribca_hip.h")).read()
+def declared_symbols(header="ribca_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(ribca_[a-z0-9_]+)\s*\(", text)))
+
+
+def exported_symbols(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(l.split()[-1] for l in out.splitlines() if " T ribca_" in l)
 
 
 def test_header_symbols_are_exported_and_bound():
@@ -25,7 +31,40 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(handle, n), f"{n} declared in include/ribca_hip.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in _lib.SIGNATURES"
     assert sorted(_lib.SIGNATURES) == names
+    # the product library exports the product ABI and nothing else with C linkage: no test hook, no A/B switch
+    assert exported_symbols(_lib.LIB_PATH) == names
     assert _lib.lib().ribca_version() >= 100
+
+
+def test_test_hooks_live_in_their_own_library():
+    """include/ribca_hip_test.h == exports of libribca_hip_test.so == _lib.TEST_SIGNATURES, disjoint from the product ABI; the package never
+    names a hook (only tests/ and tools/ load that library)"""
+    import __graft_entry__
+    __graft_entry__.build()
+    from multiplexed_image_annotator_amd import _lib
+    hooks = declared_symbols("ribca_hip_test.h")
+    assert len(hooks) >= 20 and not set(hooks) & set(declared_symbols())
+    assert exported_symbols(_lib.TEST_LIB_PATH) == hooks
+    assert sorted(_lib.TEST_SIGNATURES) == hooks
+    lib = _lib.lib()
+    assert lib.ribca_gemm_padded_n(100) in (128, 192)      # resolved through the proxy from the second library (no GPU needed)
+    with pytest.raises(AttributeError):
+        lib.ribca_no_such_entry_point
+    pkg = os.path.join(ROOT, "multiplexed-image-annotator_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py") and f != "_lib.py":
+            text = open(os.path.join(pkg, f)).read()
+            for h in hooks:
+                assert h not in text, f"{f} names the test hook {h}"
+
+
+def test_library_never_ends_the_process():
+    """no abort() / exit() / assert in the sources of either library: a refused request is a status (ribca_common.h launch_error)"""
+    csrc = os.path.join(ROOT, "multiplexed-image-annotator_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        text = re.sub(r"//.*", "", open(os.path.join(csrc, f)).read())
+        for bad in (r"\babort\s*\(", r"\bexit\s*\(", r"\b_exit\s*\(", r"\bassert\s*\(", r"std::terminate"):
+            assert not re.search(bad, text), f"{f} can end the calling process: {bad}"
 
 
 def test_blob_length_matches_reference_parameter_counts():
