@@ -211,6 +211,7 @@ def main():
     # as Annotator.predict does: cells whose fast (MX) result lies within 1e-3 of a decision boundary (top-2 margin, the vote's confidence
     # threshold) are re-evaluated with three fp16 passes per product INSIDE the timed region
     RECHECK = [0.3]
+    recheck_counts = {}     # last timed pass: the vote pair's cells re-evaluated / left inside the noise floor (Annotator.predict's own criterion)
     stage_events = []      # per timed pass: [(stage, start event, end event)] on the current stream (the ViT's segment streams join it)
     STAGES = ("normalise", "label_table", "crop", "imputer", "vit", "all_gather", "vote", "d2h")
 
@@ -258,7 +259,26 @@ def main():
                 del panel
                 continue
             with stage("vit"):
-                probs[name] = model.predict_proba(patches, srcs[name], chunk_cells=args.chunk, streams=streams, recheck=RECHECK)
+                # the two classifiers the vote reads are re-evaluated below by the vote's own distance (ops.decision_distance, what
+                # Annotator._recheck_near_boundaries does); the others keep the per-classifier rule (top-2 margin + the confidence threshold)
+                pair_member = models_sel is None and name in vote_pair
+                probs[name] = model.predict_proba(patches, srcs[name], chunk_cells=args.chunk, streams=streams, recheck=None if pair_member else RECHECK)
+        if models_sel is None and vote_pair[1] is not None:
+            with stage("vit"):
+                a_, b_ = vote_pair
+                oth = {k: (CLASS_NAMES[k].index("Others") if "Others" in CLASS_NAMES[k] else None) for k in vote_pair}
+                dd = ops.decision_distance(probs[a_], oth[a_], probs[b_], oth[b_], RECHECK)
+                rows = torch.nonzero(dd < ops.VitModel.RECHECK_MARGIN).flatten()
+                uses_mx = [k for k in vote_pair if _lib.lib().ribca_mx_enabled(models[k].D)]
+                if rows.numel() and uses_mx:
+                    for k in uses_mx:
+                        src_p = patches
+                        probs[k].index_copy_(0, rows, models[k]._forward(src_p.index_select(0, rows), srcs[k] if not (imputer is not None and k == "immune_full")
+                                                                         else list(range(15)), args.chunk, 0, 1, precise=True))
+                    dd = ops.decision_distance(probs[a_], oth[a_], probs[b_], oth[b_], RECHECK)
+                if record:
+                    recheck_counts["vote_pair_cells_re_evaluated"] = int(rows.numel()) if uses_mx else 0
+                    recheck_counts["vote_pair_cells_within_noise_floor"] = int((dd < 2.0e-4).sum().item())
         if sharded and gather:         # ONE all-gather per tile: the five models' probability columns side by side (33 floats per cell)
             names = list(probs)
             widths = [probs[k].shape[1] for k in names]
@@ -349,10 +369,22 @@ def main():
     out["per_stage_ms"] = {k: round(v / max(len(stage_events), 1), 3) for k, v in per_stage.items() if v > 0.0 or k in ("normalise", "label_table", "crop", "vit", "vote", "d2h")}
     out["replicated_preprocessing_ms"] = round((per_stage["normalise"] + per_stage["label_table"]) / max(len(stage_events), 1), 3)
     out["matrix_units_per_product"] = {name: matrix_units(m.D) for name, m in models.items()}
-    out["cells_re_evaluated_at_full_precision"] = {name: m.last_recheck["cells"] for name, m in models.items() if getattr(m, "last_recheck", None)}
+    out["cells_re_evaluated_at_full_precision"] = {name: m.last_recheck["cells"] for name, m in models.items()
+                                                   if getattr(m, "last_recheck", None) and name not in vote_pair}
+    # the vote's two classifiers, by the product's criterion (ops.decision_distance < VitModel.RECHECK_MARGIN on the pair's tables: top-2
+    # margin over both tables, "Others", the confidence threshold); within_noise_floor = cells still within 2e-4 of a boundary after the
+    # re-evaluation -- the cells whose label two correct fp32 evaluations need not agree on (Annotator.NOISE_FLOOR)
+    out["cells_re_evaluated_at_full_precision"]["vote_pair (" + " + ".join(k for k in vote_pair if k) + ")"] = recheck_counts.get("vote_pair_cells_re_evaluated")
+    out["cells_undecidable"] = recheck_counts.get("vote_pair_cells_within_noise_floor")
+    out["recheck_margin"] = ops.VitModel.RECHECK_MARGIN
+    out["parity_audit"] = parity_audit_record(out["kernel_source_sha256"])
     if sharded:
         ag_ms = sum(a.elapsed_time(b) for a, b in ag_events)
         out["collective"] = collective_record(world, ag_ms, args.steps, ag_state.get("local", torch.zeros(0)))
+        if out["collective"]["world_size_seen"] != args.gpus:
+            # a line labelled n_gpus = N whose all-gather ran in a group of another size is not an N-GPU measurement: no line at all
+            print(f"bench.py: the all-gather ran in a process group of {out['collective']['world_size_seen']} ranks, --gpus says {args.gpus}", file=sys.stderr)
+            sys.exit(3)
 
     # ---- roofline of the dominant kernel (the bf16x3 GEMM family), one extra profiled pass -----------------------------
     if not args.no_roofline and rank == 0:
@@ -405,15 +437,15 @@ def main():
         # carry the fingerprint of the kernel sources they were measured on: other sources being timed here -> null, not stale numbers
         traffic, traffic_src, busy, lds, pass_bytes = None, None, None, None, None
         sha = out["kernel_source_sha256"]
-        tpath = os.path.join(ROOT, "profiles", "r4", "gemm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", PROFILE_ROUND, "gemm_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj.get("kernel_source_sha256") == sha:
                 traffic = round(tj["traffic_bytes_per_launch"])
-                traffic_src = "profiles/r4/gemm_traffic.json"
+                traffic_src = f"profiles/{PROFILE_ROUND}/gemm_traffic.json"
                 if tj.get("vit_bytes_per_cell"):
                     pass_bytes = tj["vit_bytes_per_cell"] * n_local
-        spath = os.path.join(ROOT, "profiles", "r4", "sq_summary.json")
+        spath = os.path.join(ROOT, "profiles", PROFILE_ROUND, "sq_summary.json")
         if os.path.exists(spath):
             sq = json.load(open(spath))
             if sq.get("kernel_source_sha256") == sha:
@@ -452,6 +484,12 @@ def main():
                            "achieved": round(achieved, 2),
                            "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 5),
                            "traffic": traffic, "traffic_unit": f"bytes/launch (2*FETCH_SIZE + WRITE_SIZE, {traffic_src})",
+                           # provenance of the counter-derived fields (traffic, mfma_busy_frac, lds_active_frac, hbm_*_pass): rocprofv3 --pmc passes
+                           # cannot run inside this process, so they are READ from the committed profile of the same kernel sources (sha-matched:
+                           # other sources -> null); achieved / frac / avg_launch_ms / per_kernel_ms are measured live by this run's own events
+                           "counter_fields_source": (f"committed profile (profiles/{PROFILE_ROUND}/, kernel_source_sha256 matches)" if traffic is not None or busy is not None
+                                                     else "none: no committed counter passes for these kernel sources"),
+                           "timing_fields_source": "measured in this run (HIP events on the launch stream)",
                            "algorithmic_bytes_per_launch": round(alg_bytes / max(g_n, 1)),
                            # not the peak the fraction is priced against: what register-resident MFMA loops sustain on this chip under its
                            # power management (tools/mfma_sustain_probe.hip, profiles/r3/mfma_sustain_probe.txt: 1.88 PF at 1.89 GHz)
@@ -459,7 +497,7 @@ def main():
                            "frac_of_sustained_cap": round(achieved / (sustained / mu_all), 4) if sustained else None,
                            "mfma_busy_frac": busy, "lds_active_frac": lds,
                            "counters": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), SQ_LDS_IDX_ACTIVE / (256 CUs x ...): "
-                                       "profiles/r4/sq_summary.json; null = the committed counters belong to another build of the library",
+                                       f"profiles/{PROFILE_ROUND}/sq_summary.json; null = the committed counters belong to another build of the library",
                            "launches": int(g_n), "avg_launch_ms": round(g_ms / max(g_n, 1), 5),
                            "algorithmic_gflop_per_launch": round(gemm_flops / max(g_n, 1) / 1e9, 4),
                            "matrix_units_per_product": round(mu_all, 4),      # FLOP-weighted over the classifiers (per shape: top-level matrix_units_per_product)
@@ -535,6 +573,24 @@ def avg_units(dims, depths):
         num += blocks * d * d * sum(w[k] * u[k] for k in w)
         den += blocks * d * d * sum(w.values())
     return num / den
+
+
+PROFILE_ROUND = "r5"      # the directory under profiles/ whose counter passes the line may quote (sha-matched)
+
+
+def parity_audit_record(sha):
+    """label flips / undecidable cells of the committed config-3 parity audit (tests/test_gpu_e2e.py::test_config3_parity_audit_2000_cells
+    writes it on the GPU box) -- quoted only when it was taken on these kernel sources"""
+    path = os.path.join(ROOT, "profiles", PROFILE_ROUND, "parity_audit_config3.json")
+    try:
+        j = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if j.get("kernel_source_sha256") != sha:
+        return {"source": f"profiles/{PROFILE_ROUND}/parity_audit_config3.json belongs to other kernel sources", "label_flips_in_audit": None}
+    return {"source": f"committed profile (profiles/{PROFILE_ROUND}/parity_audit_config3.json, kernel_source_sha256 matches)",
+            "cells_audited_per_model": j.get("cells_per_model"), "label_flips_in_audit": j.get("label_flips_total"),
+            "flips_outside_twice_the_error_band": j.get("flips_outside_band_total"), "max_abs_dp": j.get("max_abs_dp")}
 
 
 def sustained_probe_tflops():

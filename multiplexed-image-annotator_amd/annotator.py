@@ -62,11 +62,22 @@ def _load_state_dict(path: str) -> Dict[str, torch.Tensor]:
     """``{"model": state_dict}`` checkpoint as the reference stores it (model.py:189-231, markerImputer.py:260-271).
 
     The reference unpickles with ``weights_only=False``; a state dict is plain tensors, so the drop-in uses the loader that executes
-    nothing from the file and says so when a checkpoint holds anything else.
+    nothing from the file.  MAE-style training scripts (the lineage of the reference's checkpoints) save an ``args`` Namespace, an epoch
+    number and optimizer / scaler state beside ``"model"``: ``argparse.Namespace`` is allow-listed for this one load -- rebuilding it
+    runs no code from the file (its state is a dict the restricted unpickler has already vetted) -- so such a checkpoint loads as it does
+    in the reference.  Anything else the restricted loader refuses is reported with the file name and the remedy; I/O errors (missing
+    file, permissions, truncated archive) propagate as what they are.
     """
+    import argparse
+    import pickle
     try:
-        ckpt = torch.load(path, map_location="cpu", weights_only=True)
-    except Exception as e:  # pickle.UnpicklingError and friends: name the file and the remedy
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    except OSError:
+        raise
+    except (pickle.UnpicklingError, RuntimeError) as e:      # a global outside the allow-list: pickle.UnpicklingError (torch >= 2.4) / RuntimeError
+        if isinstance(e, RuntimeError) and "weights_only" not in str(e).lower() and "unpickl" not in str(e).lower() and "global" not in str(e).lower():
+            raise      # a truncated or corrupt archive, not a refused global: torch's own message says what is wrong
         raise RuntimeError(
             "{}: not a plain tensor checkpoint (torch.load(weights_only=True) refused it: {}). Re-save it as "
             "torch.save({{'model': model.state_dict()}}, path).".format(path, e)) from e
@@ -254,9 +265,14 @@ class Annotator(object):
         if uses_mx:
             rows = torch.nonzero(d < ops.VitModel.RECHECK_MARGIN).flatten()
             if rows.numel():
+                moved = 0.0
                 for k in uses_mx:
-                    tables[k].index_copy_(0, rows, self._predict_cell_types(image_idx, k, rows=rows, precise=True))
+                    again = self._predict_cell_types(image_idx, k, rows=rows, precise=True)
+                    # how far the full-precision result lies from the fast one on these cells: the quantity RECHECK_MARGIN has to dominate
+                    moved = max(moved, float((again - tables[k].index_select(0, rows)).abs().max().item()))
+                    tables[k].index_copy_(0, rows, again)
                 stats["re_evaluated"] = int(rows.numel())
+                stats["max_fast_minus_full_precision"] = moved
                 d = distance()
         stats["within_noise_floor"] = int((d < self.NOISE_FLOOR).sum().item())
         return stats
@@ -292,6 +308,9 @@ class Annotator(object):
                 msg = ("{} of {} cells lay within {:g} of a decision boundary and were re-evaluated at full operand precision; {} remain within "
                        "{:g} (inside the arithmetic's noise floor: another correct fp32 evaluation may label them differently)."
                        ).format(rs["re_evaluated"], rs["cells"], ops.VitModel.RECHECK_MARGIN, rs["within_noise_floor"], self.NOISE_FLOOR)
+                if "max_fast_minus_full_precision" in rs:
+                    msg += " Largest move of a confidence under the re-evaluation: {:.1e} (margin {:g}).".format(rs["max_fast_minus_full_precision"],
+                                                                                                                 ops.VitModel.RECHECK_MARGIN)
                 self.logger.log(msg if self.world_size == 1 else "rank {}: {}".format(self.rank, msg))
             if self.world_size > 1:
                 # ONE all-gather per image: the models' probability columns side by side (<= 33 floats per cell), SURVEY 8(e)

@@ -253,17 +253,21 @@ def _read_tiff(path: str) -> np.ndarray:
             view[pl, y0:y1, x0:x1] = chunk[:y1 - y0, :x1 - x0]
 
     layouts, seen, description = [], set(), None
+    expect, behind_one_ifd = None, None
     while off and off not in seen and off + 2 <= size:
         seen.add(off)
         tags, off = read_ifd(off)
         if description is None:
             description = tags.get(270, "") if isinstance(tags.get(270, ""), str) else ""
+            # BEFORE any page layout is looked at: a Z / T stack in a compression this reader does not decode (LZW, JPEG) must be refused
+            # as a stack (TiffStackError: no fallback), not as "unsupported" -- read_image() would hand that to PIL, which stacks the Z / T
+            # planes as channels
+            expect, behind_one_ifd = _stack_dims(description, path)
         if one(tags, 254, 0) & 1:                    # reduced-resolution page of a pyramid
             continue
         layouts.append(page_layout(tags))
     if not layouts:
         raise TiffUnsupported(f"{path}: no image pages")
-    expect, behind_one_ifd = _stack_dims(description or "", path)
     first = layouts[0]
     same = [L for L in layouts if L["shape"] == first["shape"] and L["dt"] == first["dt"]]
     nat = first["dt"].newbyteorder("=")
@@ -282,7 +286,8 @@ def _read_tiff(path: str) -> np.ndarray:
     if expect is not None:
         planes_found = len(same) * (first["spp"] if first["spp"] > 1 else 1)
         if planes_found != expect:
-            raise TiffUnsupported(f"{path}: the description announces {expect} channel planes, the file holds {planes_found}")
+            # (no fallback either: a multi-series OME file read page by page by another decoder would mix the series into one image)
+            raise TiffStackError(f"{path}: the description announces {expect} channel planes, the file holds {planes_found}")
     if len(same) == 1:
         out = np.zeros(first["shape"], dtype=nat)
         decode_into(first, out)

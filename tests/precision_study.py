@@ -24,6 +24,8 @@ w = weight; the attention products and every linear not named by --linears stay 
     mx150       ah.wh + al8.wh6             no W lo image at all (weights rounded to fp16)                       1 + 1/2
     mx125       ah.wh + ah6.wl6             no A lo plane at all (activations rounded to fp16: 2 bytes / element) 1 + 1/4
     mx100       ah.wh                       one fp16 pass                                                        1
+    mx150s      ah.wh + al6.wh6 + ah6.wl6   BOTH corrections kept, A lo as MX e2m3 under its own block scale (the fp8 operand is what makes
+                                            the first correction a half-rate instruction): 2.78 bytes / element       1 + 1/4 + 1/4
 """
 from __future__ import annotations
 
@@ -161,7 +163,7 @@ def mx3_lo(x, h, block=32):
     return out[..., :k] if pad else out
 
 
-MX_TERMS = {"mx175": (True, True), "mx150": (True, False), "mx125": (False, True), "mx100": (False, False)}
+MX_TERMS = {"mx175": (True, True), "mx150": (True, False), "mx125": (False, True), "mx100": (False, False), "mx150s": (True, True)}
 LINEARS = {"wqkv", "wproj", "w1", "w2"}      # --linears: which weights take an mx* scheme (the others: f16x3)
 
 
@@ -170,7 +172,7 @@ def mm_mx(a, b, scheme):
     ah, bh = r_f16(a), r_f16(b)
     aa, bb = [ah], [bh]
     if use_al:
-        aa.append(mx3_lo(a, ah))
+        aa.append(mx_e2m3(a - ah) if scheme == "mx150s" else mx3_lo(a, ah))
         bb.append(mx_e2m3(bh))
     if use_wl:
         aa.append(mx_e2m3(ah))

@@ -81,3 +81,21 @@ def test_rank0_only_passes_issue_no_collective():
     assert calls, "the roofline block no longer calls one_pass: update this test"
     assert all("gather=False" in c for c in calls), calls
     assert "if sharded and gather:" in src
+
+
+def test_a_line_whose_collective_saw_another_world_size_is_refused():
+    """bench.py itself compares the world size the all-gather's process group reports with --gpus and exits non-zero
+    instead of printing a line labelled with a GPU count the collective did not run on.  Static check of the guard (it sits behind the timed
+    region of a sharded GPU run, which this CPU suite cannot reach) + the record it reads."""
+    import importlib.util
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    i = src.index('out["collective"] = collective_record(')
+    guard = src[i:i + 700]
+    assert 'out["collective"]["world_size_seen"] != args.gpus' in guard and "sys.exit(3)" in guard
+    assert src.index("sys.exit(3)") < src.index("print(json.dumps(out))")      # the guard runs before the line is printed
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    import torch
+    rec = mod.collective_record(1, 0.0, 1, torch.zeros(0))
+    assert rec["world_size_seen"] == 1 and rec["backend"] is None

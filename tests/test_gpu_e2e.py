@@ -560,6 +560,13 @@ def test_config3_parity_audit_2000_cells():
         vm = ops.VitModel(sd, dev)
         got = vm.predict_proba(patches, list(range(c)), chunk_cells=1024, streams=3, recheck=[]).cpu()
         err = (got - ref).abs().max().item()
+        # what the margin-gated re-evaluation rests on: the fast (MX) forward and the full-precision one differ by far less than
+        # RECHECK_MARGIN, so a cell the fast path places outside the margin cannot cross a boundary at full precision
+        fast = vm._forward(patches, list(range(c)), 1024, 0, 1, precise=False)
+        full = vm._forward(patches, list(range(c)), 1024, 0, 1, precise=True)
+        fast_vs_full = (fast - full).abs().max().item()
+        assert fast_vs_full <= ops.VitModel.RECHECK_MARGIN / 4, (name, fast_vs_full)
+        del fast, full
         srt = ref.sort(dim=1, descending=True).values
         margin = (srt[:, 0] - srt[:, 1]).numpy()
         hist = np.histogram(margin, bins=edges)[0].tolist()
@@ -577,7 +584,8 @@ def test_config3_parity_audit_2000_cells():
         report[name] = {"max_abs_dp": err, "label_flips": flips, "flips_with_margin_below_2x_max_dp": undecidable,
                         "flips_where_fp64_sides_with_this_path": ref_wrong, "min_top2_margin": float(margin.min()), "margin_hist_edges": edges,
                         "margin_hist": hist, "classes_used": int(len(torch.unique(ref.argmax(1)))), "cells_with_margin_below_1e-2": int((margin < 1e-2).sum()),
-                        "cells_re_evaluated_at_full_precision": vm.last_recheck["cells"], "matrix_units_fc2": 1.75 if (4 * d) % 128 == 0 else 3.0}
+                        "cells_re_evaluated_at_full_precision": vm.last_recheck["cells"], "matrix_units_fc2": 1.75 if (4 * d) % 128 == 0 else 3.0,
+                        "max_abs_fast_minus_full_precision": fast_vs_full, "recheck_margin": ops.VitModel.RECHECK_MARGIN}
         print(f"[parity audit] {name}: 2000 cells, max|dp| {err:.2e}, flips {flips} (undecidable {undecidable}, fp64 sides with this path on "
               f"{ref_wrong}), top-2 margin min {margin.min():.2e} hist {hist}")
         # identical labels wherever the reference's own margin exceeds twice the measured confidence error; a handful of ties within
@@ -587,6 +595,13 @@ def test_config3_parity_audit_2000_cells():
         assert int((margin < 1e-2).sum()) >= 20, (name, int((margin < 1e-2).sum()))                  # close calls exist on every model
         assert err < 1e-3, (name, err)          # north star
         assert err < E2E_TOL, (name, err)       # fp32 summation-order floor of real patches (E2E_TOL)
+    from multiplexed_image_annotator_amd import build as _build
+    names = list(synth.VIT_CONFIGS)
+    report["kernel_source_sha256"] = _build.source_fingerprint()      # bench.py quotes the flip count only for the sources it was taken on
+    report["cells_per_model"] = len(sel)
+    report["label_flips_total"] = sum(report[k]["label_flips"] for k in names)
+    report["flips_outside_band_total"] = sum(report[k]["label_flips"] - report[k]["flips_with_margin_below_2x_max_dp"] for k in names)
+    report["max_abs_dp"] = max(report[k]["max_abs_dp"] for k in names)
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out_dir):
         json.dump(report, open(os.path.join(out_dir, "parity_audit_config3.json"), "w"), indent=1)

@@ -228,7 +228,7 @@ def test_unsupported_attention_geometry_is_a_status(dev):
 def test_mx_launchers_refuse_shapes_without_a_tile_form(dev):
     """N % 192 != 0 on the MX forms of qkv / fc1 / the MX3 copy: status + message (round 4: fprintf + abort())"""
     from multiplexed_image_annotator_amd._lib import lib, ptr, stream_ptr
-    m, d = 64, 240      # 3 d = 720, 4 d = 960: multiples of 48 (the MX kernel's wave block), not of 192
+    m, d = 64, 132      # 4 d = 528 = 11 x 48: a multiple of the MX kernel's wave block, not of its 192-column tile
     n = 4 * d
     z_ps, _, g, b, dp = _ln_case(m, d, 50, dev)
     w = rnd((n, d), 53, dev, 0.1)

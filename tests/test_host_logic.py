@@ -101,6 +101,22 @@ def test_checkpoint_loader_executes_nothing_from_the_file(tmp_path):
     torch.save({"state": sd}, str(nokey))
     with pytest.raises(RuntimeError, match="'model'"):
         _load_state_dict(str(nokey))
+    # an MAE-style training checkpoint: args Namespace, epoch, optimizer state beside "model" (what the reference's torch.load of
+    # model.py:189-231 accepts) loads through the allow-list, still without executing anything from the file
+    import argparse
+    mae = tmp_path / "mae_style.pth"
+    torch.save({"model": sd, "args": argparse.Namespace(lr=1e-3, model="vit", blr=[1, 2]), "epoch": 7,
+                "optimizer": {"state": {0: {"exp_avg": torch.zeros(2)}}, "param_groups": [{"lr": 1e-3, "params": [0]}]}}, str(mae))
+    got = _load_state_dict(str(mae))
+    assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    # I/O errors are not "re-save your checkpoint" errors
+    with pytest.raises(FileNotFoundError):
+        _load_state_dict(str(tmp_path / "missing.pth"))
+    trunc = tmp_path / "truncated.pth"
+    trunc.write_bytes(good.read_bytes()[:100])
+    with pytest.raises(Exception) as ei:
+        _load_state_dict(str(trunc))
+    assert "Re-save it" not in str(ei.value)
 
 
 def test_decision_distance_covers_every_comparison_of_the_vote():

@@ -213,8 +213,42 @@ def test_ome_channel_count_must_match_the_pages(tmp_path):
     np.testing.assert_array_equal(pp.read_tiff(ok), np.stack(planes))
     bad = str(tmp_path / "c5.ome.tif")
     write_tiff(bad, planes, descriptions=[_ome(5)] + [None] * 3)
-    with pytest.raises(pp.TiffUnsupported):
+    with pytest.raises(pp.TiffStackError):       # not TiffUnsupported: another decoder reading page by page would mix series into one image
         pp.read_tiff(bad)
+    with pytest.raises(ValueError):
+        pp.read_image(bad)
+
+
+def _set_compression(path, code):
+    """patch the Compression tag (259) of every IFD of a classic little-endian file written by write_tiff"""
+    raw = bytearray(open(path, "rb").read())
+    ifd = struct.unpack("<I", raw[4:8])[0]
+    while ifd:
+        n = struct.unpack("<H", raw[ifd:ifd + 2])[0]
+        for i in range(n):
+            e = ifd + 2 + 12 * i
+            if struct.unpack("<H", raw[e:e + 2])[0] == 259:
+                raw[e + 8:e + 10] = struct.pack("<H", code)
+        ifd = struct.unpack("<I", raw[ifd + 2 + 12 * n:ifd + 6 + 12 * n])[0]
+    open(path, "wb").write(bytes(raw))
+
+
+def test_z_stack_in_an_undecoded_compression_is_still_a_stack(tmp_path):
+    """the Z / T check ran only after every page's layout had been accepted, so an LZW- or JPEG-compressed OME Z stack raised
+    TiffUnsupported and read_image() handed it to PIL, which stacks the Z planes as channels"""
+    planes = [_rand((20, 24), np.uint16, 140 + i) for i in range(3)]
+    path = str(tmp_path / "z_lzw.ome.tif")
+    write_tiff(path, planes, descriptions=[_ome(1, z=3)] + [None] * 2)
+    _set_compression(path, 5)                     # LZW: this reader does not decode it
+    with pytest.raises(pp.TiffStackError):
+        pp.read_tiff(path)
+    with pytest.raises(ValueError):
+        pp.read_image(path)
+    plain = str(tmp_path / "c3_lzw.ome.tif")      # the same compression on a plain (C, H, W) file is merely unsupported (fallback allowed)
+    write_tiff(plain, planes, descriptions=[_ome(3)] + [None] * 2)
+    _set_compression(plain, 5)
+    with pytest.raises(pp.TiffUnsupported):
+        pp.read_tiff(plain)
 
 
 def test_imagej_stack_behind_one_ifd(tmp_path):
