@@ -253,7 +253,7 @@ def main():
                 # reference preprocess.py:268-281: the panel tensor with its missing plane imputed feeds that panel's classifier
                 with stage("imputer"):
                     panel = patches[:, :15].contiguous()
-                    imputer.impute(panel, imp_present, chunk_cells=args.chunk)
+                    imputer.impute(panel, imp_present, chunk_cells=ops.MaeModel.CHUNK_FACTOR * args.chunk)
                 with stage("vit"):
                     probs[name] = model.predict_proba(panel, list(range(15)), chunk_cells=args.chunk, streams=streams, recheck=RECHECK)
                 del panel

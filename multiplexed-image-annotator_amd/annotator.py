@@ -238,7 +238,7 @@ class Annotator(object):
             sel = torch.tensor([max(c, 0) for c in src], dtype=torch.long, device=patches.device)
             panel = patches.index_select(1, sel).contiguous()           # channel gather (layout only); blanks are overwritten below
             present = [i for i, c in enumerate(index) if c != -1]
-            imputer.impute(panel, present, chunk_cells=self.chunk_cells)
+            imputer.impute(panel, present, chunk_cells=ops.MaeModel.CHUNK_FACTOR * self.chunk_cells)
             patches, src = panel, list(range(len(index)))
         if precise:
             return model._forward(patches, src, chunk_cells=self.chunk_cells, streams=1, precise=True)

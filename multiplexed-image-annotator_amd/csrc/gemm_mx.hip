@@ -355,8 +355,13 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
     return;
 #endif
     char* st = smem + L_L8 + (b & 1) * 16384 + wave * 1024;
+#ifdef MXDBG_LO4      // timing variant: half the lo bytes (what an fp4 image of A lo would move)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#else
 #pragma unroll
     for (int i = 0; i < 4; ++i)
+#endif
       __builtin_amdgcn_raw_ptr_buffer_load_lds(l8_rsrc, (__attribute__((address_space(3))) void*)(st + i * 4096), 16, l8_voff, i * 32 * Kp + b * 128, 0, 0);
     // 64 rows per wave from row 32 w: the upper half repeats what the next wave writes (the same bytes) and the last wave's spills into the slot's pad
     __builtin_amdgcn_raw_ptr_buffer_load_lds(sc_rsrc, (__attribute__((address_space(3))) void*)(smem + L_SC + (b & 1) * L_SC_SLOT + wave * 128), 4, sc_voff,
@@ -566,23 +571,32 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
       u32v4 la[2], lb[2], ha[2];
       u32v2 hb[2];
       unsigned sb[2];
-      lds_rd128<0>(la[0], m_l8a); lds_rd128<0>(lb[0], m_l8b); lds_rd128<0>(ha[0], rd_h6a); lds_rd64<0>(hb[0], rd_h6b); lds_rd8<0>(sb[0], m_sc);
+#ifdef MXDBG_LO4
+#define MX_LB_READ(dst, off, addr) dst = la[0]
+#define MX_LGKM_PER_TILE 4
+#define MX_LO_FMT 2
+#else
+#define MX_LB_READ(dst, off, addr) lds_rd128<off>(dst, addr)
+#define MX_LGKM_PER_TILE 5
+#define MX_LO_FMT 0
+#endif
+      lds_rd128<0>(la[0], m_l8a); MX_LB_READ(lb[0], 0, m_l8b); lds_rd128<0>(ha[0], rd_h6a); lds_rd64<0>(hb[0], rd_h6b); lds_rd8<0>(sb[0], m_sc);
       sfor<MT>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int cur = i & 1, nxt = cur ^ 1;
         if constexpr (i + 1 < MT) {
-          lds_rd128<(i + 1) * 2048>(la[nxt], m_l8a); lds_rd128<(i + 1) * 2048>(lb[nxt], m_l8b);
+          lds_rd128<(i + 1) * 2048>(la[nxt], m_l8a); MX_LB_READ(lb[nxt], (i + 1) * 2048, m_l8b);
           lds_rd128<(i + 1) * 1024>(ha[nxt], rd_h6a); lds_rd64<(i + 1) * 512>(hb[nxt], rd_h6b); lds_rd8<(i + 1) * 64>(sb[nxt], m_sc);
-          asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(la[cur]), "+v"(lb[cur]), "+v"(ha[cur]), "+v"(hb[cur]), "+v"(sb[cur])::"memory");
+          asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(la[cur]), "+v"(lb[cur]), "+v"(ha[cur]), "+v"(hb[cur]), "+v"(sb[cur]) : "n"(MX_LGKM_PER_TILE) : "memory");
         } else {
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(la[cur]), "+v"(lb[cur]), "+v"(ha[cur]), "+v"(hb[cur]), "+v"(sb[cur])::"memory");
         }
         const i32x8 al8 = op8(la[cur], lb[cur]), ah6 = op6(ha[cur], hb[cur]);
         const int asc = (int)(sb[cur] | ((sb[cur] + kMxShDelta) << 8));      // byte 0: lo scale, byte 1: fp6-hi scale
         // W hi' (fp6, its sh byte) x A lo (fp8, byte 0);  W lo' (fp6, its sl byte) x A hi' (fp6, byte 1)
-        acc[0][i][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wh6[0], al8, acc[0][i][0], 2, 0, 1, (int)wsh[0], 0, asc);
-        acc[0][i][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wh6[1], al8, acc[0][i][1], 2, 0, 3, (int)wsh[0], 0, asc);
-        acc[0][i][2] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wh6[2], al8, acc[0][i][2], 2, 0, 1, (int)wsh[1], 0, asc);
+        acc[0][i][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wh6[0], al8, acc[0][i][0], 2, MX_LO_FMT, 1, (int)wsh[0], 0, asc);
+        acc[0][i][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wh6[1], al8, acc[0][i][1], 2, MX_LO_FMT, 3, (int)wsh[0], 0, asc);
+        acc[0][i][2] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wh6[2], al8, acc[0][i][2], 2, MX_LO_FMT, 1, (int)wsh[1], 0, asc);
         acc[0][i][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wl6[0], ah6, acc[0][i][0], 2, 2, 0, (int)wsc[0], 1, asc);
         acc[0][i][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wl6[1], ah6, acc[0][i][1], 2, 2, 2, (int)wsc[0], 1, asc);
         acc[0][i][2] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wl6[2], ah6, acc[0][i][2], 2, 2, 0, (int)wsc[1], 1, asc);

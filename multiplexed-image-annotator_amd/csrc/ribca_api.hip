@@ -145,6 +145,9 @@ struct ribca_vit {
 // marker imputer (reference markerImputer.py:69-329): encoder 768 / 12 heads, decoder 512 / 8 heads, tokens = channels
 struct ribca_mae {
   int L, enc_depth, dec_depth;
+  // round 5: the blocks run on the classifiers' folded path (LayerNorm folded into qkv / fc1, packed-split residual stream, residual tile
+  // through the operand ring; the 768-wide encoder on the MX kernel as well).  RIBCA_MAE_FOLD=0 at create: the round-2 path (A/B)
+  bool fold = true;
   char* arena = nullptr;
   size_t arena_bytes = 0;
   const float *cls, *pos, *pe_b, *norm_w, *norm_b, *de_b, *mask_tok, *dpos, *dnorm_w, *dnorm_b, *pred_b;
@@ -217,14 +220,14 @@ size_t layout_mae(ribca_mae* m, char* base) {
   m->pe_w = c.take<uint16_t>((size_t)gemm_padded_n(kEncD) * 2 * kTokPix);
   m->pe_b = c.take<float>(kEncD);
   m->enc.resize(m->enc_depth);
-  for (auto& L : m->enc) layout_block(c, L, kEncD);
+  for (auto& L : m->enc) layout_block(c, L, kEncD, m->fold);
   m->norm_w = c.take<float>(kEncD); m->norm_b = c.take<float>(kEncD);
   m->de_w = c.take<uint16_t>((size_t)gemm_padded_n(kDecD) * 2 * kEncD);
   m->de_b = c.take<float>(kDecD);
   m->mask_tok = c.take<float>(kDecD);
   m->dpos = c.take<float>((size_t)(m->L + 1) * kDecD);
   m->dec.resize(m->dec_depth);
-  for (auto& L : m->dec) layout_block(c, L, kDecD);
+  for (auto& L : m->dec) layout_block(c, L, kDecD, m->fold);
   m->dnorm_w = c.take<float>(kDecD); m->dnorm_b = c.take<float>(kDecD);
   m->pred_w = c.take<uint16_t>((size_t)gemm_padded_n(kTokPix) * 2 * kDecD);
   m->pred_b = c.take<float>(kTokPix);
@@ -668,6 +671,7 @@ int ribca_mae_create(const float* blob, int64_t blob_len, int32_t L, int32_t enc
   hipStream_t s = (hipStream_t)stream;
   ribca_mae* m = new ribca_mae();
   m->L = L; m->enc_depth = enc_depth; m->dec_depth = dec_depth;
+  m->fold = !(getenv("RIBCA_MAE_FOLD") && atoi(getenv("RIBCA_MAE_FOLD")) == 0);
   m->arena_bytes = layout_mae(m, nullptr);
   hipError_t e = hipMalloc((void**)&m->arena, m->arena_bytes);
   if (e != hipSuccess) { delete m; return hip_fail(e, "hipMalloc(imputer weights)"); }
@@ -677,13 +681,13 @@ int ribca_mae_create(const float* blob, int64_t blob_len, int32_t L, int32_t enc
   r.copy(m->pos, (size_t)(L + 1) * kEncD);
   r.pack(m->pe_w, kEncD, kTokPix, kTokPix);
   r.copy(m->pe_b, kEncD);
-  for (auto& B : m->enc) r.block(B, kEncD);
+  for (auto& B : m->enc) r.block(B, kEncD, m->fold);
   r.copy(m->norm_w, kEncD); r.copy(m->norm_b, kEncD);
   r.pack(m->de_w, kDecD, kEncD, kEncD);
   r.copy(m->de_b, kDecD);
   r.copy(m->mask_tok, kDecD);
   r.copy(m->dpos, (size_t)(L + 1) * kDecD);
-  for (auto& B : m->dec) r.block(B, kDecD);
+  for (auto& B : m->dec) r.block(B, kDecD, m->fold);
   r.copy(m->dnorm_w, kDecD); r.copy(m->dnorm_b, kDecD);
   r.pack(m->pred_w, kTokPix, kDecD, kDecD);
   r.copy(m->pred_b, kTokPix);
@@ -704,16 +708,24 @@ namespace {
 struct MaeWs {
   BlockWs enc, dec;
   uint16_t* tok_ps;     // present channel tiles as packed-split rows [cells*P][2*1600]; reused for decoder_norm rows [cells*Mi][2*512]
-  int* tables;          // device int tables (6 x 16)
+  int* tables;          // device int tables (kMaeTables x 16)
+  // folded path: the token rows are assembled in fp32 (embedding GEMM through its row map, cls / mask rows, positional embeddings) and then
+  // split once into the packed-split residual stream the blocks run on
+  float *enc_zf = nullptr, *dec_zf = nullptr;
   size_t total;
 };
+constexpr int kMaeTables = 7;
 MaeWs carve_mae(const ribca_mae* m, int chunk, int P, char* base) {
   Carver c(base);
   MaeWs w;
-  w.enc = carve_blocks(c, chunk, make_attn_geom(kEncD, kEncH, P + 1));
-  w.dec = carve_blocks(c, chunk, make_attn_geom(kDecD, kDecH, m->L + 1));
+  w.enc = carve_blocks(c, chunk, make_attn_geom(kEncD, kEncH, P + 1), m->fold);
+  w.dec = carve_blocks(c, chunk, make_attn_geom(kDecD, kDecH, m->L + 1), m->fold);
+  if (m->fold) {
+    w.enc_zf = c.take<float>((size_t)chunk * (P + 1) * kEncD);
+    w.dec_zf = c.take<float>((size_t)chunk * (m->L + 1) * kDecD);
+  }
   w.tok_ps = c.take<uint16_t>((size_t)chunk * m->L * 2 * kTokPix);
-  w.tables = c.take<int>(6 * 16);
+  w.tables = c.take<int>(kMaeTables * 16);
   w.total = c.off;
   return w;
 }
@@ -735,8 +747,9 @@ int ribca_mae_impute(const ribca_mae_t* m, float* patches, const int32_t* presen
   if (((uintptr_t)workspace & 255) != 0) return fail("ribca_mae_impute: workspace must be 256-byte aligned");
   // host tables: [0] present, [1] missing, [2] enc slot (1+j), [3] enc pos row (1+present[j]), [4] dec slot/pos (0, 1+present[..]),
   // [5] dec mask rows (1+missing[j])
-  int tab[6][16] = {};
+  int tab[kMaeTables][16] = {};      // [6]: identity (every token row of a cell, in order)
   bool seen[16] = {};
+  for (int j = 0; j < 16; ++j) tab[6][j] = j;
   for (int j = 0; j < P; ++j) {
     const int c = present_host[j];
     if (c < 0 || c >= L || seen[c] || (j > 0 && c <= present_host[j - 1])) return fail("ribca_mae_impute: present must be strictly increasing in [0, L)");
@@ -751,30 +764,58 @@ int ribca_mae_impute(const ribca_mae_t* m, float* patches, const int32_t* presen
   HIP_TRY(hipMemcpyAsync(w.tables, tab, sizeof(tab), hipMemcpyHostToDevice, s));
   HIP_TRY(hipStreamSynchronize(s));   // `tab` lives on this stack frame
   const int *t_present = w.tables, *t_missing = w.tables + 16, *t_eslot = w.tables + 32, *t_epos = w.tables + 48, *t_dslot = w.tables + 64,
-            *t_dmask = w.tables + 80;
+            *t_dmask = w.tables + 80, *t_all = w.tables + 96;
   const AttnGeom ge = make_attn_geom(kEncD, kEncH, P + 1), gd = make_attn_geom(kDecD, kDecH, L + 1);
   if (zero_pads(w.enc, s) || zero_pads(w.dec, s)) return 1;
+  const bool fold = m->fold;
+  // fp32 token rows -> the packed-split residual stream of a run of folded blocks + the statistics its first LayerNorm reads (+ the MX3
+  // copy where that width's qkv runs on the MX kernel): what vit_forward_impl does behind the patch embedding
+  auto enter_fold = [&](const float* zf, const BlockWs& bw, int cells, const AttnGeom& a, size_t depth) {
+    const int D = a.D, ld = 2 * round_up(D, 32), Mc = cells * a.T;
+    launch_rows_to_ps(zf, D, bw.zps, ld, round_up(D, 32), cells, a.T, a.T, t_all, s);
+    launch_row_stats_ps(bw.zps, ld, Mc, D, bw.rs, true, s);
+    if (bw.zmx.hi != nullptr && !cell_attn_on(a) && depth > 0) {
+      MxAct zmx = bw.zmx;
+      zmx.M = Mc;
+      launch_mx_pack_act(bw.zps, ld, Mc, round_up(D, 32), zmx, s);
+    }
+  };
   for (int c0 = 0; c0 < n_cells; c0 += chunk_cells) {
     const int bc = n_cells - c0 < chunk_cells ? n_cells - c0 : chunk_cells;
     float* pch = patches + (size_t)c0 * L * kTokPix;
+    float* ez = fold ? w.enc_zf : w.enc.z;
+    float* dz = fold ? w.dec_zf : w.dec.z;
     // encoder input: embed the present channel tiles (markerImputer.py:186-199)
     launch_rows_to_ps(pch, kTokPix, w.tok_ps, 2 * kTokPix, kTokPix, bc, L, P, t_present, s);
     {
       GemmArgs g{w.tok_ps, 2 * kTokPix, m->pe_w, 2 * kTokPix, bc * P, kEncD, kTokPix, m->pe_b};
-      launch_gemm_rowmap(g, w.enc.z, kEncD, m->pos, kEncD, t_eslot, t_epos, P, P + 1, s);
+      launch_gemm_rowmap(g, ez, kEncD, m->pos, kEncD, t_eslot, t_epos, P, P + 1, s);
     }
-    launch_cls_rows(w.enc.z, kEncD, m->cls, m->pos, kEncD, bc, P + 1, s);
-    for (const auto& B : m->enc) run_block(B, w.enc, bc, ge, s);
-    // decoder input (markerImputer.py:208-219): project latents, mask tokens at the missing positions, + decoder pos
-    launch_layernorm_ps(w.enc.z, kEncD, m->norm_w, m->norm_b, w.enc.xa, 2 * kEncD, bc * (P + 1), kEncD, s);
+    launch_cls_rows(ez, kEncD, m->cls, m->pos, kEncD, bc, P + 1, s);
+    if (fold) {
+      enter_fold(ez, w.enc, bc, ge, m->enc.size());
+      for (size_t li = 0; li < m->enc.size(); ++li) run_block_fold(m->enc[li], w.enc, bc, ge, s, false, li + 1 < m->enc.size());
+      // decoder input (markerImputer.py:208-219): final encoder norm (its own statistics from the packed-split rows), project latents
+      launch_layernorm_gather_ps_from_ps(w.enc.zps, 2 * kEncD, m->norm_w, m->norm_b, w.enc.xa, 2 * kEncD, bc, P + 1, P + 1, t_all, kEncD, s);
+    } else {
+      for (const auto& B : m->enc) run_block(B, w.enc, bc, ge, s);
+      launch_layernorm_ps(w.enc.z, kEncD, m->norm_w, m->norm_b, w.enc.xa, 2 * kEncD, bc * (P + 1), kEncD, s);
+    }
     {
       GemmArgs g{w.enc.xa, 2 * kEncD, m->de_w, 2 * kEncD, bc * (P + 1), kDecD, kEncD, m->de_b};
-      launch_gemm_rowmap(g, w.dec.z, kDecD, m->dpos, kDecD, t_dslot, t_dslot, P + 1, L + 1, s);
+      launch_gemm_rowmap(g, dz, kDecD, m->dpos, kDecD, t_dslot, t_dslot, P + 1, L + 1, s);
     }
-    launch_fill_rows(w.dec.z, kDecD, m->mask_tok, m->dpos, kDecD, bc, L + 1, Mi, t_dmask, s);
-    for (const auto& B : m->dec) run_block(B, w.dec, bc, gd, s);
+    // mask tokens at the missing positions, + decoder pos
+    launch_fill_rows(dz, kDecD, m->mask_tok, m->dpos, kDecD, bc, L + 1, Mi, t_dmask, s);
     // predict only the missing channels and write them into the patch tensor (blend, markerImputer.py:312-326)
-    launch_layernorm_gather_ps(w.dec.z, kDecD, m->dnorm_w, m->dnorm_b, w.tok_ps, 2 * kDecD, bc, L + 1, Mi, t_dmask, kDecD, s);
+    if (fold) {
+      enter_fold(dz, w.dec, bc, gd, m->dec.size());
+      for (size_t li = 0; li < m->dec.size(); ++li) run_block_fold(m->dec[li], w.dec, bc, gd, s, false, li + 1 < m->dec.size());
+      launch_layernorm_gather_ps_from_ps(w.dec.zps, 2 * kDecD, m->dnorm_w, m->dnorm_b, w.tok_ps, 2 * kDecD, bc, L + 1, Mi, t_dmask, kDecD, s);
+    } else {
+      for (const auto& B : m->dec) run_block(B, w.dec, bc, gd, s);
+      launch_layernorm_gather_ps(w.dec.z, kDecD, m->dnorm_w, m->dnorm_b, w.tok_ps, 2 * kDecD, bc, L + 1, Mi, t_dmask, kDecD, s);
+    }
     {
       GemmArgs g{w.tok_ps, 2 * kDecD, m->pred_w, 2 * kDecD, bc * Mi, kTokPix, kDecD, m->pred_b};
       launch_gemm_rowmap(g, pch, kTokPix, nullptr, 0, t_missing, t_missing, Mi, L, s);

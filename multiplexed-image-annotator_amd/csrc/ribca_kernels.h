@@ -116,6 +116,9 @@ void launch_cls_rows(float* z, int ldz, const float* cls, const float* pos, int 
 // out_ps row (cell*S + j) = LayerNorm(z row (cell*T + sel[j])): the rows a following GEMM actually needs
 void launch_layernorm_gather_ps(const float* z, int ldz, const float* gamma, const float* beta, uint16_t* out, int ldo, int cells, int T,
                                 int S, const int* sel, int D, hipStream_t s);
+// the same from a packed-split residual stream (the imputer's folded blocks): z_ps rows [cells*T][ldz] of 16-bit elements, D <= 768
+void launch_layernorm_gather_ps_from_ps(const uint16_t* z_ps, int ldz, const float* gamma, const float* beta, uint16_t* out, int ldo, int cells,
+                                        int T, int S, const int* sel, int D, hipStream_t s);
 // out_ps row (cell*S + j) = split(src fp32 row (cell*T + sel[j])) of K values, zero padded to Kp
 void launch_rows_to_ps(const float* src, int K, uint16_t* out, int ldo, int Kp, int cells, int T, int S, const int* sel, hipStream_t s);
 // z row (cell*T + sel[j]) = a[:] + table[sel[j]][:]   (mask tokens + positional embedding)

@@ -275,7 +275,11 @@ void launch_cls_rows(float* z, int ldz, const float* cls, const float* pos, int 
 }
 
 // LayerNorm of selected rows: out_ps row (cell*S + j) = LN(z row (cell*T + sel[j])).  Same arithmetic as layernorm_ps_kernel.
-__global__ __launch_bounds__(256) void layernorm_gather_ps_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ gamma,
+// PS_IN: z is a packed-split residual stream (fp16 hi + lo, ldz in 16-bit elements: the imputer's blocks on the folded path, round 5) --
+// a row is decoded as hi + lo in fp32 (exact) and normalised with its own statistics, whatever constant the re-centring of the residual
+// epilogues has taken off it (LayerNorm is shift-invariant)
+template <bool PS_IN>
+__global__ __launch_bounds__(256) void layernorm_gather_ps_kernel(const void* __restrict__ zv, int ldz, const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, uint16_t* __restrict__ out, int ldo,
                                                                   int rows_out, int T, int S, const int* __restrict__ sel, int D) {
   const int lane = threadIdx.x & 63;
@@ -283,13 +287,23 @@ __global__ __launch_bounds__(256) void layernorm_gather_ps_kernel(const float* _
   if (ro >= rows_out) return;
   const int cell = ro / S, j = ro - cell * S;
   const int nv = D >> 2;
-  const float4* zr = reinterpret_cast<const float4*>(z + ((size_t)cell * T + sel[j]) * ldz);
+  const size_t row_in = (size_t)cell * T + sel[j];
   float4 x[3];
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int v = lane + 64 * i;
-    x[i] = v < nv ? zr[v] : float4{0.f, 0.f, 0.f, 0.f};
+    x[i] = float4{0.f, 0.f, 0.f, 0.f};
+    if (v < nv) {
+      if constexpr (PS_IN) {
+        const uint16_t* zr = static_cast<const uint16_t*>(zv) + row_in * ldz + ps_off(4 * v);
+        const uint2 h = *reinterpret_cast<const uint2*>(zr), l = *reinterpret_cast<const uint2*>(zr + 8);
+        const f32x2 h0 = unpack_f16(h.x), h1 = unpack_f16(h.y), l0 = unpack_f16(l.x), l1 = unpack_f16(l.y);
+        x[i] = float4{h0[0] + l0[0], h0[1] + l0[1], h1[0] + l1[0], h1[1] + l1[1]};
+      } else {
+        x[i] = reinterpret_cast<const float4*>(static_cast<const float*>(zv) + row_in * ldz)[v];
+      }
+    }
     sum += (x[i].x + x[i].y) + (x[i].z + x[i].w);
   }
   const float mean = wave_sum(sum) / (float)D;
@@ -320,7 +334,14 @@ void launch_layernorm_gather_ps(const float* z, int ldz, const float* gamma, con
                                 int S, const int* sel, int D, hipStream_t s) {
   const int rows = cells * S;
   if (rows <= 0) return;
-  hipLaunchKernelGGL(layernorm_gather_ps_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, z, ldz, gamma, beta, out, ldo, rows, T, S, sel, D);
+  hipLaunchKernelGGL(layernorm_gather_ps_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, z, ldz, gamma, beta, out, ldo, rows, T, S, sel, D);
+}
+void launch_layernorm_gather_ps_from_ps(const uint16_t* z_ps, int ldz, const float* gamma, const float* beta, uint16_t* out, int ldo, int cells,
+                                        int T, int S, const int* sel, int D, hipStream_t s) {
+  const int rows = cells * S;
+  if (rows <= 0) return;
+  if (D > 768 || D % 4 != 0) { launch_error("launch_layernorm_gather_ps_from_ps: D = %d (a multiple of 4, at most 768)", D); return; }
+  hipLaunchKernelGGL(layernorm_gather_ps_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, z_ps, ldz, gamma, beta, out, ldo, rows, T, S, sel, D);
 }
 
 // out_ps row (cell*S + j) = hi/lo split of fp32 src row (cell*T + sel[j]) (K values, zero padded to Kp).  One thread per 4 values.

@@ -625,6 +625,11 @@ class MaeModel:
                 pass
             self._h = None
 
+    #: a cell is <= 16 token rows here against 101 in a classifier: callers that size chunks for the classifiers (Annotator, bench.py) hand the
+    #: imputer this many times their chunk, so that its GEMMs see a comparable row count (50 000 cells: 0.489 s at 1024, 0.464 s at 4096;
+    #: profiles/r5/ab_mae_fold.txt).  Results do not depend on the chunk size (tests/test_gpu_e2e.py::test_config5_full_size_properties).
+    CHUNK_FACTOR = 4
+
     def impute(self, patches: torch.Tensor, present: Sequence[int], chunk_cells: int = 1024) -> torch.Tensor:
         """In place: every channel of ``patches`` (n, L, 40, 40) not listed in ``present`` is replaced by its prediction."""
         assert patches.is_cuda and patches.dtype == torch.float32 and patches.is_contiguous() and tuple(patches.shape[1:]) == (self.L, PATCH, PATCH)

@@ -163,8 +163,41 @@ def mx3_lo(x, h, block=32):
     return out[..., :k] if pad else out
 
 
-MX_TERMS = {"mx175": (True, True), "mx150": (True, False), "mx125": (False, True), "mx100": (False, False), "mx150s": (True, True)}
+MX_TERMS = {"mx175": (True, True), "mx150": (True, False), "mx125": (False, True), "mx100": (False, False), "mx150s": (True, True),
+            # A lo in a 6- or 4-bit block format whose scale is DERIVED from the block's hi exponent (no second scale byte in the MX3 row):
+            "mx150h": (True, True), "mx_a4": (True, True), "mx_a4h": (True, True), "mx_a4w4": (True, True)}
 LINEARS = {"wqkv", "wproj", "w1", "w2"}      # --linears: which weights take an mx* scheme (the others: f16x3)
+
+
+def mx_block(x, block, fmt, ref=None, ref_shift=0.0):
+    """block-scaled image of x: fmt e2m3 (max 7.5, 3 mantissa bits) or e2m1 (fp4: 0 .5 1 1.5 2 3 4 6); scale 2^(floor(log2 max|x|) - 2), or --
+    ref given -- 2^(floor(log2 max|ref|) + ref_shift): the scale a kernel can derive from the block's hi exponent without a byte of its own"""
+    k = x.shape[-1]
+    pad = (-k) % block
+    xp = F.pad(x, (0, pad)) if pad else x
+    xb = xp.reshape(*xp.shape[:-1], -1, block)
+    if ref is None:
+        amax = xb.abs().amax(dim=-1, keepdim=True)
+        e = torch.floor(torch.log2(torch.where(amax > 0, amax, torch.ones_like(amax)))) - 2.0
+    else:
+        rp = F.pad(ref, (0, pad)) if pad else ref
+        amax = rp.reshape(*rp.shape[:-1], -1, block).abs().amax(dim=-1, keepdim=True)
+        e = torch.floor(torch.log2(torch.where(amax > 0, amax, torch.full_like(amax, 2.0 ** -14)))).clamp(min=-14.0) + ref_shift
+    scale = torch.exp2(e)
+    y = xb / scale
+    ay = y.abs()
+    if fmt == "e2m3":
+        ay = ay.clamp(max=7.5)
+        ex = torch.floor(torch.log2(torch.where(ay >= 1.0, ay, torch.ones_like(ay))))
+        step = torch.exp2(ex - 3.0)
+        q = (torch.round(ay / step) * step).clamp(max=7.5)
+    else:      # e2m1: subnormal step 0.5 below 1, one mantissa bit above
+        ay = ay.clamp(max=6.0)
+        ex = torch.floor(torch.log2(torch.where(ay >= 1.0, ay, torch.ones_like(ay))))
+        step = torch.exp2(ex - 1.0)
+        q = (torch.round(ay / step) * step).clamp(max=6.0)
+    out = (torch.sign(y) * q * scale).reshape(*xp.shape)
+    return out[..., :k] if pad else out
 
 
 def mm_mx(a, b, scheme):
@@ -172,11 +205,15 @@ def mm_mx(a, b, scheme):
     ah, bh = r_f16(a), r_f16(b)
     aa, bb = [ah], [bh]
     if use_al:
-        aa.append(mx_e2m3(a - ah) if scheme == "mx150s" else mx3_lo(a, ah))
+        # |lo| <= half an ulp of the block's largest hi = 2^(E - 11): scale 2^(E - 13) puts it at <= 4 (e2m3 max 7.5, e2m1 max 6)
+        al = {"mx150s": lambda: mx_e2m3(a - ah), "mx150h": lambda: mx_block(a - ah, 32, "e2m3", ah, -13.0),
+              "mx_a4": lambda: mx_block(a - ah, 32, "e2m1"), "mx_a4h": lambda: mx_block(a - ah, 32, "e2m1", ah, -13.0),
+              "mx_a4w4": lambda: mx_block(a - ah, 32, "e2m1", ah, -13.0)}.get(scheme, lambda: mx3_lo(a, ah))()
+        aa.append(al)
         bb.append(mx_e2m3(bh))
     if use_wl:
         aa.append(mx_e2m3(ah))
-        bb.append(mx_e2m3(r_f16(b - bh)))
+        bb.append(mx_block(r_f16(b - bh), 32, "e2m1") if scheme == "mx_a4w4" else mx_e2m3(r_f16(b - bh)))
     return torch.cat(aa, dim=-1) @ torch.cat(bb, dim=-1).transpose(-2, -1)
 
 
