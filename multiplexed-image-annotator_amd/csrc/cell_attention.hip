@@ -76,7 +76,13 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
   constexpr int NK = G::NK, GROUPS = G::GROUPS, HPG = G::HPG, kRing = G::RING, kGroupDims = G::GD, NTP = G::NTP, kWStage = G::WSTAGE;
   constexpr int NTILES = 3 * NTP;              // accumulator tiles per wave and group: q | k | v
   constexpr int TOTAL = GROUPS * NK;           // K steps of the whole cell
+#ifdef CELLDBG_MXBOUND      // timing-only bound (results wrong on purpose; tools/build_ab_lib.py ... -DCELLDBG_MXBOUND): what the weight stream in an
+  // MX image (fp16 hi + fp6 lo: ~2/3 of the bytes) and one correction on the block-scaled instruction could buy the QKV phase at most --
+  // 2/3 of the DMA pieces per stage, no lo fragment reads, 2 of the 3 MFMAs per tile and step
+  constexpr int GPL = G::WROWS / 8 * 2 / 3;
+#else
   constexpr int GPL = G::WROWS / 8;            // 18 / 24 DMA instructions (1 KB each) per stage
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -175,10 +181,16 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           whi[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(st + w_rd[3 * jb + j]));
+#ifndef CELLDBG_MXBOUND
           wlo[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(st + (w_rd[3 * jb + j] ^ 16)));
+#else
+          wlo[j] = whi[j];
+#endif
         }
+#ifndef CELLDBG_MXBOUND
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[3 * jb + j] = mfma_f16(wlo[j], ahi[s], acc[3 * jb + j]);
+#endif
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[3 * jb + j] = mfma_f16(whi[j], alo[s], acc[3 * jb + j]);
 #pragma unroll
