@@ -2,6 +2,7 @@
 and against the CPU oracle pipeline at BASELINE config-2 size; plus size-independent properties at larger sizes."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -587,7 +588,7 @@ def test_config3_parity_audit_2000_cells():
                         "cells_re_evaluated_at_full_precision": vm.last_recheck["cells"], "matrix_units_fc2": 1.75 if (4 * d) % 128 == 0 else 3.0,
                         "max_abs_fast_minus_full_precision": fast_vs_full, "recheck_margin": ops.VitModel.RECHECK_MARGIN}
         print(f"[parity audit] {name}: 2000 cells, max|dp| {err:.2e}, flips {flips} (undecidable {undecidable}, fp64 sides with this path on "
-              f"{ref_wrong}), top-2 margin min {margin.min():.2e} hist {hist}")
+              f"{ref_wrong}), top-2 margin min {margin.min():.2e} hist {hist}; |fast - full precision| {fast_vs_full:.1e}", file=sys.__stdout__, flush=True)
         # identical labels wherever the reference's own margin exceeds twice the measured confidence error; a handful of ties within
         # the fp32 noise floor may fall either way (and do so between the fp32 and the fp64 CPU forward as well)
         assert flips == undecidable and flips <= 2, (name, flips, undecidable)
@@ -663,7 +664,8 @@ def test_config5_full_size_properties():
     margin = srt[:, 0] - srt[:, 1]
     flipped = got.argmax(1) != ref.argmax(1)
     print(f"[config 5 audit] {ns} cells imputer -> immune_full: max|dp| {err:.2e}, imputed plane {d_imp:.2e}, flips {int(flipped.sum())}, "
-          f"close calls (< 1e-2) {int((margin < 1e-2).sum())}, classes used {len(torch.unique(ref.argmax(1)))}, re-evaluated {model2.last_recheck}")
+          f"close calls (< 1e-2) {int((margin < 1e-2).sum())}, classes used {len(torch.unique(ref.argmax(1)))}, re-evaluated {model2.last_recheck}",
+          file=sys.__stdout__, flush=True)
     assert err < 1e-3, err
     assert len(torch.unique(ref.argmax(1))) >= 3 and int((margin < 1e-2).sum()) >= 20
     assert bool((margin[flipped] <= 2.0 * err).all()) and int(flipped.sum()) <= 2, (int(flipped.sum()), err)

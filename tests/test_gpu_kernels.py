@@ -45,7 +45,8 @@ def ps_decode(buf: torch.Tensor, k: int) -> torch.Tensor:
 def note_err(tag, err):
     """RIBCA_TEST_REPORT=1: print the measured error next to each bound (how the bounds below were checked on hardware)."""
     if os.environ.get("RIBCA_TEST_REPORT"):
-        print(f"[measured] {tag}: {err:.3e}")
+        import sys
+        print(f"[measured] {tag}: {err:.3e}", file=sys.__stdout__, flush=True)      # past pytest's capture: the log of a run carries the values
 
 
 def rnd(shape, seed, dev, scale=1.0):
