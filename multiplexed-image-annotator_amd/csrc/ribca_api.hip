@@ -572,6 +572,7 @@ void ribca_vit_destroy(ribca_vit_t* m) {
 }
 
 double ribca_vit_flops_per_cell(const ribca_vit_t* m) {
+  if (!m) return 0.0;
   const double d = m->D, n = kTokens;
   return 2.0 * 100 * 16 * m->C * d + m->depth * (24.0 * n * d * d + 4.0 * n * n * d) + 2.0 * d * m->K;
 }
@@ -599,6 +600,7 @@ static int vit_forward_impl(const ribca_vit_t* m, const float* patches, int32_t 
   if (n_cells < 0 || chunk_cells <= 0) return fail("ribca_vit_forward: bad cell counts");
   if (n_cells == 0) return 0;
   if (!patches || !src_chan || !probs || !workspace) return fail("ribca_vit_forward: NULL buffer");
+  if (c_img <= 0) return fail("ribca_vit_forward: c_img (channels per patch in `patches`) must be positive");
   if (((uintptr_t)workspace & 255) != 0) return fail("ribca_vit_forward: workspace must be 256-byte aligned");
   const AttnGeom geom = make_attn_geom(m->D, kHeads, kTokens);
   Carver c((char*)workspace);

@@ -85,3 +85,37 @@ def test_product_path_refuses_to_run_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(_lib.RibcaError):
         _lib.require_gpu()
+
+
+def test_entry_points_refuse_bad_arguments_with_a_status():
+    """the argument checks of the C ABI run before any HIP call: NULL buffers, bad sizes and NULL handles come back as status != 0 with a
+    message naming the entry point -- on this GPU-less container as on the box (no dereference, no launch)"""
+    from multiplexed_image_annotator_amd import _lib
+    lib = _lib.lib()
+
+    def refused(status, name):
+        assert status != 0
+        msg = lib.ribca_last_error()
+        assert msg and name.encode() in msg, (name, msg)
+
+    refused(lib.ribca_mask_minmax(None, 10, None, None), "ribca_mask_minmax")
+    refused(lib.ribca_label_table(None, 4, 4, 3, None, None, None), "ribca_label_table")
+    refused(lib.ribca_channel_min(None, 3, 16, None, None), "ribca_channel_min")
+    refused(lib.ribca_extract_patches(None, 3, 8, 8, None, None, None, None, None, 5, None, None, None), "ribca_extract_patches")
+    refused(lib.ribca_vote(None, 3, None, None, 0, None, None, 0.3, 7, None, None, None), "ribca_vote")
+    refused(lib.ribca_colorize(None, 16, None, 4, None, None, None, None, None, None, None), "ribca_colorize")
+    refused(lib.ribca_knn_cooccurrence(None, None, None, 10, 3, 4, None, None), "ribca_knn_cooccurrence")
+    refused(lib.ribca_gauss1d(None, None, 1, 4, 4, 0, None, 1, 0, None), "ribca_gauss1d")
+    refused(lib.ribca_radix_hist(None, 1, 16, None, 0, 0, 8, None, None), "ribca_radix_hist")
+    refused(lib.ribca_vit_forward(None, None, 3, None, 5, None, None, 0, 4, None), "ribca_vit_forward")
+    refused(lib.ribca_vit_forward_precise(None, None, 3, None, 5, None, None, 0, 4, None), "ribca_vit_forward")
+    refused(lib.ribca_mae_impute(None, None, None, 3, 5, None, 0, 4, None), "ribca_mae_impute")
+    handle = ctypes.c_void_p()
+    refused(lib.ribca_vit_create(None, 0, 100, 3, 4, 2, None, ctypes.byref(handle)), "ribca_vit_create")      # D not a multiple of 48
+    assert not handle.value
+    refused(lib.ribca_mae_create(None, 0, 40, 2, 2, None, ctypes.byref(handle)), "ribca_mae_create")
+    assert lib.ribca_vit_workspace_bytes(None, 16) == 0 and lib.ribca_mae_workspace_bytes(None, 16, 3) == 0
+    assert lib.ribca_vit_flops_per_cell(None) == 0.0
+    lib.ribca_vit_destroy(None)
+    lib.ribca_mae_destroy(None)
+    assert lib.ribca_vote(None, 3, None, None, 0, None, None, 0.3, 0, None, None, None) == 0      # n = 0: nothing to do, nothing touched
