@@ -795,6 +795,7 @@ def test_mae_golden(dev, golden_dir, panel):
     y = model.impute(x.to(dev).contiguous(), present, chunk_cells=4).cpu()      # 2 chunks, ragged tail
     assert torch.equal(y[:, present], x[:, present])                              # kept channels bit-for-bit untouched
     err = np.abs(y[:, missing].numpy() - g[panel + "_pred"]).max()
+    note_err(f"mae golden {panel} (imputed planes vs the reference's MarkerImputer)", err)
     assert err < 5e-4, err          # pixel values in [-1, 1] feed a classifier whose 1e-3 budget is on probabilities
 
 
@@ -808,7 +809,9 @@ def test_mae_vs_oracle(dev, panel, present):
     ref = ref_mae.impute(sd, x, present)
     got = ops.MaeModel(sd, dev).impute(x.to(dev).contiguous(), present, chunk_cells=16).cpu()
     assert torch.equal(got[:, present], x[:, present])
-    assert (got - ref).abs().max().item() < 5e-4
+    err = (got - ref).abs().max().item()
+    note_err(f"mae vs oracle {panel} ({len(present)} present)", err)
+    assert err < 5e-4, err
 
 
 @pytest.mark.gpu
