@@ -246,6 +246,7 @@ def main():
             bb_d = bb_all[lo:hi].contiguous()
             patches, _ = ops.extract_patches(image, mask, cmin, ids_d, bb_d)
         probs = {}
+        imputed_panel = None
         for name, model in models.items():
             if models_sel is not None and name not in models_sel:
                 continue
@@ -255,7 +256,10 @@ def main():
                     panel = patches[:, :15].contiguous()
                     imputer.impute(panel, imp_present, chunk_cells=ops.MaeModel.CHUNK_FACTOR * args.chunk)
                 with stage("vit"):
-                    probs[name] = model.predict_proba(panel, list(range(15)), chunk_cells=args.chunk, streams=streams, recheck=RECHECK)
+                    # (a member of the vote pair: re-evaluated below by the vote's own distance -- on the IMPUTED panel, kept for that)
+                    probs[name] = model.predict_proba(panel, list(range(15)), chunk_cells=args.chunk, streams=streams,
+                                                      recheck=None if (models_sel is None and name in vote_pair) else RECHECK)
+                imputed_panel = panel
                 del panel
                 continue
             with stage("vit"):
@@ -272,9 +276,10 @@ def main():
                 uses_mx = [k for k in vote_pair if _lib.lib().ribca_mx_enabled(models[k].D)]
                 if rows.numel() and uses_mx:
                     for k in uses_mx:
-                        src_p = patches
-                        probs[k].index_copy_(0, rows, models[k]._forward(src_p.index_select(0, rows), srcs[k] if not (imputer is not None and k == "immune_full")
-                                                                         else list(range(15)), args.chunk, 0, 1, precise=True))
+                        from_imputed = imputed_panel is not None and k == "immune_full"
+                        src_p = imputed_panel if from_imputed else patches
+                        probs[k].index_copy_(0, rows, models[k]._forward(src_p.index_select(0, rows), list(range(15)) if from_imputed else srcs[k],
+                                                                         args.chunk, 0, 1, precise=True))
                     dd = ops.decision_distance(probs[a_], oth[a_], probs[b_], oth[b_], RECHECK)
                 if record:
                     recheck_counts["vote_pair_cells_re_evaluated"] = int(rows.numel()) if uses_mx else 0
@@ -494,6 +499,7 @@ def main():
                            # not the peak the fraction is priced against: what register-resident MFMA loops sustain on this chip under its
                            # power management (tools/mfma_sustain_probe.hip, profiles/r3/mfma_sustain_probe.txt: 1.88 PF at 1.89 GHz)
                            "mfma_sustained_tflops_probe": sustained,
+                           "mfma_sustained_tflops_probe_source": "committed file profiles/r3/mfma_sustain_probe.txt (a one-off probe of round 3 on another box), not this run",
                            "frac_of_sustained_cap": round(achieved / (sustained / mu_all), 4) if sustained else None,
                            "mfma_busy_frac": busy, "lds_active_frac": lds,
                            "counters": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), SQ_LDS_IDX_ACTIVE / (256 CUs x ...): "
