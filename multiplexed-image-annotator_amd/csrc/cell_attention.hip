@@ -126,10 +126,16 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
     issue(0);
     issue(1);
     for (int step = 0; step < TOTAL; ++step) {
+#ifdef CELLDBG_HALFBAR      // timing-only (results racy on purpose): what half the step barriers (64-deep ring stages) would buy
+      if ((step & 1) == 0 || step + 1 == TOTAL) {
+#endif
       if (step + 1 < TOTAL) wait_vmcnt<GPL>();
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();                            // stage `step` landed; the slot of step - 1 has been read by everyone
       asm volatile("" ::: "memory");
+#ifdef CELLDBG_HALFBAR
+      }
+#endif
       if (step + 2 < TOTAL) issue(step + 2);
       if ((step + 1) % NK == 0) __builtin_amdgcn_s_barrier();  // the group's "k, v published" barrier
     }
@@ -170,9 +176,15 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
       // in the ISA) -- and the slot is only protected by the DMA's latency exceeding an LDS read's.  That is the non-repeatability the
       // round-3 buffer-descriptor loader showed (a few rows per thousand cells at D = 144 / 288): it issues its first piece a few
       // cycles behind the barrier instead of ~70 and so closed the window.
+#ifdef CELLDBG_HALFBAR
+      if ((step & 1) == 0 || step + 1 == TOTAL) {
+#endif
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+#ifdef CELLDBG_HALFBAR
+      }
+#endif
       const char* st = smem + (step % kRing) * kWStage;
       if (dbg & 2) continue;                                   // timing ablation: barriers and the weight stream only
 #pragma unroll
