@@ -44,6 +44,12 @@
 
 #include "gemm_epi.h"
 
+#ifdef MX_BIG      // (see the kernel section: 256-row tiles, accumulators in AGPRs)
+#define MX_ACC_CONSTRAINT "+a"
+#else
+#define MX_ACC_CONSTRAINT "+v"
+#endif
+
 namespace ribca {
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -126,7 +132,7 @@ __device__ __forceinline__ void pin_acc(f32x4 (&acc)[1][MT][TN]) {
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[0][i][j]));
+    for (int j = 0; j < TN; ++j) asm volatile("" : MX_ACC_CONSTRAINT(acc[0][i][j]));
 }
 
 }  // namespace
@@ -256,12 +262,25 @@ void launch_mx_pack_act(const uint16_t* ps, int ldps, int M, int Kp, const MxAct
 #define MXDBG_PF 3
 #endif
 namespace {
-constexpr int MX_BM = 128, MX_BN = 192, MX_MT = 8, MX_TN = 3;
-// LDS map: hi as two halves of 128 rows x 128 bytes (sub-steps 0-1 | 2-3), the fp6 rows, two scale slots, two lo slots
-constexpr int L_HI = 0, L_H6A = 32768, L_H6B = 40960, L_SC = 45056, L_SC_SLOT = 640, L_L8 = L_SC + 2 * L_SC_SLOT, L_XCH = L_L8 + 32768;
+// MX_BIG (experiment of round 5, tools/build_ab_lib.py ... -DMX_BIG; NOT the product): 256-row tiles, ONE 4-wave workgroup per CU, a wave owns 256 rows x
+// 48 columns (16 x 3 accumulator tiles in AGPRs) -- every W fragment then serves twice the rows: 0.027 operand bytes per multiply-add instead of
+// 0.038.  No MX3 emission in this form (the staging image is that of a 128-row tile).
+#ifdef MX_BIG
+constexpr int MX_BM = 256, MX_MT = 16;
+#else
+constexpr int MX_BM = 128, MX_MT = 8;
+#endif
+constexpr int MX_BN = 192, MX_TN = 3;
+// LDS map: hi as two halves of BM rows x 128 bytes (sub-steps 0-1 | 2-3), the fp6 rows, two scale slots, two lo slots
+constexpr int L_HALF = MX_BM * 128;
+constexpr int L_HI = 0, L_H6A = 2 * L_HALF, L_H6B = L_H6A + MX_BM * 64, L_SC = L_H6B + MX_BM * 32, L_SC_SLOT = MX_BM * 4 + 128, L_L8 = L_SC + 2 * L_SC_SLOT,
+              L_XCH = L_L8 + 2 * L_HALF;
+static_assert(MX_BM != 128 || (L_H6A == 32768 && L_H6B == 40960 && L_SC == 45056 && L_SC_SLOT == 640), "the 128-row map is the one the tests pinned");
 // (L_XCH: 2 KB outside every ring slot for the MX3-emitting epilogues, gemm_epi.h mx3_emit_wave48; their staging image overlays the ring)
 constexpr int L_TOTAL = L_XCH + 2048;
-static_assert(kMx3StageBytes <= L_XCH, "the staging image of the MX3 emission must not reach the exchange space");
+static_assert(L_TOTAL <= 160 * 1024, "LDS of a CU");
+static_assert(MX_BM != 128 || kMx3StageBytes <= L_XCH, "the staging image of the MX3 emission must not reach the exchange space");
+
 static_assert(L_L8 % 16 == 0, "LDS-DMA destination alignment");
 __device__ __forceinline__ int mx_f4(int row) { return (4 - ((row >> 2) & 3)) & 3; }      // chunk swizzle of the 64-byte hi rows
 // chunk swizzle of the 128-byte lo rows: an fp8 operand's lane (row, g) holds k = 16 g .. + 15 and 64 + 16 g .. + 15 (tools/mx_kmap_probe.hip:
@@ -272,7 +291,12 @@ __device__ __forceinline__ int mx_f8(int row) { return (row >> 1) & 7; }
 
 // ABL (diagnostic library only): 1 = no epilogue (results dropped)
 template <class Epi, int ABL>
-__global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint16_t* __restrict__ WH, const unsigned char* __restrict__ WX, int M, int nb,
+#ifdef MX_BIG
+__global__ __launch_bounds__(256, 1) void gemm_mx_duo_kernel(
+#else
+__global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(
+#endif
+MxAct A, const uint16_t* __restrict__ WH, const unsigned char* __restrict__ WX, int M, int nb,
                                                               int mtiles, int ntiles, Epi epi, int panel) {
   // epilogues: EpiResidZK (proj / fc2: the residual tile through the ring, optionally a second copy of the new rows in MX3), EpiQKVLn,
   // EpiGeluMx (fc1: GELU output in MX3)
@@ -336,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
     hi_voff = hrow * Kp * 2 + (((lane & 7) ^ mx_f8(hrow)) << 4);
     const int drow = wave * 8 + (lane >> 3);                       // + 32 i for the wave's other groups (same swizzle)
     l8_voff = drow * Kp + (((lane & 7) ^ mx_f8(drow)) << 4);
-    sc_voff = (wave * 32 + lane) * 4;
+    sc_voff = (wave * (BM / 4) + lane) * 4;
   }
   auto issue_hi = [&](int b) {      // the hi columns of step b as two halves of 64 columns (sub-steps 0-1, 2-3): 8 operations per wave
 #ifdef MXDBG_NOA
@@ -346,25 +370,25 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(hi_rsrc, (__attribute__((address_space(3))) void*)(smem + L_HI + h * 16384 + wave * 1024 + i * 4096), 16,
+      for (int i = 0; i < BM / 32; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(hi_rsrc, (__attribute__((address_space(3))) void*)(smem + L_HI + h * L_HALF + wave * 1024 + i * 4096), 16,
                                                  hi_voff, i * 32 * Kp * 2 + b * 256 + h * 128, 0, 0);
   };
   auto issue_l8 = [&](int b) {      // lo unit + scale unit of step b: 5 operations per wave
 #ifdef MXDBG_NOA
     return;
 #endif
-    char* st = smem + L_L8 + (b & 1) * 16384 + wave * 1024;
+    char* st = smem + L_L8 + (b & 1) * L_HALF + wave * 1024;
 #ifdef MXDBG_LO4      // timing variant: half the lo bytes (what an fp4 image of A lo would move)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < BM / 64; ++i)
 #else
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < BM / 32; ++i)
 #endif
       __builtin_amdgcn_raw_ptr_buffer_load_lds(l8_rsrc, (__attribute__((address_space(3))) void*)(st + i * 4096), 16, l8_voff, i * 32 * Kp + b * 128, 0, 0);
     // 64 rows per wave from row 32 w: the upper half repeats what the next wave writes (the same bytes) and the last wave's spills into the slot's pad
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(sc_rsrc, (__attribute__((address_space(3))) void*)(smem + L_SC + (b & 1) * L_SC_SLOT + wave * 128), 4, sc_voff,
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(sc_rsrc, (__attribute__((address_space(3))) void*)(smem + L_SC + (b & 1) * L_SC_SLOT + wave * BM), 4, sc_voff,
                                              b * A.M * 4, 0, 0);
   };
   auto issue_z = [&](int t, int slot_off) {      // 32 columns of the residual tile (packed-split: 128 bytes per row): 4 operations per wave
@@ -374,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
     const int drow = wave * 8 + (lane >> 3);
     const int z_voff = drow * ldz_ * 2 + (((lane & 7) ^ swz_f(drow)) << 4);      // (recomputed: not worth a register across the K loop)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < BM / 32; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(z_rsrc, (__attribute__((address_space(3))) void*)(st + i * 4096), 16, z_voff, i * 32 * ldz_ * 2 + ko, 0, 2);
   };
 
@@ -479,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
       constexpr int PF = MXDBG_PF;
       f16x8 ah[PF + 1];
       const unsigned rd_s = (S & 1) ? (rd_hi ^ 64u) : rd_hi;
-      constexpr int HOFF = (S >> 1) * 16384;
+      constexpr int HOFF = (S >> 1) * L_HALF;
       sfor<PF>([&](auto pc) {
         constexpr int q = decltype(pc)::value;
         lds_rd128h<HOFF + q * 2048>(ah[q], rd_s);
@@ -511,16 +535,17 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
 #ifndef MXDBG_NOCONV
     // ---- conversion: this wave turns the hi rows of row tiles 2 w, 2 w + 1 into fp6 for everybody
     {
-      const unsigned cv_hi = rd_hi + (unsigned)(wave * 4096), cv_hi1 = cv_hi ^ 64u, cv_sc = rd_sc + (unsigned)(wave * 128 + (b & 1) * L_SC_SLOT);
-      const unsigned cv_a = rd_h6a + (unsigned)(wave * 2048), cv_b = rd_h6b + (unsigned)(wave * 1024);
-      sfor<2>([&](auto u_c) {
+      constexpr int CVT = MT / 4;      // row tiles this wave converts
+      const unsigned cv_hi = rd_hi + (unsigned)(wave * CVT * 2048), cv_hi1 = cv_hi ^ 64u, cv_sc = rd_sc + (unsigned)(wave * CVT * 64 + (b & 1) * L_SC_SLOT);
+      const unsigned cv_a = rd_h6a + (unsigned)(wave * CVT * 1024), cv_b = rd_h6b + (unsigned)(wave * CVT * 512);
+      sfor<CVT>([&](auto u_c) {
         constexpr int U = decltype(u_c)::value;
         f16x8 h[4];
         unsigned sb;
         lds_rd128h<U * 2048>(h[0], cv_hi);
         lds_rd128h<U * 2048>(h[1], cv_hi1);
-        lds_rd128h<U * 2048 + 16384>(h[2], cv_hi);
-        lds_rd128h<U * 2048 + 16384>(h[3], cv_hi1);
+        lds_rd128h<U * 2048 + L_HALF>(h[2], cv_hi);
+        lds_rd128h<U * 2048 + L_HALF>(h[3], cv_hi1);
         lds_rd8<U * 64>(sb, cv_sc);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(sb)::"memory");
         h32 hv;
@@ -550,8 +575,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
     } else if constexpr (ZK) {
       // the residual tile's first three 32-column units: two into the hi slots, one into the lo slot of the other parity
       issue_z(0, L_HI);
-      issue_z(1, L_HI + 16384);
-      issue_z(2, L_L8 + ((b + 1) & 1) * 16384);
+      issue_z(1, L_HI + L_HALF);
+      issue_z(2, L_L8 + ((b + 1) & 1) * L_HALF);
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- MX phase
@@ -566,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
       wh6[j] = __builtin_bit_cast(i32x8, __builtin_shufflevector(wh6r[j], wh6r[j], 0, 1, 2, 3, 4, 5, -1, -1));
     }
     {
-      const unsigned m_l8a = rd_l8 + (unsigned)(L_L8 + (b & 1) * 16384), m_l8b = m_l8a ^ 64u;
+      const unsigned m_l8a = rd_l8 + (unsigned)(L_L8 + (b & 1) * L_HALF), m_l8b = m_l8a ^ 64u;
       const unsigned m_sc = rd_sc + (unsigned)((b & 1) * L_SC_SLOT);
       u32v4 la[2], lb[2], ha[2];
       u32v2 hb[2];
@@ -642,7 +667,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
     {
       const int last = nb - 1;
       const unsigned rd_ps_hi = lds_base + (unsigned)lds_off(r16e, 2 * ge);      // packed-split rows: hi chunk 2 g, lo chunk at ^ 16
-      const int zslot[4] = {L_HI, L_HI + 16384, L_L8 + ((last + 1) & 1) * 16384, L_L8 + (last & 1) * 16384};
+      const int zslot[4] = {L_HI, L_HI + L_HALF, L_L8 + ((last + 1) & 1) * L_HALF, L_L8 + (last & 1) * L_HALF};
       const int p8 = r16e & 7;
       const unsigned one = (p8 & 1) ? 0x3C000000u : 0x00003C00u;
       const u32x4 pat = {(p8 >> 1) == 0 ? one : 0u, (p8 >> 1) == 1 ? one : 0u, (p8 >> 1) == 2 ? one : 0u, (p8 >> 1) == 3 ? one : 0u};
@@ -720,10 +745,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
     const bool emit = epi.zmx.hi != nullptr;
     if (m0 + BM <= M) {
       resid_zk_epilogue<TN, MT, MT, true>(epi, mbase, nbase, blk, ge, acc, zb4, zpm);
-      if (emit) mx3_emit_wave48<MT, true>(epi.zmx, M, m0, n0 + wn * (16 * TN), ge, r16e, wave, lds_base, xch, acc[0], epi.nt != 0);
+      if constexpr (MT == 8) { if (emit) mx3_emit_wave48<MT, true>(epi.zmx, M, m0, n0 + wn * (16 * TN), ge, r16e, wave, lds_base, xch, acc[0], epi.nt != 0); }
     } else {
       resid_zk_epilogue<TN, MT, MT, false>(epi, mbase, nbase, blk, ge, acc, zb4, zpm);
-      if (emit) mx3_emit_wave48<MT, false>(epi.zmx, M, m0, n0 + wn * (16 * TN), ge, r16e, wave, lds_base, xch, acc[0], epi.nt != 0);
+      if constexpr (MT == 8) { if (emit) mx3_emit_wave48<MT, false>(epi.zmx, M, m0, n0 + wn * (16 * TN), ge, r16e, wave, lds_base, xch, acc[0], epi.nt != 0); }
     }
   } else {
     // N is a multiple of the tile width for these (gemm_mx_supported + the launchers): only the rows need guards
@@ -739,8 +764,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_duo_kernel(MxAct A, const uint
       return;
     }
     if constexpr (is_mx_out<Epi>::value) {
-      if (m0 + BM <= M) gelu_mx48_epilogue<MT, true>(epi, m0, n0 + wn * (16 * TN), ge, r16e, wave, lds_base, xch, acc);
-      else gelu_mx48_epilogue<MT, false>(epi, m0, n0 + wn * (16 * TN), ge, r16e, wave, lds_base, xch, acc);
+      if constexpr (MT == 8) {
+        if (m0 + BM <= M) gelu_mx48_epilogue<MT, true>(epi, m0, n0 + wn * (16 * TN), ge, r16e, wave, lds_base, xch, acc);
+        else gelu_mx48_epilogue<MT, false>(epi, m0, n0 + wn * (16 * TN), ge, r16e, wave, lds_base, xch, acc);
+      }
     } else {
       if (m0 + BM <= M) run_epilogue<TN, Epi, MT, true>(epi, mbase, nbase, acc[0]);
       else run_epilogue<TN, Epi, MT>(epi, mbase, nbase, acc[0]);
