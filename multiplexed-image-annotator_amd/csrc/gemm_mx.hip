@@ -464,6 +464,7 @@ MxAct A, const uint16_t* __restrict__ WH, const unsigned char* __restrict__ WX, 
 
 #ifdef MXDBG_STAMP      // timing variant (tools/build_mx_variant.py): shader-clock cycles per phase, summed over the K loop, per wave
   unsigned long long st_prev = __builtin_amdgcn_s_memtime(), st_b1 = 0, st_f16 = 0, st_cv = 0, st_b2 = 0, st_mx = 0;
+  const unsigned long long st_start = st_prev, rt_start = __builtin_amdgcn_s_memrealtime();      // (100 MHz: the in-kernel clock = d memtime / d memrealtime)
 #define MX_STAMP(acc_) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc_ += t_ - st_prev; st_prev = t_; }
 #else
 #define MX_STAMP(acc_)
@@ -739,7 +740,9 @@ MxAct A, const uint16_t* __restrict__ WH, const unsigned char* __restrict__ WX, 
       o[0] = float2{(float)st_b1, (float)st_f16};
       o[1] = float2{(float)st_cv, (float)st_b2};
       o[2] = float2{(float)st_mx, (float)nb};
-      o[3] = float2{(float)(__builtin_amdgcn_s_memtime() - st_prev), 0.f};      // everything behind the K loop
+      const unsigned long long st_now = __builtin_amdgcn_s_memtime(), rt_now = __builtin_amdgcn_s_memrealtime();
+      // everything behind the K loop; the shader clock this wave saw from its first instruction to here, in MHz (MI355X_MICROARCH.md, DVFS give-back item 6)
+      o[3] = float2{(float)(st_now - st_prev), rt_now > rt_start ? 100.0f * (float)(st_now - st_start) / (float)(rt_now - rt_start) : 0.f};
     }
 #endif
     const bool emit = epi.zmx.hi != nullptr;

@@ -28,7 +28,8 @@ for d, k in ((576, 2304), (384, 1536), (576, 640)):
     check(lib().ribca_test_gemm_mx_resid(ptr(a), 2 * k, ptr(w), 2 * k, 128, d, k, ptr(bias), ptr(hi), ptr(l8), ptr(sc), ptr(wh), ptr(wx),
                                          ptr(z), 2 * dp, None, None, None, stream_ptr()), "w")
     check(lib().ribca_test_mx_pack_act(ptr(a), 2 * k, M, k, ptr(hi), ptr(l8), ptr(sc), stream_ptr()), "pack")
-    for rep in range(2):      # the second launch is the one read (warm instruction cache)
+    warm = int(os.environ.get("RIBCA_STAMP_WARM", "400"))      # back-to-back launches before the one read: the chip's clock settles under load
+    for rep in range(warm + 1):      # the last launch is the one read
         part.zero_()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -39,8 +40,10 @@ for d, k in ((576, 2304), (384, 1536), (576, 640)):
     st = st[st[:, 2, 1] > 0]                      # waves that wrote (live column blocks)
     nb = st[0, 2, 1].item()
     b1, f16, cv, b2, mx, tail = st[:, 0, 0], st[:, 0, 1], st[:, 1, 0], st[:, 1, 1], st[:, 2, 0], st[:, 3, 0]
+    mhz = st[:, 3, 1]
     tot = b1 + f16 + cv + b2 + mx
     f = lambda x: f"{(x / nb).mean().item():7.0f}"
     print(f"D={d} K={k}: {e0.elapsed_time(e1):.3f} ms, {len(st)} waves, {nb:.0f} steps; cycles per step (mean over waves): "
           f"B1 wait+barrier {f(b1)} | f16 phase {f(f16)} | conversion {f(cv)} | B2 wait+barrier {f(b2)} | MX phase {f(mx)} | step {f(tot)} ; "
-          f"behind the K loop {tail.mean().item():.0f} cycles", flush=True)
+          f"behind the K loop {tail.mean().item():.0f} cycles; in-kernel clock (d s_memtime / d s_memrealtime) median {mhz.median().item():.0f} MHz "
+          f"(5 % .. 95 %: {mhz.quantile(0.05).item():.0f} .. {mhz.quantile(0.95).item():.0f})", flush=True)
