@@ -6,6 +6,7 @@ parameter preparation (Gaussian taps, index tables).  All calls enqueue on the c
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -487,6 +488,13 @@ class VitModel:
     # 1e-3 leaves an order of magnitude, and is the north star's own confidence tolerance.
     RECHECK_MARGIN = 1.0e-3
 
+    #: width -> multiple of the caller's chunk_cells a forward of that width uses (RIBCA_CHUNK_SCALE=<n> overrides it for every width: A/B)
+    CHUNK_SCALE = {576: 4}
+
+    def chunk_scale(self) -> int:
+        env = os.environ.get("RIBCA_CHUNK_SCALE")
+        return max(1, int(env)) if env else self.CHUNK_SCALE.get(self.D, 1)
+
     def predict_proba(self, patches: torch.Tensor, src_chan: Sequence[int], chunk_cells: int = 1024, ws_slot: int = 0,
                       streams: int = 1, recheck: Optional[Sequence[float]] = None) -> torch.Tensor:
         """``_forward`` plus, where this width runs the MX pair, the full-precision re-evaluation of the cells near a decision boundary:
@@ -532,7 +540,11 @@ class VitModel:
         if n == 0:
             return probs
         fwd = lib().ribca_vit_forward_precise if precise else lib().ribca_vit_forward
-        chunk = max(1, min(int(chunk_cells), n))
+        # callers size chunks for the ensemble (1024 cells = 103 424 GEMM rows); the 576-wide classifier's launches are then 4.7 rounds of
+        # workgroups and lose a twentieth each to the partial last round plus a fixed 39 us of ramp (profiles/r5/mx_rounds.txt): it takes
+        # CHUNK_SCALE times the caller's chunk (same-box sweep, profiles/r5/chunk_streams_full.txt: 39.3-39.9 -> 40.4-41.3 k cells/s at 4 x;
+        # the narrower classifiers measured flat or slightly worse).  Results do not depend on the chunk size (test_classifier_bitwise_repeatable).
+        chunk = max(1, min(int(chunk_cells) * self.chunk_scale(), n))
         src = torch.tensor(list(src_chan), dtype=torch.int32, device=patches.device)
         nbytes = lib().ribca_vit_workspace_bytes(self._h, chunk)
         patches = patches.contiguous()
