@@ -5,7 +5,8 @@
     RIBCA_LIB=libribca_ab_old.so python tools/bench_mx_only.py          (the hooks resolve to the matching _test.so: _lib.TEST_LIB_PATH)
 
 `rev` = WORK takes the working tree (with extra -D flags: a timing variant of the current sources).  The libraries are git-ignored and travel
-to the GPU box (named libribca_ab_*: .gpurunignore only drops libribca_hip_*); delete them when the A/B is done."""
+to the GPU box (named libribca_ab_*: .gpurunignore only drops libribca_hip_diag*); delete them when the A/B is done.
+RIBCA_AB_PATCH=<file>: a patch (-p1, paths from the repo root) applied to the temporary copy before compiling -- experiments that never touch the tree."""
 import concurrent.futures
 import os
 import shutil
@@ -26,6 +27,8 @@ try:
     else:
         ar = subprocess.run(["git", "-C", ROOT, "archive", rev, "multiplexed-image-annotator_amd/csrc", "include"], check=True, capture_output=True).stdout
         subprocess.run(["tar", "-x", "-C", tmp], input=ar, check=True)
+    if os.environ.get("RIBCA_AB_PATCH"):      # a timing-only or experimental change that never touches the tree: applied to the temporary copy
+        subprocess.run(["patch", "-p1", "-d", tmp, "-i", os.path.abspath(os.environ["RIBCA_AB_PATCH"])], check=True)
     csrc = os.path.join(tmp, "multiplexed-image-annotator_amd", "csrc")
     srcs = [s for s in B.SOURCES + B.TEST_SOURCES if os.path.exists(os.path.join(csrc, s))]
 
