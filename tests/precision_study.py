@@ -26,6 +26,9 @@ w = weight; the attention products and every linear not named by --linears stay 
     mx100       ah.wh                       one fp16 pass                                                        1
     mx150s      ah.wh + al6.wh6 + ah6.wl6   BOTH corrections kept, A lo as MX e2m3 under its own block scale (the fp8 operand is what makes
                                             the first correction a half-rate instruction): 2.78 bytes / element       1 + 1/4 + 1/4
+--zstream: the format the residual stream z is STORED in between the residual GEMMs (fp32: not rounded, the study's default; ps: fp16 hi + fp16
+lo, what the kernels keep; mx3: fp16 hi + e4m3 lo under the MX3 block scale -- 3 bytes per element, the stream attn.proj / mlp.fc2 would read
+and write if the packed-split copy were dropped).
 """
 from __future__ import annotations
 
@@ -42,6 +45,17 @@ from multiplexed_image_annotator_amd import synth  # noqa: E402
 from oracle import ref_vit  # noqa: E402
 
 LO_SCALE = 4096.0  # 2^12: l of an fp16-rounded value is below 2^-11 |x|
+ZSTREAM = "fp32"
+
+
+def store_z(z):
+    """the residual stream as it would sit in memory between two residual GEMMs (--zstream)"""
+    if ZSTREAM == "fp32":
+        return z
+    h = r_f16(z)
+    if ZSTREAM == "ps":
+        return h + r_f16(z - h)
+    return h + mx3_lo(z, h)
 
 
 def r_bf16(x):
@@ -246,7 +260,7 @@ def logits_scheme(sd, x, scheme, attn_scheme=None):
     d = sd["cls_token"].shape[-1]
     hd = d // heads
     t = ref_vit.patch_embed(sd, x)
-    z = torch.cat((sd["cls_token"].expand(b, -1, -1), t), dim=1) + sd["pos_embed"]
+    z = store_z(torch.cat((sd["cls_token"].expand(b, -1, -1), t), dim=1) + sd["pos_embed"])
     n = z.shape[1]
     for i in range(ref_vit.depth_of(sd)):
         p = f"blocks.{i}."
@@ -256,10 +270,10 @@ def logits_scheme(sd, x, scheme, attn_scheme=None):
         q, k, v = qkv[0] * hd ** -0.5, qkv[1], qkv[2]
         att = mm(q, k, attn_scheme, "q", "k").softmax(dim=-1)
         y = mm(att, v.transpose(-2, -1), attn_scheme, "p", "v").transpose(1, 2).reshape(b, n, d)
-        z = z + mm(y, sd[p + "attn.proj.weight"], scheme, "o", "wproj") + sd[p + "attn.proj.bias"]
+        z = store_z(z + mm(y, sd[p + "attn.proj.weight"], scheme, "o", "wproj") + sd[p + "attn.proj.bias"])
         y = F.layer_norm(z, (d,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], ref_vit.LN_EPS)
         y = F.gelu(mm(y, sd[p + "mlp.fc1.weight"], scheme, "x2", "w1") + sd[p + "mlp.fc1.bias"])
-        z = z + mm(y, sd[p + "mlp.fc2.weight"], scheme, "hh", "w2") + sd[p + "mlp.fc2.bias"]
+        z = store_z(z + mm(y, sd[p + "mlp.fc2.weight"], scheme, "hh", "w2") + sd[p + "mlp.fc2.bias"])
     z = F.layer_norm(z, (d,), sd["norm.weight"], sd["norm.bias"], ref_vit.LN_EPS)
     return z[:, 0] @ sd["head.weight"].t() + sd["head.bias"]
 
@@ -280,7 +294,10 @@ def main():
     ap.add_argument("--schemes", nargs="+", default=["bf16x3", "f16", "f16_bf8t", "f16_bf8r", "f16_fp8", "f16_fp6"])
     ap.add_argument("--seed", type=int, default=synth.SEED_BASE + 7)
     ap.add_argument("--linears", nargs="+", default=["wqkv", "wproj", "w1", "w2"], help="weights that take an mx* scheme (others: f16x3)")
+    ap.add_argument("--zstream", choices=["fp32", "ps", "mx3"], default="fp32", help="storage format of the residual stream between residual GEMMs")
     args = ap.parse_args()
+    global ZSTREAM
+    ZSTREAM = args.zstream
     LINEARS.clear()
     LINEARS.update(args.linears)
     torch.set_num_threads(os.cpu_count() or 1)
