@@ -272,8 +272,8 @@ def main():
                 a_, b_ = vote_pair
                 oth = {k: (CLASS_NAMES[k].index("Others") if "Others" in CLASS_NAMES[k] else None) for k in vote_pair}
                 dd = ops.decision_distance(probs[a_], oth[a_], probs[b_], oth[b_], RECHECK)
-                rows = torch.nonzero(dd < ops.VitModel.RECHECK_MARGIN).flatten()
                 uses_mx = [k for k in vote_pair if _lib.lib().ribca_mx_enabled(models[k].D)]
+                rows = torch.nonzero(dd < max([models[k].recheck_margin for k in uses_mx] or [ops.VitModel.RECHECK_MARGIN])).flatten()
                 if rows.numel() and uses_mx:
                     for k in uses_mx:
                         from_imputed = imputed_panel is not None and k == "immune_full"
@@ -351,7 +351,8 @@ def main():
                                + ("one marker missing -> MAE imputer (infer=True) + " if args.impute else "")
                                + f"{len(models)} ViT classifiers per cell (normalise + label table + crop/soft-mask + ViT + vote)",
                    "baseline_config": "configs[4] (one tile per GPU, imputation)" if args.impute else ("configs[2]" if world == 1 else "configs[3]"),
-                   "cells": n_cells, "models": list(models), "chunk_cells": args.chunk, "segment_streams": args.streams,
+                   "cells": n_cells, "models": list(models), "chunk_cells": args.chunk,
+                   "chunk_cells_effective": {name: m.effective_chunk(args.chunk) for name, m in models.items()}, "segment_streams": args.streams,
                    "precision": "fp16 hi+lo split operands, fp32 accumulate: 3 fp16 MFMA passes per product, or (mlp.fc2 where 4 D % 128 == 0; attn.qkv as a GEMM "
                                 "of its own and mlp.fc1 where D % 192 == 0) fp16 hi*hi + two block-scaled fp8/fp6 corrections = 1.75 matrix units per 128 k "
                                 "(matrix_units_per_product: issued units per algorithmic product, K padding included)",
@@ -381,7 +382,9 @@ def main():
     # re-evaluation -- the cells whose label two correct fp32 evaluations need not agree on (Annotator.NOISE_FLOOR)
     out["cells_re_evaluated_at_full_precision"]["vote_pair (" + " + ".join(k for k in vote_pair if k) + ")"] = recheck_counts.get("vote_pair_cells_re_evaluated")
     out["cells_undecidable"] = recheck_counts.get("vote_pair_cells_within_noise_floor")
-    out["recheck_margin"] = ops.VitModel.RECHECK_MARGIN
+    # the margin each classifier uses: max(1e-3, 16 x |fast - full precision| on a fixed 64-cell probe, measured at load time on the model's own weights)
+    out["recheck_margin"] = {name: m.recheck_margin for name, m in models.items()}
+    out["recheck_probe_fast_minus_full"] = {name: m.probe_fast_minus_full for name, m in models.items()}
     out["parity_audit"] = parity_audit_record(out["kernel_source_sha256"])
     if sharded:
         ag_ms = sum(a.elapsed_time(b) for a, b in ag_events)
@@ -397,7 +400,7 @@ def main():
         # model's GEMMs can be priced against the roofline that binds THEM (arithmetic intensity below / above the ridge)
         lo, hi = dist.shard_bounds(n_cells, rank, world) if sharded else (0, n_cells)
         n_local = hi - lo
-        prof, per_model = {}, []
+        prof, per_model, shape_rows = {}, [], {}
         # the per-cell fused qkv + attention kernel (D <= 384) belongs to the family: it carries the qkv product of those classifiers
         GEMM_OPS = ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2", "cell_qkv_attention")
         fused_attn = fused_attn_on()
@@ -410,6 +413,17 @@ def main():
             for k, v in pm.items():
                 prof[k] = (prof.get(k, (0.0, 0))[0] + v[0], prof.get(k, (0, 0))[1] + v[1])
             d = model.D
+            # per GEMM shape (classifiers of one width share their shapes): the launches of one op of one model, full blocks + the last block's
+            # CLS-row launches, against their algorithmic FLOP -- the row the vendor yardstick below is put beside
+            u_d = matrix_units(d)
+            for op, kk, nn in (("qkv", d, 3 * d), ("proj", d, d), ("fc1", d, 4 * d), ("fc2", 4 * d, d)):
+                if op == "qkv" and fused_attn and d <= 384:
+                    continue        # runs inside the fused per-cell kernel: not a GEMM launch of its own
+                fl = n_local * 2.0 * kk * nn * ((model.depth - 1) * 101 + (101 * 2.0 / 3.0 + 1.0 / 3.0 if op == "qkv" else 1.0))
+                row = shape_rows.setdefault(f"{op}@{d}", {"M_per_launch": model.effective_chunk(args.chunk) * 101, "K": kk, "N": nn, "ms": 0.0, "flop": 0.0,
+                                                          "matrix_units": round(u_d[op], 4)})
+                row["ms"] += pm["gemm_" + op][0]
+                row["flop"] += fl
             m_ms = sum(pm[k][0] for k in GEMM_OPS if k in pm)
             m_fl = n_local * ((model.depth - 1) * 24.0 * 101 * d * d + 6.0 * 101 * d * d + 18.0 * d * d)
             if fused_attn and d <= 384:      # its attention FLOPs run inside the family's kernel
@@ -427,6 +441,30 @@ def main():
                               "algorithmic_gb_per_s": round(gbs, 1), "flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1),
                               "bound": bound, "matrix_units": round(mu, 3),
                               "frac_of_bound": round(mu * tf / PEAK_BF16_DENSE_TFLOPS if bound == "mfma" else gbs / 8000.0, 4)})
+        # ---- vendor yardstick, measured in THIS run on THIS box, outside the product path: torch.matmul (hipBLASLt) in plain
+        # fp16 on the same [M x K] . [K x N] shapes at the same M per launch.  A plain 16-bit GEMM is ONE matrix unit per product: the figure to
+        # hold against it is a product kernel's ISSUED rate (algorithmic TFLOP/s x its matrix units per product).
+        per_shape = {}
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import vendor_gemm
+            by_cells = {}
+            for key, row in shape_rows.items():
+                if key in {n_ for n_, _, _ in vendor_gemm.SHAPES}:
+                    by_cells.setdefault(row["M_per_launch"] // 101, []).append(key)
+            vendor = {}
+            for cells_v, keys in by_cells.items():
+                vendor.update(vendor_gemm.measure(cells_v, names=keys, dtypes=("fp16",), rounds=2)["fp16"])
+        except Exception as e:      # the yardstick must never cost the line
+            vendor = {}
+            print(f"bench.py: vendor yardstick skipped ({type(e).__name__}: {e})", file=sys.stderr)
+        for key, row in sorted(shape_rows.items(), key=lambda kv: -kv[1]["ms"]):
+            alg = row["flop"] / (row["ms"] * 1e-3) / 1e12 if row["ms"] > 0 else 0.0
+            per_shape[key] = {"M_per_launch": row["M_per_launch"], "K": row["K"], "N": row["N"], "ms_per_pass": round(row["ms"], 2),
+                              "algorithmic_tflops": round(alg, 1), "matrix_units_per_product": row["matrix_units"],
+                              "issued_tflops": round(alg * row["matrix_units"], 1),
+                              "vendor_fp16_gemm_tflops": vendor.get(key, {}).get("tflops"),
+                              "issued_over_vendor": round(alg * row["matrix_units"] / vendor[key]["tflops"], 3) if key in vendor else None}
         gemm_flops = 0.0
         for name, model in models.items():
             d = model.D
@@ -465,14 +503,15 @@ def main():
             alg_bytes += n_local * 101 * (model.depth - 1) * gemm_bytes_per_row(d) + 12.0 * d * d * 4.0 * model.depth * ((n_local + args.chunk - 1) // args.chunk)
         # the bound that binds most of the GEMM time: every classifier's GEMMs are priced against their own roofline (per_model_*),
         # the family's label is the time-weighted majority
-        sustained = sustained_probe_tflops()
         mu_all = avg_units({n: m.D for n, m in models.items()}, {n: m.depth for n, m in models.items()})
         t_mfma = sum(m["gemm_ms"] for m in per_model if m["bound"] == "mfma")
         t_hbm = sum(m["gemm_ms"] for m in per_model if m["bound"] == "hbm")
         out["per_kernel_ms"] = {k: round(v[0], 3) for k, v in prof.items() if v[1]}
         out["per_model_gemm_ms"] = {m["model"]: m["gemm_ms"] for m in per_model}
         out["per_model_bound"] = {m["model"]: m["bound"] for m in per_model}
-        out["per_model_frac_of_bound"] = {m["model"]: m["frac_of_bound"] for m in per_model}
+        # ISSUED fraction (algorithmic TFLOP/s x matrix units per product / 2.5 PF) where MFMA-bound, algorithmic GB/s of 8 TB/s where HBM-bound:
+        # not the algorithmic fraction of the peak, which is roofline.frac
+        out["per_model_issued_frac_of_bound"] = {m["model"]: m["frac_of_bound"] for m in per_model}
         out["per_model_flop_per_byte"] = {m["model"]: m["flop_per_byte"] for m in per_model}
         # whole ViT pass against HBM: counter bytes (GEMM + attention + statistics kernels, 2 x FETCH_SIZE + WRITE_SIZE of the
         # committed, sha-matched passes, scaled per cell) over the timed step
@@ -496,11 +535,12 @@ def main():
                                                      else "none: no committed counter passes for these kernel sources"),
                            "timing_fields_source": "measured in this run (HIP events on the launch stream)",
                            "algorithmic_bytes_per_launch": round(alg_bytes / max(g_n, 1)),
-                           # not the peak the fraction is priced against: what register-resident MFMA loops sustain on this chip under its
-                           # power management (tools/mfma_sustain_probe.hip, profiles/r3/mfma_sustain_probe.txt: 1.88 PF at 1.89 GHz)
-                           "mfma_sustained_tflops_probe": sustained,
-                           "mfma_sustained_tflops_probe_source": "committed file profiles/r3/mfma_sustain_probe.txt (a one-off probe of round 3 on another box), not this run",
-                           "frac_of_sustained_cap": round(achieved / (sustained / mu_all), 4) if sustained else None,
+                           # per GEMM shape: this run's launches beside the vendor library's plain fp16 GEMM of the same shape, timed in this run
+                           "per_shape": per_shape,
+                           "per_shape_note": "issued_tflops = algorithmic_tflops x matrix_units_per_product (the work the matrix cores are handed); "
+                                             "vendor_fp16_gemm_tflops = torch.matmul (hipBLASLt) in plain fp16, ONE unit per product, same M / K / N, "
+                                             "operands rotated, measured in this run outside the product path (tools/vendor_gemm.py); the product kernels also "
+                                             "carry the LayerNorm fold, GELU / residual / statistics epilogues and the MX3 emission the vendor GEMM does not",
                            "mfma_busy_frac": busy, "lds_active_frac": lds,
                            "counters": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), SQ_LDS_IDX_ACTIVE / (256 CUs x ...): "
                                        f"profiles/{PROFILE_ROUND}/sq_summary.json; null = the committed counters belong to another build of the library",
@@ -509,9 +549,9 @@ def main():
                            "matrix_units_per_product": round(mu_all, 4),      # FLOP-weighted over the classifiers (per shape: top-level matrix_units_per_product)
                            "issued_mfma_frac_of_peak": round(mu_all * achieved / PEAK_BF16_DENSE_TFLOPS, 4),
                            "per_model_note": "GEMMs of one classifier: algorithmic FLOP per algorithmic byte against the ridge of the ISSUED "
-                                             "work (the classifier's matrix units per product at 2.5 PF dense / 8 TB/s: 104 FLOP/B at 3 units); frac_of_bound = issued "
-                                             "MFMA fraction of peak where MFMA-bound, algorithmic GB/s of 8 TB/s where HBM-bound "
-                                             "(top-level per_model_* keys)"}
+                                             "work (the classifier's matrix units per product at 2.5 PF dense / 8 TB/s: 104 FLOP/B at 3 units); "
+                                             "per_model_issued_frac_of_bound = ISSUED MFMA fraction of peak where MFMA-bound, algorithmic GB/s of 8 TB/s where "
+                                             "HBM-bound (top-level per_model_* keys)"}
 
     # ---- the boundary itself: Annotator.preprocess -> predict -> export_annotations from host files ------------------------
     if not args.no_dropin and rank == 0 and world == 1 and not args.impute:
@@ -597,20 +637,6 @@ def parity_audit_record(sha):
     return {"source": f"committed profile (profiles/{PROFILE_ROUND}/parity_audit_config3.json, kernel_source_sha256 matches)",
             "cells_audited_per_model": j.get("cells_per_model"), "label_flips_in_audit": j.get("label_flips_total"),
             "flips_outside_twice_the_error_band": j.get("flips_outside_band_total"), "max_abs_dp": j.get("max_abs_dp")}
-
-
-def sustained_probe_tflops():
-    """what register-resident fp16 MFMA loops sustained on one MI355X in ONE probe session (tools/mfma_sustain_probe.hip): read from the
-    committed output, None when the file is absent -- a one-off measurement, not a property of the box this line was timed on"""
-    path = os.path.join(ROOT, "profiles", "r3", "mfma_sustain_probe.txt")
-    try:
-        best = 0.0
-        for line in open(path):
-            if "mfma_f32_16x16x32_f16" in line and "TFLOP/s dense" in line:
-                best = max(best, float(line.split("ms")[1].split("TFLOP/s")[0]))
-        return best or None
-    except (OSError, ValueError, IndexError):
-        return None
 
 
 def lib_sha256():

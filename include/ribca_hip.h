@@ -23,6 +23,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: the declarations between this push and the pop are its whole dynamic symbol table */
+#pragma GCC visibility push(default)
 
 typedef struct ribca_vit ribca_vit_t;
 typedef struct ribca_mae ribca_mae_t;
@@ -182,6 +184,13 @@ int ribca_vote(const float* p_a, int32_t k_a, const int8_t* map_a, const float* 
 int ribca_prof_enable(int32_t on);
 int ribca_prof_read(double* ms_out10, int64_t* count_out10);
 const char* ribca_prof_name(int32_t cls);
+
+/* NOT part of the stable ABI.  The versioned table of host launchers that libribca_hip_test.so (the kernel-level hooks of tests/ and tools/,
+ * include/ribca_hip_test.h) binds instead of C++ symbols: csrc/ribca_internal.h describes it and belongs to one build.  NULL for any other
+ * version than that build's RIBCA_INTERNAL_VERSION.  A caller of the product ABI never needs it. */
+const void* ribca_internal_table(int32_t version);
+
+#pragma GCC visibility pop
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)   /* built with -fvisibility=hidden: these hooks are the library's whole dynamic symbol table */
 
 /* Kernel-level hooks used by tests/ to localise a mismatch (same kernels the forward launches). */
 int ribca_test_pack_weight(const float* w, int32_t N, int32_t K, uint16_t* out, int32_t Np, int32_t Kp, void* stream);
@@ -115,6 +116,7 @@ int ribca_set_gemm_stamps(void* dev_buffer, int64_t capacity_blocks);
 /* 1 if this library carries the diagnostic kernel forms (-DRIBCA_DIAG), else 0 */
 int ribca_is_diag_build(void);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

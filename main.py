@@ -65,7 +65,7 @@ def _pipeline(annotator, bs, n_regions):
     annotator.predict(bs)
     annotator.generate_heatmap(integrate=True)
     annotator.export_annotations()
-    n_cells = min((len(ids) for ids in annotator.preprocessor.cell_ids), default=0)
+    n_cells = annotator.min_cells_per_image()
     if n_regions > 0 and n_cells >= 201:           # the reference's 201-neighbour query raises on smaller images
         annotator.tissue_region_analysis(n_regions)
         if os.environ.get("RIBCA_EXPORT_REGIONS") == "1":      # opt-in deviation: the reference's CSV never carries the regions

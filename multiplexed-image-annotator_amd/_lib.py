@@ -60,6 +60,8 @@ SIGNATURES = {
     "ribca_prof_enable": (c_int32, [c_int32]),
     "ribca_prof_read": (c_int32, [POINTER(c_double), POINTER(c_int64)]),
     "ribca_prof_name": (c_char_p, [c_int32]),
+    # not part of the stable ABI: the launcher table libribca_hip_test.so binds (csrc/ribca_internal.h); the package never calls it
+    "ribca_internal_table": (c_void_p, [c_int32]),
 }
 
 #: the kernel-level hooks of include/ribca_hip_test.h: libribca_hip_test.so, loaded on first use by tests/ and tools/ only -- the package
@@ -133,6 +135,8 @@ class _Library:
 
 def _bind(handle, table):
     for name, (res, args) in table.items():
+        if name == "ribca_internal_table" and os.environ.get("RIBCA_LIB") and not hasattr(handle, name):
+            continue      # an A/B build of a revision older than the table (tools/build_ab_lib.py old <rev>): the package itself never calls it
         fn = getattr(handle, name)
         fn.restype = res
         fn.argtypes = args

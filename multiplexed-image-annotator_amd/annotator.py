@@ -108,6 +108,10 @@ class Annotator(object):
         self.channel_parser.parse(marker_list_path)
         self.preprocessor = ImageProcessor(image_path, self.channel_parser, log_dir, device, batch_id, infer, normalize, blur, amax,
                                            cell_size, self.logger, n_jobs=n_jobs)
+        # multi-rank runs: whole images per rank when the batch CSV has at least one per rank (reference main.py:39-52 batch_run; BASELINE
+        # config 5: replicas only, nothing exchanged, every rank writes the CSVs of its own images under their batch-wide numbers), cells of
+        # every image otherwise (contiguous shards, one all-gather per image, rank 0 writes)
+        self.tile_mode = dist.tile_mode(self.preprocessor._n_images, self.world_size, os.environ.get("RIBCA_TILE_MODE"))
         self._loaded = False
         self.n_jobs = n_jobs
         self._n_images = 0
@@ -203,6 +207,14 @@ class Annotator(object):
         # any collective is entered (a rank raising later would leave the others waiting in the all-gather).
         for panel in self._panels_to_impute():
             self._imputer(panel)
+        if self.tile_mode:
+            self.preprocessor.transform(image_filter=lambda i: dist.owns_image(i, rank, ws))
+            self._n_images = len(self.preprocessor.image_ids)      # every per-image list below is indexed by LOCAL position
+            self.logger.log("rank {} of {}: tile-per-rank mode, images {} of {}".format(rank, ws, self.preprocessor.image_ids,
+                                                                                        self.preprocessor._n_images))
+            return
+        if ws > 1 and os.environ.get("RIBCA_NORM_SHARD") == "1":
+            self.preprocessor.norm_shard = (rank, ws)
         self.preprocessor.transform(shard_fn=(lambda n: dist.shard_bounds(n, rank, ws)) if ws > 1 else None,
                                     gather_fn=(lambda t, n: dist.all_gather_rows(t, n)) if ws > 1 else None)
         self._n_images = self.preprocessor._n_images
@@ -263,7 +275,9 @@ class Annotator(object):
         d = distance()
         uses_mx = [k for k in pair if k and _lib.lib().ribca_mx_enabled(self.models[k].D)]
         if uses_mx:
-            rows = torch.nonzero(d < ops.VitModel.RECHECK_MARGIN).flatten()
+            margin = max(self.models[k].recheck_margin for k in uses_mx)      # calibrated per model on its own weights (ops.VitModel)
+            stats["margin"] = margin
+            rows = torch.nonzero(d < margin).flatten()
             if rows.numel():
                 moved = 0.0
                 for k in uses_mx:
@@ -307,12 +321,12 @@ class Annotator(object):
                 self.recheck_stats.append(rs)      # (this rank's shard: the counts are logged per rank, no collective for a log line)
                 msg = ("{} of {} cells lay within {:g} of a decision boundary and were re-evaluated at full operand precision; {} remain within "
                        "{:g} (inside the arithmetic's noise floor: another correct fp32 evaluation may label them differently)."
-                       ).format(rs["re_evaluated"], rs["cells"], ops.VitModel.RECHECK_MARGIN, rs["within_noise_floor"], self.NOISE_FLOOR)
+                       ).format(rs["re_evaluated"], rs["cells"], rs.get("margin", ops.VitModel.RECHECK_MARGIN), rs["within_noise_floor"], self.NOISE_FLOOR)
                 if "max_fast_minus_full_precision" in rs:
                     msg += " Largest move of a confidence under the re-evaluation: {:.1e} (margin {:g}).".format(rs["max_fast_minus_full_precision"],
-                                                                                                                 ops.VitModel.RECHECK_MARGIN)
+                                                                                                                 rs.get("margin", ops.VitModel.RECHECK_MARGIN))
                 self.logger.log(msg if self.world_size == 1 else "rank {}: {}".format(self.rank, msg))
-            if self.world_size > 1:
+            if self.world_size > 1 and not self.tile_mode:
                 # ONE all-gather per image: the models' probability columns side by side (<= 33 floats per cell), SURVEY 8(e)
                 names = list(tables)
                 widths = [tables[k].shape[1] for k in names]
@@ -385,6 +399,12 @@ class Annotator(object):
         seen = set()
         for per_image in self.annotations:
             seen.update(per_image)
+        if self.tile_mode:
+            # the reference's list covers every image of the batch (model.py:678-686): the union over the ranks, as an 18-entry presence
+            # vector (the only exchange of a tile-per-rank run: control plane, 144 bytes)
+            present = torch.tensor([1 if name in seen else 0 for name in ops.GLOBAL_NAMES], dtype=torch.int64)
+            present = dist.all_reduce_sum(present)
+            seen = {name for name, p in zip(ops.GLOBAL_NAMES, present.tolist()) if p > 0}
         return np.sort(np.array(list(seen)))
 
     def get_cell_type_names(self):
@@ -397,11 +417,13 @@ class Annotator(object):
     def export_annotations(self):
         """model.py:768-795: same header, columns, rounding and number formatting."""
         if len(self.annotations) == 0:
+            if self.tile_mode and self.preprocessor._n_images > 0:
+                return       # a rank that owns no image of the batch has nothing to write
             raise ValueError("No annotations to export")
-        if self.rank != 0:
+        if self.rank != 0 and not self.tile_mode:
             return
         for i in range(len(self.annotations)):
-            path = os.path.join(self.result_dir, f"{self.batch_id}_annotation_{i}.csv")
+            path = os.path.join(self.result_dir, f"{self.batch_id}_annotation_{self._image_number(i)}.csv")
             ids = self.preprocessor.cell_ids[i]
             tab = self.preprocessor.cell_tables[i]
             conf = self.confidence[i]
@@ -429,6 +451,22 @@ class Annotator(object):
                     reg = regions[i]
                     f.write("".join([f"{k},{l},{c},{r},{cc},Region {reg[k]}\n" for k, l, c, r, cc in zip(keys, labs, conf_txt, rl, cl)]))
             self.logger.log(f"Exported annotations for image {i} to {path}")
+
+    def min_cells_per_image(self) -> int:
+        """fewest cells in any image of the batch (what the reference's k-NN calls need to exceed); in tile-per-rank mode the minimum over
+        every rank's images, so that all ranks take the same branches of the pipeline (main._pipeline)"""
+        n = min((len(ids) for ids in self.preprocessor.cell_ids), default=0)
+        return dist.all_reduce_min_int(n) if self.tile_mode else n
+
+    def _image_number(self, i: int) -> int:
+        """row of the batch CSV that local position i holds: i itself except in tile-per-rank mode (file names carry the batch-wide number)"""
+        ids = self.preprocessor.image_ids
+        return ids[i] if i < len(ids) else i
+
+    def _writes_files(self) -> bool:
+        """rank 0 writes everything in cell-sharded runs (every rank holds the same tables after the all-gather); in tile-per-rank mode
+        every rank writes the files of its own images"""
+        return self.rank == 0 or self.tile_mode
 
     def clear_tmp(self):
         for f in os.listdir(self.temp_dir):
@@ -458,21 +496,22 @@ class Annotator(object):
         from PIL import Image
         for i in range(len(self.preprocessor.masks)):
             type_rgb, conf_rgb, type_idx = (t.cpu().numpy() for t in self.paint(i))
-            if self.rank != 0:
+            if not self._writes_files():
                 continue
-            Image.fromarray(type_rgb).save(os.path.join(self.result_dir, f"{self.batch_id}_colorized_annotation_{i}.png"))
+            num = self._image_number(i)
+            Image.fromarray(type_rgb).save(os.path.join(self.result_dir, f"{self.batch_id}_colorized_annotation_{num}.png"))
             if not from_script:            # napari working file of the reference GUI (model.py:845-847), only inside its source tree
                 gui_dir = "./src/multiplexed_image_annotator/cell_type_annotation/_working_dir_temp"
                 if os.path.isdir(gui_dir):
                     Image.fromarray(type_idx).save(os.path.join(gui_dir, "output_img.png"))
-            Image.fromarray(conf_rgb).save(os.path.join(self.result_dir, f"{self.batch_id}_confidence_{i}.png"))
+            Image.fromarray(conf_rgb).save(os.path.join(self.result_dir, f"{self.batch_id}_confidence_{num}.png"))
             if self.n_regions > 0:             # model.py:823-855: region colours from the same palette, silver last
                 pre = self.preprocessor
                 ids = pre.cell_ids[i]
                 region = np.array([self.tissue_regions[i][int(k)] for k in ids.tolist()], dtype=np.int64)
                 palette = np.array(colors.get_colors(self.n_regions + 1), dtype=np.uint8)
                 t_rgb, _, t_idx = ops.colorize(pre.masks_dev[i], ids, palette[region], palette[region], (region + 1).astype(np.uint8))
-                Image.fromarray(t_rgb.cpu().numpy()).save(os.path.join(self.result_dir, f"{self.batch_id}_tissue_region_{i}.png"))
+                Image.fromarray(t_rgb.cpu().numpy()).save(os.path.join(self.result_dir, f"{self.batch_id}_tissue_region_{num}.png"))
                 if not from_script and os.path.isdir("./src/multiplexed_image_annotator/cell_type_annotation/_working_dir_temp"):
                     Image.fromarray(t_idx.cpu().numpy()).save("./src/multiplexed_image_annotator/cell_type_annotation/_working_dir_temp/output_img_2.png")
 
@@ -501,11 +540,15 @@ class Annotator(object):
         groups = [list(range(self._n_images))] if integrate else [[i] for i in range(self._n_images)]
         for g, idx in enumerate(groups):
             m = self.neighborhood_matrix(idx, n_neighbors)
+            if integrate and self.tile_mode:
+                # the integrated matrix sums over ALL images of the batch: T x T counts from every rank (cell_types are per rank in this
+                # mode, so the type axes must agree: guaranteed when the ranks see the same label set, checked through the matrix shape)
+                m = dist.all_reduce_sum(torch.from_numpy(m)).numpy()
             if normalize:
                 sums = m.sum(axis=1, keepdims=True)
                 m = np.divide(m, sums, out=m.copy(), where=sums > 0)
-            name = f"{self.batch_id}_integrated_neighborhood.csv" if integrate else f"{self.batch_id}_neighborhood_{g}.csv"
-            if self.rank == 0:
+            name = f"{self.batch_id}_integrated_neighborhood.csv" if integrate else f"{self.batch_id}_neighborhood_{self._image_number(g)}.csv"
+            if self.rank == 0 or (self.tile_mode and not integrate):
                 with open(os.path.join(self.result_dir, name), "w") as f:
                     f.write("cell_type," + "".join(f"{c}," for c in self.cell_types) + "\n")
                     for r, c in enumerate(self.cell_types):

@@ -19,10 +19,13 @@ LIB_DIAG = os.path.join(HERE, "libribca_hip_diag.so")
 LIB_TEST = os.path.join(HERE, "libribca_hip_test.so")
 LIB_TEST_DIAG = os.path.join(HERE, "libribca_hip_diag_test.so")
 TEST_SOURCES = ["ribca_test_api.hip"]
+EXPORTS = os.path.join(CSRC, "exports.map")
 SOURCES = ["gemm_split16.hip", "gemm_duo.hip", "gemm_mx.hip", "attention.hip", "cell_attention.hip", "vit_misc.hip", "preprocess.hip", "preprocess_scaled.hip", "vote.hip", "colorize.hip", "knn.hip", "normalize.hip", "ribca_api.hip"]
-HEADERS = ["ribca_common.h", "ribca_kernels.h", "ribca_status.h", "gemm_epi.h", os.path.join("..", "..", "include", "ribca_hip.h"),
+HEADERS = ["ribca_common.h", "ribca_kernels.h", "ribca_status.h", "ribca_internal.h", "gemm_epi.h", os.path.join("..", "..", "include", "ribca_hip.h"),
            os.path.join("..", "..", "include", "ribca_hip_test.h")]
-FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# -fvisibility=hidden: the dynamic symbol table of either library is what its header declares between `#pragma GCC visibility push(default)` and
+# `pop` -- no C++ launcher, kernel stub or template instantiation is exported (tests/test_abi.py compares the full `nm -D` list with the header)
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fvisibility=hidden", "-fvisibility-inlines-hidden"]
 
 
 def source_fingerprint() -> str:
@@ -82,15 +85,17 @@ def build(force: bool = False, verbose: bool = True, diag: bool = False) -> str:
         res = list(ex.map(compile_one, srcs))
     objs = [o for (o, _), src in zip(res, srcs) if src not in TEST_SOURCES]
     test_objs = [o for (o, _), src in zip(res, srcs) if src in TEST_SOURCES]
-    if force or _stale(lib_path, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-soname," + os.path.basename(lib_path), "-o", lib_path] + objs
+    if force or _stale(lib_path, objs + [EXPORTS]):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-soname," + os.path.basename(lib_path), "-Wl,--version-script=" + EXPORTS, "-o", lib_path] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
     test_path = LIB_TEST_DIAG if diag else LIB_TEST
-    if force or _stale(test_path, test_objs + [lib_path]):
+    if force or _stale(test_path, test_objs + [lib_path, EXPORTS]):
         libname = os.path.basename(lib_path)[3:-3]
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", test_path] + test_objs + ["-L" + HERE, "-l" + libname, "-Wl,-rpath,$ORIGIN"]
+        # --no-undefined: the hooks reach the product library through its C entry points (ribca_internal_table) only; a stray direct reference to a
+        # hidden launcher fails HERE, not at dlopen on the GPU box
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--no-undefined", "-Wl,--version-script=" + EXPORTS, "-o", test_path] + test_objs + ["-L" + HERE, "-l" + libname, "-Wl,-rpath,$ORIGIN"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))

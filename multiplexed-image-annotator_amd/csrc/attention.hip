@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       uint4 h4 = {0u, 0u, 0u, 0u}, l4 = {0u, 0u, 0u, 0u};
-      if (ks * 4 + 3 < ngrp || ks * 4 + g < ngrp) {
+      if ((ks * 4 + 3 < ngrp || ks * 4 + g < ngrp) && qt * 16 + r16 < T) {      // (pad query rows: zeros, never fetched; their output is not stored)
         const uint4* p = reinterpret_cast<const uint4*>(qb + (size_t)(qt * 16 + r16) * ROW + (ks * 4 + g) * 16);
         h4 = p[0]; l4 = p[1];
       }
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
 // keys {32 t + 4 g + r, 32 t + 16 + 4 g + r} of head dim 16 dt + d.  ds_read_b64_tr_b16 hands the 16 lanes of group g a 4-row x
 // 16-column block of 16-bit elements column-major (lane 4q + p supplies the address of row q, columns 4p .. 4p + 3; lane i receives
 // column i of the four rows): one read per key quartet, hi and lo halves separately = 4 reads per (dt, t) where the V^T form had two
-// 16-byte ones.  Rows 101 .. 111 are zero in memory (never written), rows 112 .. 127 are zeroed in LDS: their P is exactly 0.
+// 16-byte ones.  Rows 101 .. 111 lie beyond the staging descriptor's range and arrive as zeros (never fetched), rows 112 .. 127 are zeroed in LDS: their P is exactly 0.
 typedef __attribute__((__vector_size__(4 * sizeof(_Float16)))) _Float16 f16x4;
 typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4;
 __device__ __forceinline__ f16x4 lds_read_tr16(const char* p) {
@@ -197,17 +197,17 @@ __global__ __launch_bounds__(64 * WPP) void attention_lds_kernel(const uint16_t*
   const char* kb = reinterpret_cast<const char*>(K + (size_t)pair * TP * ROW);
   const char* vb = reinterpret_cast<const char*>(V + (size_t)pair * TP * ROW);
 
-  // ---- stage K and V: 1 KB per wave instruction, linear.  (Behind V's rows: zeros, written before the copies are issued; the tail
-  // piece of the copy re-reads the last chunk of row TP - 1, a pad token row that is zero in memory, so both leave zeros.)
+  // ---- stage K and V: 1 KB per wave instruction, linear, through a buffer descriptor that ends behind token row T - 1: the pad rows
+  // T .. TP - 1 (101 .. 111: a tenth of the operand) are out of its range, so they arrive in LDS as zeros WITHOUT being fetched -- this
+  // kernel runs at its HBM roof (5.6 TB/s at head dim 48), bytes are its only lever.  (Behind V's rows: zeros, written before the copies
+  // are issued; the tail piece of a copy lies wholly or partly beyond the range and leaves zeros as well.)
   for (int o = K_BYTES / 1024 * 1024 + threadIdx.x * 16; o < V_LDS; o += 64 * WPP * 16)
     *reinterpret_cast<uint4*>(lds + K_LDS + o) = uint4{0u, 0u, 0u, 0u};
   __syncthreads();
-  for (int i = wave; i < K_LDS / 1024; i += WPP) {
-    int off = i * 1024 + lane * 16;
-    off = off < K_BYTES ? off : K_BYTES - 16;        // the tail instruction re-reads the last chunk into LDS padding
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + off),
-                                     (__attribute__((address_space(3))) void*)(lds + i * 1024), 16, 0, 0);
-  }
+  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kb), 0, T * ROWB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vb), 0, T * ROWB, 0x00020000);
+  for (int i = wave; i < K_LDS / 1024; i += WPP)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(lds + i * 1024), 16, i * 1024 + lane * 16, 0, 0, 0);
   // Bank swizzle of the V image (HD = 32 only: 128-byte rows put every second row on the same banks, and a transposed read spans 8
   // rows per half wave: SQ_LDS_BANK_CONFLICT 0.31 of the kernel's cycles without it).  The copy is linear in LDS, so the XOR is applied
   // to the GLOBAL source address: LDS chunk p of row r holds the row's 16-byte chunk p ^ vswz(r).
@@ -215,9 +215,7 @@ __global__ __launch_bounds__(64 * WPP) void attention_lds_kernel(const uint16_t*
   for (int i = wave; i < V_DMA / 1024; i += WPP) {
     int off = i * 1024 + lane * 16;
     if (HD == 32) { const int row = off / ROWB, ch = (off % ROWB) >> 4; off = row * ROWB + ((ch ^ vswz(row)) << 4); }
-    off = off < K_BYTES ? off : K_BYTES - 16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb + off),
-                                     (__attribute__((address_space(3))) void*)(lds + K_LDS + i * 1024), 16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(lds + K_LDS + i * 1024), 16, off, 0, 0, 0);
   }
   // first Q tile of this wave while the copies fly
   auto load_q = [&](int qt, f16x8 (&qh)[KS], f16x8 (&ql)[KS]) __attribute__((always_inline)) {

@@ -12,6 +12,7 @@
 
 #include "../../include/ribca_hip.h"
 #include "ribca_common.h"
+#include "ribca_internal.h"
 #include "ribca_kernels.h"
 #include "ribca_status.h"
 
@@ -520,6 +521,19 @@ extern "C" {
 
 int ribca_version(void) { return 100; }
 const char* ribca_last_error(void) { return api_last_error(); }
+
+// the launcher table of libribca_hip_test.so (csrc/ribca_internal.h): the only way into the library besides the C entry points
+const void* ribca_internal_table(int32_t version) {
+  static const InternalTable table = {RIBCA_INTERNAL_VERSION,
+#define RIBCA_X(name) +1
+                                      0 RIBCA_INTERNAL_FUNCS(RIBCA_X),
+#undef RIBCA_X
+#define RIBCA_X(name) &ribca::name,
+                                      RIBCA_INTERNAL_FUNCS(RIBCA_X)
+#undef RIBCA_X
+  };
+  return version == RIBCA_INTERNAL_VERSION ? &table : nullptr;
+}
 
 int32_t ribca_mx_enabled(int32_t D) { return mx_on(D) ? 1 : 0; }
 int32_t ribca_mxz_enabled(int32_t D) { return mx_z_on(D) ? 1 : 0; }

@@ -473,6 +473,38 @@ class VitModel:
             torch.cuda.current_stream().synchronize()  # the blob may be freed once packing has finished
         self._h = handle
         self.flops_per_cell = float(lib().ribca_vit_flops_per_cell(self._h))
+        self.probe_fast_minus_full = 0.0
+        self._margin = 0.0
+        if lib().ribca_mx_enabled(self.D) and os.environ.get("RIBCA_MARGIN_PROBE", "1") != "0":
+            self._calibrate_margin()
+
+    # ---- the re-evaluation margin is measured on the weights, not assumed (round 6) -------------------------------------------------
+    PROBE_CELLS = 64
+    PROBE_FACTOR = 16.0
+
+    def _calibrate_margin(self) -> None:
+        """What the margin-gated re-evaluation rests on is |fast - full precision| <= margin / 4 for every cell (a cell the fast path places
+        outside the margin cannot cross a boundary at full precision).  On the uniform synthetic family that distance is 1-3e-5 and the
+        1e-3 floor holds it 40 times over; weights with heavy tails, LayerNorm gains two decades apart or massive-activation channels --
+        what trained ViTs have (synth.make_vit_state_dict_heavy) -- move the block-scaled correction products by 3-6e-4.  So the distance is
+        MEASURED once per model, at load time, on a fixed synthetic probe (PROBE_CELLS patches: background -1, sparse positive signal; the
+        same cells whatever the image, the rank or the chunk, so a cell's treatment never depends on where it was computed), and the
+        margin is max(RECHECK_MARGIN, PROBE_FACTOR x the probe's largest distance): 16 x = 4 (the premise) x 4 (64 probe cells against
+        the largest of 100 k).  Costs two 64-cell forwards per model."""
+        g = torch.Generator().manual_seed(0x5249424341)
+        u = torch.rand((self.PROBE_CELLS, self.C, PATCH, PATCH), generator=g, dtype=torch.float32) * 2.0 - 1.0
+        x = torch.where(u > 0.1, u, torch.full_like(u, -1.0)).to(self.device)
+        with torch.cuda.device(self.device):
+            src = list(range(self.C))
+            fast = self._forward(x, src, chunk_cells=self.PROBE_CELLS, precise=False)
+            full = self._forward(x, src, chunk_cells=self.PROBE_CELLS, precise=True)
+            self.probe_fast_minus_full = float((fast - full).abs().max().item())
+        self._margin = self.PROBE_FACTOR * self.probe_fast_minus_full
+
+    @property
+    def recheck_margin(self) -> float:
+        """cells whose fast result lies this close to a decision boundary are re-evaluated at full operand precision"""
+        return max(float(type(self).RECHECK_MARGIN), self._margin)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -485,15 +517,25 @@ class VitModel:
 
     # Cells whose fast (MX) result lies this close to a decision boundary are re-evaluated with three fp16 passes per product.  The MX
     # pair moves softmax outputs by 2-4e-5 against the fp16x3 path (measured; 1e-4 class with every product in that form, emulated):
-    # 1e-3 leaves an order of magnitude, and is the north star's own confidence tolerance.
+    # 1e-3 leaves an order of magnitude, and is the north star's own confidence tolerance.  It is the FLOOR of the margin: the margin a
+    # model actually uses is ``recheck_margin`` (calibrated on the model's own weights at load time, _calibrate_margin).
     RECHECK_MARGIN = 1.0e-3
 
     #: width -> multiple of the caller's chunk_cells a forward of that width uses (RIBCA_CHUNK_SCALE=<n> overrides it for every width: A/B)
     CHUNK_SCALE = {576: 4}
 
+    #: the scaled chunk never exceeds this many cells (the workspace of a 576-wide forward is ~ 3.9 MB per cell and there is one per segment
+    #: stream: 4096 cells x 3 streams = 48 GB of the 288; a caller that asks for more than this itself gets what it asked for, unscaled)
+    MAX_SCALED_CHUNK = 4096
+
     def chunk_scale(self) -> int:
         env = os.environ.get("RIBCA_CHUNK_SCALE")
         return max(1, int(env)) if env else self.CHUNK_SCALE.get(self.D, 1)
+
+    def effective_chunk(self, chunk_cells: int) -> int:
+        """cells per launch sequence a forward of this width really uses for a caller's ``chunk_cells`` (bench.py reports it per model)"""
+        c = max(1, int(chunk_cells))
+        return max(c, min(c * self.chunk_scale(), self.MAX_SCALED_CHUNK))
 
     def predict_proba(self, patches: torch.Tensor, src_chan: Sequence[int], chunk_cells: int = 1024, ws_slot: int = 0,
                       streams: int = 1, recheck: Optional[Sequence[float]] = None) -> torch.Tensor:
@@ -515,7 +557,7 @@ class VitModel:
                     m |= (top[:, 0] - float(t)).abs() < eps
             return m
 
-        idx = torch.nonzero(near(probs, self.RECHECK_MARGIN)).flatten()
+        idx = torch.nonzero(near(probs, self.recheck_margin)).flatten()
         if idx.numel():
             again = self._forward(patches.index_select(0, idx), src_chan, chunk_cells, ws_slot, 1, precise=True)
             probs.index_copy_(0, idx, again)
@@ -544,7 +586,7 @@ class VitModel:
         # workgroups and lose a twentieth each to the partial last round plus a fixed 39 us of ramp (profiles/r5/mx_rounds.txt): it takes
         # CHUNK_SCALE times the caller's chunk (same-box sweep, profiles/r5/chunk_streams_full.txt: 39.3-39.9 -> 40.4-41.3 k cells/s at 4 x;
         # the narrower classifiers measured flat or slightly worse).  Results do not depend on the chunk size (test_classifier_bitwise_repeatable).
-        chunk = max(1, min(int(chunk_cells) * self.chunk_scale(), n))
+        chunk = max(1, min(self.effective_chunk(chunk_cells), n))
         src = torch.tensor(list(src_chan), dtype=torch.int32, device=patches.device)
         nbytes = lib().ribca_vit_workspace_bytes(self._h, chunk)
         patches = patches.contiguous()

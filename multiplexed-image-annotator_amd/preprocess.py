@@ -285,9 +285,18 @@ def _read_tiff(path: str) -> np.ndarray:
         return out
     if expect is not None:
         planes_found = len(same) * (first["spp"] if first["spp"] > 1 else 1)
-        if planes_found != expect:
-            # (no fallback either: a multi-series OME file read page by page by another decoder would mix the series into one image)
-            raise TiffStackError(f"{path}: the description announces {expect} channel planes, the file holds {planes_found}")
+        if planes_found > expect and first["spp"] == 1:
+            # more same-shape pages than the description's SizeC / images: the first series is the first `expect` of them (what tifffile's
+            # imread returns for such a file); the extra pages belong to something else (a second series, a thumbnail without the flag)
+            same = same[:expect]
+        elif planes_found != expect:
+            # FEWER planes than announced (or a count that pixel-interleaved pages cannot make up): e.g. a multi-file OME dataset whose
+            # SizeC counts planes held in companion files, which this reader does not follow.  No fallback either: another decoder reading
+            # page by page would return a partial image as if it were complete.  Stricter than the reference's tifffile path, which follows
+            # the companions (deviations).
+            raise TiffStackError(f"{path}: the description announces {expect} channel planes, the file holds {planes_found} "
+                                 f"({len(same)} page(s) of shape {first['shape']}, {first['dt']}; {len(layouts) - len(same)} page(s) of another shape): "
+                                 "planes kept in companion files of a multi-file OME dataset are not read -- export one (C, H, W) file")
     if len(same) == 1:
         out = np.zeros(first["shape"], dtype=nat)
         decode_into(first, out)
@@ -388,6 +397,11 @@ class ImageProcessor(object):
         self.patches: List[Optional[torch.Tensor]] = []     # (n_local, C_img, 40, 40) fp32 per image, this rank's cells
         self.cell_ids_dev: List[torch.Tensor] = []          # per image: ascending cell ids int32 [n] / boxes int32 [n, 4] on the device
         self.cell_bbox_dev: List[torch.Tensor] = []
+        # multi-rank runs (set by Annotator.preprocess): image_ids[j] = row of the batch CSV that local position j holds (tile-per-rank mode
+        # keeps only this rank's images; every per-image list above is indexed by local position); norm_shard = (rank, world_size) when the
+        # whole-image normalisation is split by channel with one all-gather of the planes (cell-sharded mode, RIBCA_NORM_SHARD=1)
+        self.image_ids: List[int] = []
+        self.norm_shard: Optional[Tuple[int, int]] = None
         self._log("\n")
         self._log("Starting image processing...")
 
@@ -397,7 +411,19 @@ class ImageProcessor(object):
 
     # ---- stage kernels ---------------------------------------------------------------------------------------------
     def _normalize(self, img, blur=0, amax=100) -> torch.Tensor:
-        return ops.normalize_image(img, blur=blur, amax=amax)
+        if self.norm_shard is None:
+            return ops.normalize_image(img, blur=blur, amax=amax)
+        # every channel is normalised on its own (background filter, percentile, scale: preprocess.py:216-238), so a rank can do
+        # ceil(C / world) of them and the planes are exchanged once -- bit-identical to the replicated form
+        from . import dist
+        rank, ws = self.norm_shard
+        c = img.shape[0]
+        lo, hi = dist.shard_bounds(c, rank, ws)
+        if hi > lo:
+            local = ops.normalize_image(img[lo:hi], blur=blur, amax=amax)
+        else:
+            local = torch.empty((0,) + tuple(img.shape[1:]), dtype=torch.float32, device=_lib.require_gpu())
+        return dist.all_gather_planes(local, c)
 
     def _cell_pos_dict(self, mask, n_jobs=0) -> LazyCellPositions:
         mask_np = np.asarray(mask).astype(np.int32)
@@ -417,11 +443,16 @@ class ImageProcessor(object):
                                    want_avg=want_avg, out=out, patch_size=self.patch_size)
 
     # ---- reference entry point -------------------------------------------------------------------------------------
-    def transform(self, shard_fn=None, gather_fn=None, keep_patches: bool = True, chunk: int = 16384):
+    def transform(self, shard_fn=None, gather_fn=None, keep_patches: bool = True, chunk: int = 16384, image_filter=None):
         """preprocess.py:241-290.  ``shard_fn(n) -> (lo, hi)`` picks this rank's cells (default: all);
-        ``gather_fn(local (n_local, C) fp64 tensor, n) -> (n, C)`` reassembles per-cell rows across ranks."""
+        ``gather_fn(local (n_local, C) fp64 tensor, n) -> (n, C)`` reassembles per-cell rows across ranks;
+        ``image_filter(i) -> bool`` keeps only some rows of the batch CSV (tile-per-rank mode: ``image_ids`` records which)."""
         dev = _lib.require_gpu()
         for i, (image_path, mask_path) in enumerate(zip(self.image_paths, self.mask_paths)):
+            if image_filter is not None and not image_filter(i):
+                continue
+            self.image_ids.append(i)
+            j = len(self.image_ids) - 1                  # LOCAL position: every per-image list below is indexed by it
             image = as_channel_planes(read_image(image_path), image_path)
             mask = read_image(mask_path)
             if mask.ndim == 3:
@@ -457,7 +488,7 @@ class ImageProcessor(object):
             avg = torch.empty((hi - lo, c_img), dtype=torch.float64, device=dev)
             for c0 in range(lo, hi, chunk):
                 c1 = min(c0 + chunk, hi)
-                _, a = self.crop_cells(i, c0, c1, want_avg=True, out=kept[c0 - lo:c1 - lo] if keep_patches else None)
+                _, a = self.crop_cells(j, c0, c1, want_avg=True, out=kept[c0 - lo:c1 - lo] if keep_patches else None)
                 avg[c0 - lo:c1 - lo] = a
             if gather_fn is not None:
                 avg = gather_fn(avg, n)

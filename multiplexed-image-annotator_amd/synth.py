@@ -158,6 +158,64 @@ def make_vit_state_dict(name: str, seed: int, depth: int = VIT_DEPTH, head_gain:
     return sd
 
 
+def make_vit_state_dict_heavy(name: str, seed: int, depth: int = VIT_DEPTH, head_gain: float = 4.0, lin_gain: float = 2.0,
+                              gamma_max: float = 5.0, outlier_channels: int = 4, outlier_gain: float = 50.0) -> Dict[str, torch.Tensor]:
+    """A second weight family for the parity audits (same keys as ``make_vit_state_dict``): what trained ViTs have and the uniform
+    family lacks.  No checkpoint of the reference can be loaded here (download_models.py:7-24 needs the network), so this is the stand-in
+    for model.py:188-239's real weights:
+
+    * linear weights Student-t(3), unit variance x Xavier std x ``lin_gain``: heavy tails -- single weights 10-30 sigma out, so a 32-wide
+      block of the MX weight image holds one value far above the rest (the small ones lose bits under the shared block scale);
+    * LayerNorm gains log-uniform in [1 / gamma_max, gamma_max]: per-channel scales two decades apart inside the folded weight gamma o W;
+    * ``outlier_channels`` residual channels carry ``outlier_gain`` x the others through ``pos_embed`` / ``cls_token``: massive
+      activations -- one |x| >> the rest inside a 32-column MX3 block of the residual rows, rows with |mean| / std >> 1.
+
+    ``lin_gain`` = 2 gives the linears the uniform family's variance; the net stays in the non-chaotic regime (the fp32 forward sits
+    1-2e-5 from the fp64 one: tests/precision_study.py --family heavy prints it) and the outputs still depend on the cell (2-4 classes
+    in use per classifier; with lin_gain 1 the outlier channels saturate every cell to one class).
+    """
+    d, c, k = VIT_CONFIGS[name]
+    sd = make_vit_state_dict(name, seed, depth=depth, head_gain=head_gain)
+    tag = name + "/heavy/"
+
+    def student_t3(key_name, shape):
+        n = int(math.prod(shape))
+        num = approx_normal(stream_key(seed, tag + key_name + "/n"), n)
+        den = torch.zeros(n, dtype=torch.float64)
+        for j in range(3):
+            den += approx_normal(stream_key(seed, tag + key_name + f"/d{j}"), n) ** 2
+        t = num / torch.sqrt(den / 3.0).clamp_min(1e-3)
+        return (t / math.sqrt(3.0)).reshape(shape)          # variance of t(3) is 3
+
+    def heavy_linear(key_name, out_f, in_f):
+        std = lin_gain * math.sqrt(2.0 / (in_f + out_f))
+        return (student_t3(key_name, (out_f, in_f)) * std).to(torch.float32)
+
+    def gamma(key_name):
+        u = uniform(stream_key(seed, tag + key_name), d)
+        return torch.exp((2.0 * u - 1.0) * math.log(gamma_max)).to(torch.float32)
+
+    for i in range(depth):
+        p = f"blocks.{i}."
+        sd[p + "norm1.weight"] = gamma(p + "norm1.weight")
+        sd[p + "norm2.weight"] = gamma(p + "norm2.weight")
+        sd[p + "attn.qkv.weight"] = heavy_linear(p + "attn.qkv.weight", 3 * d, d)
+        sd[p + "attn.proj.weight"] = heavy_linear(p + "attn.proj.weight", d, d)
+        sd[p + "mlp.fc1.weight"] = heavy_linear(p + "mlp.fc1.weight", 4 * d, d)
+        sd[p + "mlp.fc2.weight"] = heavy_linear(p + "mlp.fc2.weight", d, 4 * d)
+    sd["norm.weight"] = gamma("norm.weight")
+    # the massive-activation channels: distinct, spread over the width
+    picks = hash_u24(stream_key(seed, tag + "outliers"), torch.arange(outlier_channels, dtype=torch.int64))
+    chans = sorted({int((int(v) + 37 * j) % d) for j, v in enumerate(picks.tolist())})
+    for ch in chans:
+        sd["pos_embed"][..., ch] *= outlier_gain
+        sd["cls_token"][..., ch] *= outlier_gain
+    return sd
+
+
+WEIGHT_FAMILIES = {"uniform": make_vit_state_dict, "heavy": make_vit_state_dict_heavy}
+
+
 #: imputer panels: name -> number of channel tokens L (reference markerImputer.py:260-274)
 MAE_PANELS: Dict[str, int] = {"immune_full": 15, "immune_extended": 10, "immune_base": 7}
 

@@ -294,6 +294,8 @@ def main():
     ap.add_argument("--schemes", nargs="+", default=["bf16x3", "f16", "f16_bf8t", "f16_bf8r", "f16_fp8", "f16_fp6"])
     ap.add_argument("--seed", type=int, default=synth.SEED_BASE + 7)
     ap.add_argument("--linears", nargs="+", default=["wqkv", "wproj", "w1", "w2"], help="weights that take an mx* scheme (others: f16x3)")
+    ap.add_argument("--family", choices=sorted(synth.WEIGHT_FAMILIES), default="uniform",
+                    help="synthetic weight family: uniform (Xavier-uniform, LN gains near 1) or heavy (Student-t(3) weights, LN gains up to 5, outlier residual channels)")
     ap.add_argument("--zstream", choices=["fp32", "ps", "mx3"], default="fp32", help="storage format of the residual stream between residual GEMMs")
     args = ap.parse_args()
     global ZSTREAM
@@ -302,14 +304,20 @@ def main():
     LINEARS.update(args.linears)
     torch.set_num_threads(os.cpu_count() or 1)
     for name in args.models:
-        sd = synth.make_vit_state_dict(name, args.seed)
+        sd = synth.WEIGHT_FAMILIES[args.family](name, args.seed)
         x = patch_like_inputs(name, args.cells, args.seed + 1)
         t0 = time.time()
         ref = torch.cat([F.softmax(ref_vit.logits(sd, x[i:i + args.batch]), dim=1) for i in range(0, args.cells, args.batch)])
         srt = ref.sort(dim=1, descending=True).values
         margin = (srt[:, 0] - srt[:, 1])
-        print(f"{name}: {args.cells} cells, fp32 reference {time.time() - t0:.1f} s; top-2 margin min {margin.min():.2e} "
+        print(f"{name} [{args.family}]: {args.cells} cells, fp32 reference {time.time() - t0:.1f} s; top-2 margin min {margin.min():.2e} "
               f"median {margin.median():.3f}", flush=True)
+        # the reference's own distance from exact arithmetic: what no other correct evaluation can be expected to reproduce
+        sd64 = {k_: v_.to(torch.float64) for k_, v_ in sd.items()}
+        n64 = min(args.cells, 128)
+        ref64 = torch.cat([F.softmax(ref_vit.logits(sd64, x[i:i + args.batch].to(torch.float64)), dim=1) for i in range(0, n64, args.batch)])
+        d64 = (ref[:n64].to(torch.float64) - ref64).abs()
+        print(f"  fp32 vs fp64   max|dp| {d64.max():.2e}  mean|dp| {d64.mean():.2e}   ({n64} cells)", flush=True)
         for scheme in args.schemes:
             t0 = time.time()
             if scheme.startswith("alloc"):

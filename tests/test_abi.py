@@ -17,7 +17,19 @@ def declared_symbols(header="ribca_hip.h"):
 def exported_symbols(path):
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
-    return sorted(l.split()[-1] for l in out.splitlines() if " T ribca_" in l)
+    # the FULL dynamic symbol table: every defined symbol of any type -- C++ launchers, kernel handle objects and template instantiations
+    # would show up here (round 5 exported ~ 190 of them beside the C entry points)
+    return sorted(l.split()[-1] for l in out.splitlines() if l.strip())
+
+
+def lib_table_versions_agree(_lib):
+    """ribca_internal_table(v) is non-NULL exactly for the RIBCA_INTERNAL_VERSION the sources state"""
+    text = open(os.path.join(ROOT, "multiplexed-image-annotator_amd", "csrc", "ribca_internal.h")).read()
+    v = int(re.search(r"#define RIBCA_INTERNAL_VERSION (\d+)", text).group(1))
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    handle.ribca_internal_table.restype = ctypes.c_void_p
+    handle.ribca_internal_table.argtypes = [ctypes.c_int32]
+    return bool(handle.ribca_internal_table(v)) and not handle.ribca_internal_table(v + 1) and not handle.ribca_internal_table(0)
 
 
 def test_header_symbols_are_exported_and_bound():
@@ -31,8 +43,11 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(handle, n), f"{n} declared in include/ribca_hip.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in _lib.SIGNATURES"
     assert sorted(_lib.SIGNATURES) == names
-    # the product library exports the product ABI and nothing else with C linkage: no test hook, no A/B switch
+    # the product library exports the product ABI and NOTHING else -- no test hook, no A/B switch, no C++ symbol, no kernel handle
+    # (-fvisibility=hidden + csrc/exports.map); the one entry point beyond the reference-facing ones is ribca_internal_table, the versioned
+    # launcher table of the hook library, declared in the header as outside the stable ABI
     assert exported_symbols(_lib.LIB_PATH) == names
+    assert "ribca_internal_table" in names
     assert _lib.lib().ribca_version() >= 100
 
 
@@ -45,6 +60,12 @@ def test_test_hooks_live_in_their_own_library():
     hooks = declared_symbols("ribca_hip_test.h")
     assert len(hooks) >= 20 and not set(hooks) & set(declared_symbols())
     assert exported_symbols(_lib.TEST_LIB_PATH) == hooks
+    # the hook library needs nothing from the product library but C entry points (it is linked with --no-undefined against them)
+    import subprocess
+    und = subprocess.run(["nm", "-D", "--undefined-only", _lib.TEST_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    wanted = sorted(l.split()[-1] for l in und.splitlines() if "ribca" in l)
+    assert wanted and all(w in declared_symbols() for w in wanted), wanted
+    assert lib_table_versions_agree(_lib)
     assert sorted(_lib.TEST_SIGNATURES) == hooks
     lib = _lib.lib()
     assert lib.ribca_gemm_padded_n(100) in (128, 192)      # resolved through the proxy from the second library (no GPU needed)

@@ -77,3 +77,45 @@ def test_all_gather_rows_group_of_one_forced_collective():
     out = mgr.dict()
     mp.spawn(_worker_single, args=(1, _free_port(), out), nprocs=1, join=True)
     assert dict(out) == {0: True}
+
+
+def _worker_modes(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multiplexed_image_annotator_amd import dist as rd
+    ok = True
+    # channel-sharded normalisation: planes of a (C, H, W) image, C not a multiple of the world size, a rank with NO plane (C = 1)
+    for c in (1, 3, 15):
+        full = torch.arange(c * 6 * 5, dtype=torch.float32).reshape(c, 6, 5) * 0.5 - 7
+        lo, hi = rd.shard_bounds(c, rank, world)
+        got = rd.all_gather_planes(full[lo:hi].contiguous(), c)
+        ok &= got.shape == full.shape and torch.equal(got, full)
+    # tile-per-rank mode: the control-plane reductions
+    counts = torch.tensor([[1.0, 2.0], [3.0, 4.0]], dtype=torch.float64) * (rank + 1)
+    ok &= torch.equal(rd.all_reduce_sum(counts), torch.tensor([[3.0, 6.0], [9.0, 12.0]], dtype=torch.float64))
+    ok &= torch.equal(counts, torch.tensor([[1.0, 2.0], [3.0, 4.0]], dtype=torch.float64) * (rank + 1))      # the argument is not modified
+    ok &= rd.all_reduce_min_int(40 + 7 * rank) == 40
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_planes_and_tile_mode_reductions_gloo_world2():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_modes, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert dict(out) == {0: True, 1: True}
+
+
+def test_tile_mode_rule_and_image_ownership():
+    """reference main.py:39-52 batch_run: a batch CSV of >= world_size images is split by whole images (round robin), fewer images keep
+    cell sharding; every image has exactly one owner"""
+    from multiplexed_image_annotator_amd.dist import owns_image, tile_mode
+    assert not tile_mode(8, 1) and not tile_mode(1, 8) and not tile_mode(7, 8)
+    assert tile_mode(8, 8) and tile_mode(9, 8) and tile_mode(2, 2)
+    assert tile_mode(1, 8, env="1") and not tile_mode(8, 8, env="0") and tile_mode(8, 8, env="")
+    for ws in (2, 3, 8):
+        for i in range(20):
+            assert sum(owns_image(i, r, ws) for r in range(ws)) == 1
+        assert [i for i in range(10) if owns_image(i, 1, ws)] == list(range(1, 10, ws))

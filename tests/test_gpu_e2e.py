@@ -374,6 +374,122 @@ def test_two_ranks_match_single_rank(tmp_path):
     assert a == b and len(a.splitlines()) == len(one.annotations[0]) + 1
 
 
+def _tile_rank_worker(rank, world, port, root, seed):
+    """One rank of a tile-per-rank run: a batch CSV of three images over two ranks (both on cuda:0 here; gloo for the control plane)."""
+    import torch.distributed as tdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    from multiplexed_image_annotator_amd.annotator import Annotator
+    sd = {m: synth.make_vit_state_dict(m, seed, depth=2) for m in ("immune_base", "struct")}
+    a = Annotator(os.path.join(root, "markers.txt"), os.path.join(root, "images.csv"), "cuda", os.path.join(root, "tiles"), "r", False, False, -1,
+                  True, 0.3, 99.8, 0.3, 30, None)
+    a.set_weights(sd)
+    assert a.tile_mode
+    a.preprocess()
+    assert a.preprocessor.image_ids == [i for i in range(3) if i % world == rank] and a.preprocessor.shards == [(0, len(ids)) for ids in a.preprocessor.cell_ids]
+    a.predict(16)
+    a.export_annotations()
+    a.neighborhood_analysis(n_neighbors=10, integrate=True)
+    a.colorize(from_script=True)
+    with open(os.path.join(root, f"cell_types_rank{rank}.json"), "w") as f:
+        json.dump([str(t) for t in a.cell_types], f)
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_two_ranks_tile_per_rank_match_single_rank(tmp_path):
+    """BASELINE config 5's sharding in small (reference main.py:39-52 batch_run): a batch CSV with at least one image per rank is split by
+    WHOLE images -- replicas only, nothing exchanged on the data path, every rank writes the CSVs / PNGs of its own images under their
+    batch-wide numbers.  Files byte-identical to the single-rank run; the run-wide cell-type list and the integrated neighbourhood matrix
+    (the two things the reference computes over the whole batch) agree as well."""
+    import socket
+    import torch.multiprocessing as mp
+    from multiplexed_image_annotator_amd.annotator import Annotator
+    seed = synth.SEED_BASE + 72
+    markers = ['CD45', 'CD20', 'CD4', 'CD8', 'DAPI', 'CD11c', 'CD3', 'aSMA', 'CD31', 'PanCK', 'Vimentin', 'Ki67']
+    lines = ["image_path,mask_path"]
+    for j, (h, w, n) in enumerate([(208, 240, 91), (176, 200, 60), (240, 192, 75)]):
+        mask, img = synth.make_mask_and_image(h, w, n, len(markers), seed + j)
+        np.save(tmp_path / f"img{j}.npy", img.numpy().astype(np.uint16))
+        np.save(tmp_path / f"mask{j}.npy", mask.numpy().astype(np.int32))
+        lines.append(f"{tmp_path / f'img{j}.npy'},{tmp_path / f'mask{j}.npy'}")
+    (tmp_path / "markers.txt").write_text("\n".join(markers) + "\n")
+    (tmp_path / "images.csv").write_text("\n".join(lines) + "\n")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_tile_rank_worker, args=(2, port, str(tmp_path), seed), nprocs=2, join=True)
+    sd = {m: synth.make_vit_state_dict(m, seed, depth=2) for m in ("immune_base", "struct")}
+    one = Annotator(str(tmp_path / "markers.txt"), str(tmp_path / "images.csv"), "cuda", str(tmp_path / "single"), "r", False, False, -1, True, 0.3, 99.8,
+                    0.3, 30, None)
+    one.set_weights(sd)
+    assert not one.tile_mode
+    one.preprocess()
+    one.predict(16)
+    one.export_annotations()
+    one.neighborhood_analysis(n_neighbors=10, integrate=True)
+    one.colorize(from_script=True)
+    for i in range(3):
+        for name in (f"r_annotation_{i}.csv", f"r_colorized_annotation_{i}.png", f"r_confidence_{i}.png"):
+            a = open(tmp_path / "tiles" / "results" / name, "rb").read()
+            b = open(tmp_path / "single" / "results" / name, "rb").read()
+            assert a == b, name
+    assert open(tmp_path / "tiles" / "results" / "r_integrated_neighborhood.csv").read() == open(tmp_path / "single" / "results" / "r_integrated_neighborhood.csv").read()
+    for r in range(2):
+        assert json.load(open(tmp_path / f"cell_types_rank{r}.json")) == [str(t) for t in one.cell_types]
+
+
+def _norm_shard_worker(rank, world, port, root, seed):
+    os.environ["RIBCA_NORM_SHARD"] = "1"
+    import torch.distributed as tdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    from multiplexed_image_annotator_amd.annotator import Annotator
+    sd = {m: synth.make_vit_state_dict(m, seed, depth=2) for m in ("immune_base", "struct")}
+    a = Annotator(os.path.join(root, "markers.txt"), os.path.join(root, "images.csv"), "cuda", os.path.join(root, "normshard"), "r", False, False, -1,
+                  True, 0.3, 99.8, 0.3, 30, None)
+    a.set_weights(sd)
+    a.preprocess()
+    assert a.preprocessor.norm_shard == (rank, world) and not a.tile_mode
+    np.save(os.path.join(root, f"normalised_rank{rank}.npy"), a.preprocessor.images_dev[0].cpu().numpy())
+    a.predict(16)
+    a.export_annotations()
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_two_ranks_channel_sharded_normalise(tmp_path):
+    """RIBCA_NORM_SHARD=1 (cell-sharded runs): each rank normalises ceil(C / world) channels (reference preprocess.py:214-239 treats every
+    channel on its own) and ONE all-gather of the fp32 planes gives every rank the image -- bit-identical to the replicated form, and the
+    CSV behind it byte-identical to the single-rank run."""
+    import socket
+    import torch.multiprocessing as mp
+    from multiplexed_image_annotator_amd.annotator import Annotator
+    seed = synth.SEED_BASE + 73
+    markers = ['CD45', 'CD20', 'CD4', 'CD8', 'DAPI', 'CD11c', 'CD3', 'aSMA', 'CD31', 'PanCK', 'Vimentin', 'Ki67', 'X1']      # 13 planes over 2 ranks: 6 + 7
+    mask, img = synth.make_mask_and_image(208, 240, 91, len(markers), seed)
+    write_case(tmp_path, img.numpy().astype(np.uint16), mask.numpy().astype(np.int32), markers)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_norm_shard_worker, args=(2, port, str(tmp_path), seed), nprocs=2, join=True)
+    sd = {m: synth.make_vit_state_dict(m, seed, depth=2) for m in ("immune_base", "struct")}
+    one = Annotator(str(tmp_path / "markers.txt"), str(tmp_path / "images.csv"), "cuda", str(tmp_path / "single"), "r", False, False, -1, True, 0.3, 99.8,
+                    0.3, 30, None)
+    one.set_weights(sd)
+    one.preprocess()
+    ref = one.preprocessor.images_dev[0].cpu().numpy()
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"normalised_rank{r}.npy"), ref)
+    one.predict(16)
+    one.export_annotations()
+    assert open(tmp_path / "normshard" / "results" / "r_annotation_0.csv").read() == open(tmp_path / "single" / "results" / "r_annotation_0.csv").read()
+
+
 @pytest.mark.parametrize("case", ["empty", "single", "sparse_odd", "sparse_cs20", "float32", "uint8"])
 def test_edge_inputs_run_end_to_end(tmp_path, case):
     """Empty mask, one cell, non-contiguous labels on an odd-sized tile (borders on all sides), other pixel dtypes, a small cell_size:
@@ -531,7 +647,7 @@ def _config3_inputs(dev, n_cells=100000, seed_offset=3, markers_last=None):
     return seed, mask, image, ids, tab, ops.channel_min(image)
 
 
-def test_config3_parity_audit_2000_cells():
+def _config3_parity_audit(family: str, n_cells: int, out_name: str):
     """at BASELINE config 3's inputs, 2000 cells spread over the tile through ALL FIVE full-depth
     classifiers against the fp32 CPU oracle: cell-type argmax identical, max |dp| under the north-star 1e-3 (and under E2E_TOL),
     plus the top-2 margin histogram SURVEY 8(d) asks to report.  "Identical labels" must have teeth on every model: each head is
@@ -543,7 +659,8 @@ def test_config3_parity_audit_2000_cells():
     dev = _lib.require_gpu()
     seed, mask, image, ids, tab, cmin = _config3_inputs(dev)
     n = len(ids)
-    sel = np.linspace(0, n - 1, 2000).astype(np.int64)
+    sel = np.linspace(0, n - 1, n_cells).astype(np.int64)
+    heavy = family != "uniform"
     ids_d = torch.from_numpy(ids[sel].astype(np.int32)).to(dev)
     bb_d = torch.from_numpy(tab[sel, :4].astype(np.int32)).to(dev)
     patches, _ = ops.extract_patches(image, mask, cmin, ids_d, bb_d)
@@ -552,7 +669,7 @@ def test_config3_parity_audit_2000_cells():
     report = {}
     edges = [0.0, 1e-4, 1e-3, 1e-2, 0.1, 0.3, 0.6, 1.0001]
     for name, (d, c, k) in synth.VIT_CONFIGS.items():
-        sd = synth.make_vit_state_dict(name, seed, head_gain=1.5)
+        sd = synth.WEIGHT_FAMILIES[family](name, seed, head_gain=1.5)
         with torch.no_grad():
             feat = torch.cat([ref_vit.forward_features(sd, x_cpu[i:i + 128, :c]) for i in range(0, len(sel), 128)])
             sd["head.bias"] = synth.calibrate_head_bias(sd, feat[:256])
@@ -566,7 +683,7 @@ def test_config3_parity_audit_2000_cells():
         fast = vm._forward(patches, list(range(c)), 1024, 0, 1, precise=False)
         full = vm._forward(patches, list(range(c)), 1024, 0, 1, precise=True)
         fast_vs_full = (fast - full).abs().max().item()
-        assert fast_vs_full <= ops.VitModel.RECHECK_MARGIN / 4, (name, fast_vs_full)
+        assert fast_vs_full <= vm.recheck_margin / 4, (name, fast_vs_full, vm.recheck_margin, vm.probe_fast_minus_full)
         del fast, full
         srt = ref.sort(dim=1, descending=True).values
         margin = (srt[:, 0] - srt[:, 1]).numpy()
@@ -586,8 +703,9 @@ def test_config3_parity_audit_2000_cells():
                         "flips_where_fp64_sides_with_this_path": ref_wrong, "min_top2_margin": float(margin.min()), "margin_hist_edges": edges,
                         "margin_hist": hist, "classes_used": int(len(torch.unique(ref.argmax(1)))), "cells_with_margin_below_1e-2": int((margin < 1e-2).sum()),
                         "cells_re_evaluated_at_full_precision": vm.last_recheck["cells"], "matrix_units_fc2": 1.75 if (4 * d) % 128 == 0 else 3.0,
-                        "max_abs_fast_minus_full_precision": fast_vs_full, "recheck_margin": ops.VitModel.RECHECK_MARGIN}
-        print(f"[parity audit] {name}: 2000 cells, max|dp| {err:.2e}, flips {flips} (undecidable {undecidable}, fp64 sides with this path on "
+                        "max_abs_fast_minus_full_precision": fast_vs_full, "recheck_margin": vm.recheck_margin,
+                        "probe_fast_minus_full_precision": vm.probe_fast_minus_full, "weight_family": family}
+        print(f"[parity audit, {family} weights] {name}: {n_cells} cells, margin {vm.recheck_margin:.1e} (probe {vm.probe_fast_minus_full:.1e}), max|dp| {err:.2e}, flips {flips} (undecidable {undecidable}, fp64 sides with this path on "
               f"{ref_wrong}), top-2 margin min {margin.min():.2e} hist {hist}; |fast - full precision| {fast_vs_full:.1e}", file=sys.__stdout__, flush=True)
         # identical labels wherever the reference's own margin exceeds twice the measured confidence error; a handful of ties within
         # the fp32 noise floor may fall either way (and do so between the fp32 and the fp64 CPU forward as well)
@@ -595,7 +713,8 @@ def test_config3_parity_audit_2000_cells():
         assert report[name]["classes_used"] >= min(3, k), (name, report[name]["classes_used"])      # the audit is not vacuous:
         assert int((margin < 1e-2).sum()) >= 20, (name, int((margin < 1e-2).sum()))                  # close calls exist on every model
         assert err < 1e-3, (name, err)          # north star
-        assert err < E2E_TOL, (name, err)       # fp32 summation-order floor of real patches (E2E_TOL)
+        if not heavy:
+            assert err < E2E_TOL, (name, err)       # fp32 summation-order floor of real patches (E2E_TOL)
     from multiplexed_image_annotator_amd import build as _build
     names = list(synth.VIT_CONFIGS)
     report["kernel_source_sha256"] = _build.source_fingerprint()      # bench.py quotes the flip count only for the sources it was taken on
@@ -605,7 +724,19 @@ def test_config3_parity_audit_2000_cells():
     report["max_abs_dp"] = max(report[k]["max_abs_dp"] for k in names)
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out_dir):
-        json.dump(report, open(os.path.join(out_dir, "parity_audit_config3.json"), "w"), indent=1)
+        json.dump(report, open(os.path.join(out_dir, out_name), "w"), indent=1)
+
+
+def test_config3_parity_audit_2000_cells():
+    _config3_parity_audit("uniform", 2000, "parity_audit_config3.json")
+
+
+def test_config3_parity_audit_heavy_tailed_weights():
+    """the same audit with the second synthetic weight family (synth.make_vit_state_dict_heavy: Student-t(3) linear weights,
+    LayerNorm gains over two decades, four massive-activation channels) -- the stand-in for the real checkpoints of reference
+    model.py:188-239 that cannot be downloaded here.  Same bars: max |dp| < 1e-3, no flip outside twice the measured error, the
+    re-evaluation's premise |fast - full precision| <= margin / 4 with the margin each model calibrated on its own weights."""
+    _config3_parity_audit("heavy", 1000, "parity_audit_config3_heavy.json")
 
 
 def test_config5_full_size_properties():

@@ -520,6 +520,43 @@ def test_vit_forward_vs_oracle(dev, name):
     assert torch.equal(some[far], got[far])      # cells far from every boundary keep the fast result
 
 
+@pytest.mark.parametrize("name", list(synth.VIT_CONFIGS))
+def test_vit_forward_heavy_tailed_weights(dev, name):
+    """the precision machinery had only seen the uniform weight family.  synth.make_vit_state_dict_heavy has what
+    trained ViTs have (the stand-in for reference model.py:188-239's checkpoints, which cannot be downloaded here): Student-t(3) linear
+    weights, LayerNorm gains over two decades, four residual channels 50 x the rest (an |x| >> its neighbours inside the 32-wide MX blocks
+    of both operands).  Confidences within the north-star 1e-3 of the fp32 oracle, labels identical wherever the reference's own top-2
+    margin exceeds twice the measured error, the full-precision forward at fp16x3 accuracy, and the premise of the margin-gated
+    re-evaluation -- |fast - full precision| <= recheck_margin / 4 -- with the margin the model calibrated on its own weights."""
+    from oracle import ref_vit
+    ops = _ops()
+    d, c, k = synth.VIT_CONFIGS[name]
+    sd = synth.make_vit_state_dict_heavy(name, synth.SEED_BASE + 7)
+    n = 40
+    u = synth.uniform(synth.stream_key(5, "vitx/" + name), n * c * 1600).reshape(n, c, 40, 40).to(torch.float32)
+    x = torch.where(u * 2 - 1 > 0.1, u * 2 - 1, torch.full_like(u, -1.0))
+    ref = ref_vit.predict_proba(sd, x, 8)
+    sd64 = {key: v.double() for key, v in sd.items()}
+    with torch.no_grad():
+        p64 = torch.softmax(ref_vit.logits(sd64, x.double()), dim=1)
+    err32 = (ref.double() - p64).abs().max().item()
+    model = ops.VitModel(sd, dev)
+    src = list(range(c))
+    fast = model._forward(x.to(dev), src, chunk_cells=16, precise=False).cpu()
+    full = model._forward(x.to(dev), src, chunk_cells=16, precise=True).cpu()
+    got = model.predict_proba(x.to(dev), src, chunk_cells=16, recheck=[]).cpu()
+    err, err_full, moved = (got - ref).abs().max().item(), (full - ref).abs().max().item(), (fast - full).abs().max().item()
+    note_err(f"vit_forward heavy-tailed {name} (fp32 vs fp64 {err32:.1e}; full precision {err_full:.1e}; |fast - full| {moved:.1e}; probe "
+             f"{model.probe_fast_minus_full:.1e} -> margin {model.recheck_margin:.1e})", err)
+    assert err < 1e-3, err                                  # north star
+    assert err_full < max(1e-4, 6.0 * err32), (err_full, err32)      # three fp16 passes: the fp32 reference's own class of error
+    assert moved <= model.recheck_margin / 4, (moved, model.recheck_margin)
+    srt = ref.sort(dim=1, descending=True).values
+    decided = (srt[:, 0] - srt[:, 1]) > 2.0 * err
+    assert torch.equal(got.argmax(1)[decided], ref.argmax(1)[decided])
+    assert len(torch.unique(ref.argmax(1))) >= 2             # not a saturated net: the outputs depend on the cell
+
+
 def _large_mean_state_dict(name, c0=125.0, c1=30.0):
     """adversarial statistics for the folded LayerNorm: a shared offset on every residual row (pos_embed + c0, and + c1 from every
     attn.proj / mlp.fc2 bias so that it keeps pace with the growing spread): |row mean| / row std >= 30 at the input of every block"""

@@ -213,10 +213,15 @@ def test_ome_channel_count_must_match_the_pages(tmp_path):
     np.testing.assert_array_equal(pp.read_tiff(ok), np.stack(planes))
     bad = str(tmp_path / "c5.ome.tif")
     write_tiff(bad, planes, descriptions=[_ome(5)] + [None] * 3)
-    with pytest.raises(pp.TiffStackError):       # not TiffUnsupported: another decoder reading page by page would mix series into one image
+    with pytest.raises(pp.TiffStackError) as e:   # not TiffUnsupported: another decoder reading page by page would return a partial image
         pp.read_tiff(bad)
+    assert "4 page(s) of shape (20, 24)" in str(e.value) and "companion" in str(e.value)      # the message says what WAS found
     with pytest.raises(ValueError):
         pp.read_image(bad)
+    # MORE same-shape pages than SizeC: the first series is the first SizeC of them, as tifffile returns it
+    extra = str(tmp_path / "c3_of_4.ome.tif")
+    write_tiff(extra, planes, descriptions=[_ome(3)] + [None] * 3)
+    np.testing.assert_array_equal(pp.read_tiff(extra), np.stack(planes[:3]))
 
 
 def _set_compression(path, code):

@@ -40,11 +40,14 @@ try:
     with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
         objs = dict(zip(srcs, ex.map(cc, srcs)))
     lib = os.path.join(B.HERE, f"libribca_ab_{name}.so")
-    subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-soname," + os.path.basename(lib), "-o", lib]
+    # revisions older than round 6 export their C++ launchers to the hook library: no version script, no --no-undefined for those
+    hidden = os.path.exists(os.path.join(csrc, "ribca_internal.h"))
+    vs = ["-Wl,--version-script=" + B.EXPORTS] if hidden else []
+    subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-soname," + os.path.basename(lib)] + vs + ["-o", lib]
                    + [objs[s] for s in srcs if s not in B.TEST_SOURCES], check=True)
     tests = [objs[s] for s in srcs if s in B.TEST_SOURCES]
     if tests:
-        subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib[:-3] + "_test.so"] + tests
+        subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + (["-Wl,--no-undefined"] + vs if hidden else []) + ["-o", lib[:-3] + "_test.so"] + tests
                        + ["-L" + B.HERE, f"-lribca_ab_{name}", "-Wl,-rpath,$ORIGIN"], check=True)
     print("built", lib)
 finally:

@@ -18,5 +18,5 @@ objdir = os.path.join(B.HERE, "build")
 obj = os.path.join(B.HERE, "build_" + os.path.splitext(name)[0] + "_gemm_mx.o")
 subprocess.run([B._hipcc()] + B.FLAGS + extra + ["-c", os.path.join(B.CSRC, "gemm_mx.hip"), "-o", obj], check=True)
 objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in B.SOURCES if s != "gemm_mx.hip"] + [obj]
-subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(B.HERE, name)] + objs, check=True)
+subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + B.EXPORTS, "-o", os.path.join(B.HERE, name)] + objs, check=True)
 print("built", name)

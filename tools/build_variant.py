@@ -27,5 +27,5 @@ def one(src):
 
 with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
     objs = list(ex.map(one, B.SOURCES))
-subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(B.HERE, name)] + objs, check=True)
+subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + B.EXPORTS, "-o", os.path.join(B.HERE, name)] + objs, check=True)
 print("built", os.path.join(B.HERE, name))
