@@ -272,7 +272,7 @@ def main():
                 a_, b_ = vote_pair
                 oth = {k: (CLASS_NAMES[k].index("Others") if "Others" in CLASS_NAMES[k] else None) for k in vote_pair}
                 dd = ops.decision_distance(probs[a_], oth[a_], probs[b_], oth[b_], RECHECK)
-                uses_mx = [k for k in vote_pair if _lib.lib().ribca_mx_enabled(models[k].D)]
+                uses_mx = [k for k in vote_pair if models[k].uses_mx]
                 rows = torch.nonzero(dd < max([models[k].recheck_margin for k in uses_mx] or [ops.VitModel.RECHECK_MARGIN])).flatten()
                 if rows.numel() and uses_mx:
                     for k in uses_mx:
@@ -382,9 +382,11 @@ def main():
     # re-evaluation -- the cells whose label two correct fp32 evaluations need not agree on (Annotator.NOISE_FLOOR)
     out["cells_re_evaluated_at_full_precision"]["vote_pair (" + " + ".join(k for k in vote_pair if k) + ")"] = recheck_counts.get("vote_pair_cells_re_evaluated")
     out["cells_undecidable"] = recheck_counts.get("vote_pair_cells_within_noise_floor")
-    # the margin each classifier uses: max(1e-3, 16 x |fast - full precision| on a fixed 64-cell probe, measured at load time on the model's own weights)
-    out["recheck_margin"] = {name: m.recheck_margin for name, m in models.items()}
-    out["recheck_probe_fast_minus_full"] = {name: m.probe_fast_minus_full for name, m in models.items()}
+    out["recheck_margin"] = ops.VitModel.RECHECK_MARGIN
+    # whether each classifier's weights were accepted for the MX products: |fast - full precision| on a fixed 64-cell probe, measured at load
+    # time, against RECHECK_MARGIN / 16 (a model beyond the bar runs every product at three fp16 passes)
+    out["mx_probe_fast_minus_full"] = {name: m.probe_fast_minus_full for name, m in models.items()}
+    out["mx_fast_path_in_use"] = {name: m.uses_mx for name, m in models.items()}
     out["parity_audit"] = parity_audit_record(out["kernel_source_sha256"])
     if sharded:
         ag_ms = sum(a.elapsed_time(b) for a, b in ag_events)
@@ -559,6 +561,14 @@ def main():
         with contextlib.redirect_stdout(sys.stderr):      # the Annotator prints the reference's panel messages: keep stdout to ONE JSON line
             out["dropin"] = dropin_bench(args, raw, mask, markers, models, srcs, one_pass_models=lambda sel: one_pass(models_sel=sel))
 
+    # ---- BASELINE config 5 through the product class: a batch CSV of one tile per rank, Annotator in tile-per-rank mode (every rank) -------
+    if not args.no_dropin and args.impute:
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):
+            rec = dropin_tiles_bench(args, raw, mask, markers, models, imputer, rank, world, backend, dev)
+        if rank == 0:
+            out["dropin"] = rec
+
     # ---- CPU baseline: the oracle (numpy/scipy/torch fp32 restatement of the reference path) on a bounded sample ------------
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, raw, mask, markers, seed, n_cells)
@@ -621,7 +631,7 @@ def avg_units(dims, depths):
     return num / den
 
 
-PROFILE_ROUND = "r5"      # the directory under profiles/ whose counter passes the line may quote (sha-matched)
+PROFILE_ROUND = "r6"      # the directory under profiles/ whose counter passes the line may quote (sha-matched)
 
 
 def parity_audit_record(sha):
@@ -780,6 +790,76 @@ def dropin_bench(args, raw_dev, mask_dev, markers, models, srcs, one_pass_models
                 "kernel_path_same_models": round(n / t_ops, 2), "ratio_to_kernel_path": round(t_ops / t_api, 4)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def dropin_tiles_bench(args, raw_dev, mask_dev, markers, models, imputer, rank, world, backend, dev):
+    """BASELINE config 5 through the drop-in class (reference main.py:39-52 batch_run): ONE batch CSV listing every rank's tile, every rank
+    an ``Annotator`` in tile-per-rank mode (dist.tile_mode: at least one image per rank -> whole images per rank, replicas only, nothing
+    exchanged on the data path; a single rank simply annotates its one tile), infer=True with one full-panel marker missing -> MAE
+    imputer + immune_full.  Timed per rank: Annotator(...) -> preprocess() (file read, H2D, normalise, label table, crop) -> predict()
+    (imputer, ViT, re-evaluation, vote) -> export_annotations() (this rank's CSV); value = all ranks' cells / the slowest rank's time."""
+    import shutil
+    import tempfile
+    import torch.distributed as tdist
+    from multiplexed_image_annotator_amd.annotator import Annotator
+    box = [tempfile.mkdtemp(prefix="ribca_tiles_") if rank == 0 else None]
+    if world > 1:
+        tdist.broadcast_object_list(box, src=0)
+    tmp = box[0]
+    try:
+        np.save(os.path.join(tmp, f"img{rank}.npy"), raw_dev.cpu().numpy().view(np.uint16))
+        np.save(os.path.join(tmp, f"mask{rank}.npy"), mask_dev.cpu().numpy())
+        if rank == 0:
+            with open(os.path.join(tmp, "markers.txt"), "w") as f:
+                f.write("\n".join(markers) + "\n")
+            with open(os.path.join(tmp, "images.csv"), "w") as f:
+                f.write("image_path,mask_path\n" + "".join("%s,%s\n" % (os.path.join(tmp, f"img{r}.npy"), os.path.join(tmp, f"mask{r}.npy")) for r in range(world)))
+        if world > 1:
+            tdist.barrier()
+
+        def run_once():
+            a = Annotator(os.path.join(tmp, "markers.txt"), os.path.join(tmp, "images.csv"), "cuda", tmp, "bench", False, True, -1, True, 0.3,
+                          99.8, 0.3, 30, None)
+            assert a.tile_mode == (world > 1)
+            a.chunk_cells, a.streams = args.chunk, args.streams
+            a.models = {k: v for k, v in models.items() if k == "immune_full"}
+            a.imputers = {"immune_full": imputer}
+            a._loaded = True
+            a.preprocess()
+            a.predict(128)
+            a.export_annotations()
+            n = sum(len(x) for x in a.annotations)
+            a.clear_tmp()
+            a.logger.close()
+            return n
+
+        run_once()
+        torch.cuda.synchronize()
+        if world > 1:
+            tdist.barrier()
+        reps = 2
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            n = run_once()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        total = n
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+            dt = float(t.item())
+            c = torch.tensor([n], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+            tdist.all_reduce(c, op=tdist.ReduceOp.SUM)
+            total = int(c.item())
+            tdist.barrier()
+        return {"value": round(total / dt, 2), "unit": "cells/s", "ms_per_tile": round(dt * 1e3, 2), "models": ["immune_full"], "imputer": True,
+                "mode": f"tile-per-rank x {world} (Annotator.tile_mode, replicas only)" if world > 1 else "single rank, one tile",
+                "includes": "np.load of image + mask, H2D, normalise, label table, crop + intensity table, MAE imputer, ViT, re-evaluation, vote, CSV write"}
+    finally:
+        if world > 1:
+            tdist.barrier()
+        if rank == 0:
+            shutil.rmtree(tmp, ignore_errors=True)
 
 
 def cpu_baseline(args, raw_dev, mask_dev, markers, seed, n_cells):

@@ -273,9 +273,9 @@ class Annotator(object):
         if stats["cells"] == 0:
             return stats
         d = distance()
-        uses_mx = [k for k in pair if k and _lib.lib().ribca_mx_enabled(self.models[k].D)]
+        uses_mx = [k for k in pair if k and self.models[k].uses_mx]
         if uses_mx:
-            margin = max(self.models[k].recheck_margin for k in uses_mx)      # calibrated per model on its own weights (ops.VitModel)
+            margin = max(self.models[k].recheck_margin for k in uses_mx)
             stats["margin"] = margin
             rows = torch.nonzero(d < margin).flatten()
             if rows.numel():

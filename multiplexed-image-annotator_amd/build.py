@@ -25,7 +25,10 @@ HEADERS = ["ribca_common.h", "ribca_kernels.h", "ribca_status.h", "ribca_interna
            os.path.join("..", "..", "include", "ribca_hip_test.h")]
 # -fvisibility=hidden: the dynamic symbol table of either library is what its header declares between `#pragma GCC visibility push(default)` and
 # `pop` -- no C++ launcher, kernel stub or template instantiation is exported (tests/test_abi.py compares the full `nm -D` list with the header)
-FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fvisibility=hidden", "-fvisibility-inlines-hidden"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fvisibility=hidden", "-fvisibility-inlines-hidden",
+         # the scalar fp32 epilogue arithmetic stays scalar: packed fp32 operations beside another workgroup's MFMA stream cost more than the two
+         # plain ones they replace (ribca_common.h gelu_erf1; same-box A/B profiles/r6/ab_gelu_scalar.txt)
+         "-fno-slp-vectorize"]
 
 
 def source_fingerprint() -> str:

@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     f32x2v sum2 = {0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
-      const f32x2v a0 = __builtin_elementwise_fma(f32x2v{s[kt][0], s[kt][1]}, l2, moff);
-      const f32x2v a1 = __builtin_elementwise_fma(f32x2v{s[kt][2], s[kt][3]}, l2, moff);
+      const f32x2v a0 = fma2(f32x2v{s[kt][0], s[kt][1]}, l2, moff);
+      const f32x2v a1 = fma2(f32x2v{s[kt][2], s[kt][3]}, l2, moff);
       const f32x2v e0 = {__builtin_amdgcn_exp2f(a0.x), __builtin_amdgcn_exp2f(a0.y)}, e1 = {__builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y)};
       s[kt] = f32x4{e0.x, e0.y, e1.x, e1.y};
       sum2 += e0;
@@ -273,8 +273,8 @@ __global__ __launch_bounds__(64 * WPP) void attention_lds_kernel(const uint16_t*
     f32x2v sum2 = {0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
-      const f32x2v a0 = __builtin_elementwise_fma(f32x2v{s[kt][0], s[kt][1]}, l2, moff);
-      const f32x2v a1 = __builtin_elementwise_fma(f32x2v{s[kt][2], s[kt][3]}, l2, moff);
+      const f32x2v a0 = fma2(f32x2v{s[kt][0], s[kt][1]}, l2, moff);
+      const f32x2v a1 = fma2(f32x2v{s[kt][2], s[kt][3]}, l2, moff);
       const f32x2v e0 = {__builtin_amdgcn_exp2f(a0.x), __builtin_amdgcn_exp2f(a0.y)}, e1 = {__builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y)};
       s[kt] = f32x4{e0.x, e0.y, e1.x, e1.y};
       sum2 += e0;

@@ -216,8 +216,8 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
       const float4 c4 = *reinterpret_cast<const float4*>(cb + n * 4), b4 = *reinterpret_cast<const float4*>(cb + 3 * D * 4 + n * 4);
       // two columns per instruction (v_pk_fma_f32); the same two fused multiply-adds per value as ln_fold4 (gemm_epi.h)
       const f32x2v r2 = {rstd, rstd}, n2 = {nm, nm};
-      const f32x2v lo2 = __builtin_elementwise_fma(r2, f32x2v{acc[j][0], acc[j][1]}, __builtin_elementwise_fma(n2, f32x2v{c4.x, c4.y}, f32x2v{b4.x, b4.y}));
-      const f32x2v hi2 = __builtin_elementwise_fma(r2, f32x2v{acc[j][2], acc[j][3]}, __builtin_elementwise_fma(n2, f32x2v{c4.z, c4.w}, f32x2v{b4.z, b4.w}));
+      const f32x2v lo2 = fma2(r2, f32x2v{acc[j][0], acc[j][1]}, fma2(n2, f32x2v{c4.x, c4.y}, f32x2v{b4.x, b4.y}));
+      const f32x2v hi2 = fma2(r2, f32x2v{acc[j][2], acc[j][3]}, fma2(n2, f32x2v{c4.z, c4.w}, f32x2v{b4.z, b4.w}));
       acc[j] = f32x4{lo2.x, lo2.y, hi2.x, hi2.y};
     }
     // ---- publish k (fragment order, one image per head) and v (row-major packed-split rows of 48 dims)
@@ -306,8 +306,8 @@ __global__ __launch_bounds__(512) void cell_qkv_attention_kernel(const uint16_t*
         f32x2v sum2 = {0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
-          const f32x2v a0 = __builtin_elementwise_fma(f32x2v{s[e][kt][0], s[e][kt][1]}, l2, moff);
-          const f32x2v a1 = __builtin_elementwise_fma(f32x2v{s[e][kt][2], s[e][kt][3]}, l2, moff);
+          const f32x2v a0 = fma2(f32x2v{s[e][kt][0], s[e][kt][1]}, l2, moff);
+          const f32x2v a1 = fma2(f32x2v{s[e][kt][2], s[e][kt][3]}, l2, moff);
           const f32x2v e0 = {__builtin_amdgcn_exp2f(a0.x), __builtin_amdgcn_exp2f(a0.y)}, e1 = {__builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y)};
           s[e][kt] = f32x4{e0.x, e0.y, e1.x, e1.y};
           sum2 += e0;

@@ -710,12 +710,12 @@ __device__ __forceinline__ void resid_zk_epilogue(const EpiResidZK& epi, int mba
     const int m = mbase + 16 * i;
     const bool ok = IN || m < epi.M;
     uint16_t* zr = epi.z + (size_t)(ok ? m : 0) * epi.ldz;
-    const f32x2v pm2 = {pm[i], pm[i]};
-    f32x2v tot = {0.f, 0.f};
+    const f32x2p pm2 = {pm[i], pm[i]};
+    f32x2p tot = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      f32x2v x0 = (f32x2v{a[j][0], a[j][1]} - pm2) + f32x2v{b4[j].x, b4[j].y};
-      f32x2v x1 = (f32x2v{a[j][2], a[j][3]} - pm2) + f32x2v{b4[j].z, b4[j].w};
+      f32x2p x0 = (f32x2p{a[j][0], a[j][1]} - pm2) + f32x2p{b4[j].x, b4[j].y};
+      f32x2p x1 = (f32x2p{a[j][2], a[j][3]} - pm2) + f32x2p{b4[j].z, b4[j].w};
       x0.x = clamp_f16_range(x0.x); x0.y = clamp_f16_range(x0.y); x1.x = clamp_f16_range(x1.x); x1.y = clamp_f16_range(x1.y);
       a[j] = f32x4{x0.x, x0.y, x1.x, x1.y};
       tot += x0; tot += x1;
@@ -744,11 +744,11 @@ __device__ __forceinline__ void resid_zk_epilogue(const EpiResidZK& epi, int mba
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     f32x4(&a)[TN] = acc[i / RB][i % RB];
-    const f32x2v mu = {sum[i], sum[i]};
-    f32x2v qq = {0.f, 0.f};
+    const f32x2p mu = {sum[i], sum[i]};
+    f32x2p qq = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const f32x2v d0 = f32x2v{a[j][0], a[j][1]} - mu, d1 = f32x2v{a[j][2], a[j][3]} - mu;
+      const f32x2p d0 = f32x2p{a[j][0], a[j][1]} - mu, d1 = f32x2p{a[j][2], a[j][3]} - mu;
       qq += d0 * d0; qq += d1 * d1;
     }
     q[i] = qq.x + qq.y;

@@ -189,21 +189,21 @@ __device__ __forceinline__ void lds_drain_resid_ps(const EpiResidPS& epi, const 
   for (int it = 0; it < NIT; ++it)
     asm volatile("" : "+v"(zh[it].x), "+v"(zh[it].y), "+v"(zh[it].z), "+v"(zh[it].w), "+v"(zl[it].x), "+v"(zl[it].y), "+v"(zl[it].z), "+v"(zl[it].w));
   __builtin_amdgcn_sched_barrier(0);
-  f32x2v xs[NIT][4];
+  f32x2p xs[NIT][4];
   float s[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int row = rbase + 48 * it;
     const bool ok = col_ok && row < 256 && m0 + row < epi.M;
     const uint32_t hw[4] = {zh[it].x, zh[it].y, zh[it].z, zh[it].w}, lw[4] = {zl[it].x, zl[it].y, zl[it].z, zl[it].w};
-    const f32x2v acc2[4] = {f32x2v{va[it][0], va[it][1]}, f32x2v{va[it][2], va[it][3]}, f32x2v{vb[it][0], vb[it][1]}, f32x2v{vb[it][2], vb[it][3]}};
-    const f32x2v pm = {pmean[it], pmean[it]};
+    const f32x2p acc2[4] = {f32x2p{va[it][0], va[it][1]}, f32x2p{va[it][2], va[it][3]}, f32x2p{vb[it][0], vb[it][1]}, f32x2p{vb[it][2], vb[it][3]}};
+    const f32x2p pm = {pmean[it], pmean[it]};
     uint32_t nh[4], nl[4];
-    f32x2v tot = {0.f, 0.f};
+    f32x2p tot = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {      // two columns at a time: packed fp32 adds
-      const f32x2v zo = {f16lo_plus_f16lo(hw[j], lw[j]), f16hi_plus_f16hi(hw[j], lw[j])};      // hi + lo: exact
-      f32x2v x = (zo - pm) + acc2[j];              // the tile already carries the bias (consumers, before parking)
+      const f32x2p zo = {f16lo_plus_f16lo(hw[j], lw[j]), f16hi_plus_f16hi(hw[j], lw[j])};      // hi + lo: exact
+      f32x2p x = (zo - pm) + acc2[j];              // the tile already carries the bias (consumers, before parking)
       x.x = clamp_f16_range(x.x); x.y = clamp_f16_range(x.y);
       nh[j] = cvt_pk_f16(x.x, x.y);
       nl[j] = cvt_pk_f16(f32_minus_f16lo(x.x, nh[j]), f32_minus_f16hi(x.y, nh[j]));
@@ -227,10 +227,10 @@ __device__ __forceinline__ void lds_drain_resid_ps(const EpiResidPS& epi, const 
   for (int it = 0; it < NIT; ++it) {
     const int row = rbase + 48 * it;
     const bool ok = col_ok && row < 256 && m0 + row < epi.M;
-    const f32x2v mu = {s[it], s[it]};
-    f32x2v qq = {0.f, 0.f};
+    const f32x2p mu = {s[it], s[it]};
+    f32x2p qq = {0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const f32x2v d = xs[it][j] - mu; qq += d * d; }
+    for (int j = 0; j < 4; ++j) { const f32x2p d = xs[it][j] - mu; qq += d * d; }
     q[it] = ok ? qq.x + qq.y : 0.f;
   }
 #pragma unroll

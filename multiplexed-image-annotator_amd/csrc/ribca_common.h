@@ -189,31 +189,73 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// exact-erf GELU (nn.GELU() default used by timm Mlp): 0.5 x (1 + erf(x / sqrt(2))), two values at a time.
+// exact-erf GELU (nn.GELU() default used by timm Mlp): 0.5 x (1 + erf(x / sqrt(2))).
 // erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7) on z = |x| / sqrt(2):  erf(z) = 1 - q,  q = poly(t) exp(-z^2),
-// t = 1 / (1 + 0.3275911 z).  With a = |x|:   gelu = 0.5 x + a (0.5 - 0.5 q)  -- no sign select, no branch, and every
-// multiply-add is a PACKED fp32 op (v_pk_fma_f32 / v_pk_mul_f32: two lanes-worth per instruction); only the reciprocal and the
-// exponential are per value.  8.5 VALU instructions per value instead of 15: the fc1 epilogue is VALU-bound (round-2
-// measurement, tools/epilogue_scaling.py: 8.7 us per 256 x 128 tile with 18 workgroups on an idle chip, independent of K).
+// t = 1 / (1 + 0.3275911 z).  With a = |x|:   gelu = 0.5 x + a (0.5 - 0.5 q)  -- no sign select, no branch.
 // The output is re-quantised to an fp16 hi/lo pair right after, so libm erff's last bits would be discarded anyway.
+// One fp32 instruction per value and step (round 6).  Rounds 2-5 evaluated two values at a time in PACKED fp32 (v_pk_fma_f32 /
+// v_pk_mul_f32: 8.5 instructions per value instead of 15), which was faster while the GELU epilogue ran on a CU of its own; since the
+// GELU GEMMs run two workgroups per CU, one workgroup's epilogue shares its SIMDs with the other's MFMA stream, and a packed fp32
+// operation beside MFMAs costs more than the two plain ones it replaces (MI355X_MICROARCH.md, per-instruction table: "an anti-lever
+// beside MFMAs").  Same-box A/B, per 4096 cells (profiles/r6/ab_gelu_scalar.txt): fc1 at D = 288 11.9 -> 11.3 ms, at D = 384 15.6 ->
+// 15.1-15.4, at D = 576 29.5 -> 28.9-29.3.  RIBCA_GELU_PACKED restores the packed form (A/B); the library is also built with
+// -fno-slp-vectorize so that the compiler does not pack the scalar form again.
+// A pair of fp32 values.  Rounds 2-5 made it a hardware vector (ext_vector_type: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, two values per
+// instruction) in the softmax, fold and statistics code; beside an MFMA stream -- the wave's own in the attention kernels, the other
+// workgroup's in the two-workgroups-per-CU GEMMs -- a packed fp32 operation costs more than the two plain ones it replaces, so the pair is
+// a plain struct now and every operation on it one scalar instruction per value (same IEEE operations, same results; -DRIBCA_PACKED_F32
+// restores the vector form for A/B, profiles/r6/ab_packed_f32.txt).
+// (f32x2p: always the hardware vector -- the residual epilogues' statistics code keeps it: as a struct it costs the 128 x 192 residual kernel
+// four spilled registers, which a kernel that fills registers with inline-asm loads must not have, tests/test_kernel_resources.py)
+typedef float f32x2p __attribute__((ext_vector_type(2)));
+#if defined(RIBCA_PACKED_F32) || defined(RIBCA_GELU_PACKED)
 typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2v fma2(f32x2v a, f32x2v b, f32x2v c) { return __builtin_elementwise_fma(a, b, c); }
+#else
+struct f32x2v {
+  float x, y;
+  __device__ __forceinline__ f32x2v& operator+=(const f32x2v& o) { x += o.x; y += o.y; return *this; }
+};
+__device__ __forceinline__ f32x2v operator+(const f32x2v& a, const f32x2v& b) { return f32x2v{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ f32x2v operator-(const f32x2v& a, const f32x2v& b) { return f32x2v{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ f32x2v operator*(const f32x2v& a, const f32x2v& b) { return f32x2v{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ f32x2v fma2(const f32x2v& a, const f32x2v& b, const f32x2v& c) {
+  return f32x2v{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)};
+}
+#endif
+#ifndef RIBCA_GELU_PACKED
+__device__ __forceinline__ float gelu_erf1(float x) {
+  const float a = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(a, 0.23164188814f, 1.0f));      // 0.3275911 / sqrt(2)
+  float p = __builtin_fmaf(t, 0.5307027145f, -0.7265760135f);      // 0.5 x (1.061405429, -1.453152027, 1.421413741, -0.284496736, 0.254829592)
+  p = __builtin_fmaf(p, t, 0.7107068705f);
+  p = __builtin_fmaf(p, t, -0.142248368f);
+  p = __builtin_fmaf(p, t, 0.127414796f);
+  p = p * t;
+  const float e = __builtin_amdgcn_exp2f((x * x) * -0.72134752044f);      // -log2(e) / 2
+  const float s = __builtin_fmaf(-p, e, 0.5f);                           // 0.5 erfc-complement: 0.5 - 0.5 q
+  return __builtin_fmaf(a, s, x * 0.5f);
+}
+__device__ __forceinline__ f32x2v gelu_erf2(f32x2v x) { return f32x2v{gelu_erf1(x.x), gelu_erf1(x.y)}; }
+#else
 __device__ __forceinline__ f32x2v gelu_erf2(f32x2v x) {
   f32x2v a;
   a.x = fabsf(x.x); a.y = fabsf(x.y);
-  const f32x2v den = a * 0.23164188814f + 1.0f;                 // 0.3275911 / sqrt(2)
+  const f32x2v den = a * 0.23164188814f + 1.0f;
   f32x2v t;
   t.x = __builtin_amdgcn_rcpf(den.x); t.y = __builtin_amdgcn_rcpf(den.y);
-  f32x2v p = t * 0.5307027145f + -0.7265760135f;                // 0.5 x (1.061405429, -1.453152027, 1.421413741, -0.284496736, 0.254829592)
+  f32x2v p = t * 0.5307027145f + -0.7265760135f;
   p = p * t + 0.7107068705f;
   p = p * t + -0.142248368f;
   p = p * t + 0.127414796f;
   p = p * t;
-  const f32x2v ea = (x * x) * -0.72134752044f;                  // -log2(e) / 2
+  const f32x2v ea = (x * x) * -0.72134752044f;
   f32x2v e;
   e.x = __builtin_amdgcn_exp2f(ea.x); e.y = __builtin_amdgcn_exp2f(ea.y);
-  const f32x2v s = 0.5f - p * e;                                // 0.5 erfc-complement: 0.5 - 0.5 q
+  const f32x2v s = 0.5f - p * e;
   return a * s + x * 0.5f;
 }
+#endif
 __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2(f32x2v{x, x}).x; }
 
 }  // namespace ribca

@@ -158,7 +158,7 @@ def make_vit_state_dict(name: str, seed: int, depth: int = VIT_DEPTH, head_gain:
     return sd
 
 
-def make_vit_state_dict_heavy(name: str, seed: int, depth: int = VIT_DEPTH, head_gain: float = 4.0, lin_gain: float = 2.0,
+def make_vit_state_dict_heavy(name: str, seed: int, depth: int = VIT_DEPTH, head_gain: float = 4.0, lin_gain: float = 1.5,
                               gamma_max: float = 5.0, outlier_channels: int = 4, outlier_gain: float = 50.0) -> Dict[str, torch.Tensor]:
     """A second weight family for the parity audits (same keys as ``make_vit_state_dict``): what trained ViTs have and the uniform
     family lacks.  No checkpoint of the reference can be loaded here (download_models.py:7-24 needs the network), so this is the stand-in
@@ -170,9 +170,11 @@ def make_vit_state_dict_heavy(name: str, seed: int, depth: int = VIT_DEPTH, head
     * ``outlier_channels`` residual channels carry ``outlier_gain`` x the others through ``pos_embed`` / ``cls_token``: massive
       activations -- one |x| >> the rest inside a 32-column MX3 block of the residual rows, rows with |mean| / std >> 1.
 
-    ``lin_gain`` = 2 gives the linears the uniform family's variance; the net stays in the non-chaotic regime (the fp32 forward sits
-    1-2e-5 from the fp64 one: tests/precision_study.py --family heavy prints it) and the outputs still depend on the cell (2-4 classes
-    in use per classifier; with lin_gain 1 the outlier channels saturate every cell to one class).
+    ``lin_gain`` = 1.5 (the uniform family: 2) offsets the larger LayerNorm gains (rms 2.3 instead of 1) so that the net stays in the
+    non-chaotic regime of a trained model: on real patches (mostly background) the fp32 CPU forward itself then sits 1-8e-5 from the fp64
+    forward, as with the uniform family (8e-5); at lin_gain 2 the reference's OWN fp32 rounding noise is 2-4.5e-4 on such patches
+    (measured on BASELINE config 3's patches, profiles/r6/heavy_family_calibration.txt) -- a net whose reference output is only defined to
+    half the tolerance tests nothing about this path.  Every class stays in use once the head bias is calibrated (calibrate_head_bias).
     """
     d, c, k = VIT_CONFIGS[name]
     sd = make_vit_state_dict(name, seed, depth=depth, head_gain=head_gain)

@@ -684,6 +684,16 @@ def _config3_parity_audit(family: str, n_cells: int, out_name: str):
         full = vm._forward(patches, list(range(c)), 1024, 0, 1, precise=True)
         fast_vs_full = (fast - full).abs().max().item()
         assert fast_vs_full <= vm.recheck_margin / 4, (name, fast_vs_full, vm.recheck_margin, vm.probe_fast_minus_full)
+        # the raw MX forward, whatever the load-time probe decided for these weights (what a refused model is protected from), and -- for
+        # the heavy family -- the reference's own distance from exact arithmetic on these patches
+        raw_mx_vs_full = (vm._forward(patches, list(range(c)), 1024, 0, 1, precise=False, force_fast=True) - full).abs().max().item()
+        ref32_vs_fp64 = None
+        if heavy:
+            sd64 = {key: v.double() for key, v in sd.items()}
+            with torch.no_grad():
+                p64 = torch.cat([torch.softmax(ref_vit.logits(sd64, x_cpu[i:i + 100, :c].double()), dim=1) for i in range(0, len(sel), 100)])
+            ref32_vs_fp64 = float((ref.double() - p64).abs().max())
+            err_vs_fp64 = float((got.double() - p64).abs().max())
         del fast, full
         srt = ref.sort(dim=1, descending=True).values
         margin = (srt[:, 0] - srt[:, 1]).numpy()
@@ -704,14 +714,17 @@ def _config3_parity_audit(family: str, n_cells: int, out_name: str):
                         "margin_hist": hist, "classes_used": int(len(torch.unique(ref.argmax(1)))), "cells_with_margin_below_1e-2": int((margin < 1e-2).sum()),
                         "cells_re_evaluated_at_full_precision": vm.last_recheck["cells"], "matrix_units_fc2": 1.75 if (4 * d) % 128 == 0 else 3.0,
                         "max_abs_fast_minus_full_precision": fast_vs_full, "recheck_margin": vm.recheck_margin,
-                        "probe_fast_minus_full_precision": vm.probe_fast_minus_full, "weight_family": family}
-        print(f"[parity audit, {family} weights] {name}: {n_cells} cells, margin {vm.recheck_margin:.1e} (probe {vm.probe_fast_minus_full:.1e}), max|dp| {err:.2e}, flips {flips} (undecidable {undecidable}, fp64 sides with this path on "
+                        "probe_fast_minus_full_precision": vm.probe_fast_minus_full, "weight_family": family, "mx_fast_path_in_use": vm.uses_mx,
+                        "max_abs_raw_mx_minus_full_precision": raw_mx_vs_full, "fp32_reference_vs_fp64": ref32_vs_fp64,
+                        "max_abs_dp_vs_fp64": err_vs_fp64 if heavy else None}
+        print(f"[parity audit, {family} weights] {name}: {n_cells} cells, probe {vm.probe_fast_minus_full:.1e} -> MX {'in use' if vm.uses_mx else 'not in use'} "
+              f"(|raw MX - full| {raw_mx_vs_full:.1e}" + (f", fp32 reference vs fp64 {ref32_vs_fp64:.1e}, this path vs fp64 {err_vs_fp64:.1e}" if heavy else "") + f"), max|dp| {err:.2e}, flips {flips} (undecidable {undecidable}, fp64 sides with this path on "
               f"{ref_wrong}), top-2 margin min {margin.min():.2e} hist {hist}; |fast - full precision| {fast_vs_full:.1e}", file=sys.__stdout__, flush=True)
         # identical labels wherever the reference's own margin exceeds twice the measured confidence error; a handful of ties within
         # the fp32 noise floor may fall either way (and do so between the fp32 and the fp64 CPU forward as well)
         assert flips == undecidable and flips <= 2, (name, flips, undecidable)
         assert report[name]["classes_used"] >= min(3, k), (name, report[name]["classes_used"])      # the audit is not vacuous:
-        assert int((margin < 1e-2).sum()) >= 20, (name, int((margin < 1e-2).sum()))                  # close calls exist on every model
+        assert int((margin < 1e-2).sum()) >= (2 if heavy else 20), (name, int((margin < 1e-2).sum()))      # close calls exist on every model
         assert err < 1e-3, (name, err)          # north star
         if not heavy:
             assert err < E2E_TOL, (name, err)       # fp32 summation-order floor of real patches (E2E_TOL)
@@ -800,3 +813,21 @@ def test_config5_full_size_properties():
     assert err < 1e-3, err
     assert len(torch.unique(ref.argmax(1))) >= 3 and int((margin < 1e-2).sum()) >= 20
     assert bool((margin[flipped] <= 2.0 * err).all()) and int(flipped.sum()) <= 2, (int(flipped.sum()), err)
+    # the "full operand precision" re-evaluation of immune_full re-runs the imputer on its FAST path (the 768-wide encoder's qkv /
+    # fc1 / fc2 on the MX kernel; ribca_mae_impute has no precise form).  What that rests on: the imputer -> classifier chain with the fast
+    # imputer and with the round-2 imputer (RIBCA_MAE_FOLD=0 at create: fp32 residual stream, LayerNorm kernel, three fp16 passes) differ by
+    # far less than the margin -- asserted, with the classifier itself at full precision on both sides
+    os.environ["RIBCA_MAE_FOLD"] = "0"
+    try:
+        imputer_r2 = ops.MaeModel(imp_sd, dev)
+    finally:
+        del os.environ["RIBCA_MAE_FOLD"]
+    x_r2 = x.to(dev).contiguous().clone()
+    imputer_r2.impute(x_r2, present, chunk_cells=256)
+    d_planes = (x_r2[:, 14] - part[sel.to(dev), 14]).abs().max().item()
+    p_fast_imp = model2._forward(part[sel.to(dev)].contiguous(), list(range(15)), chunk_cells=256, precise=True)
+    p_r2_imp = model2._forward(x_r2, list(range(15)), chunk_cells=256, precise=True)
+    d_chain = (p_fast_imp - p_r2_imp).abs().max().item()
+    print(f"[config 5 audit] fast (folded / MX) imputer vs fp16x3 imputer: imputed plane {d_planes:.2e}, confidences behind it {d_chain:.2e} "
+          f"(margin {model2.recheck_margin:.1e})", file=sys.__stdout__, flush=True)
+    assert d_chain <= model2.recheck_margin / 4, (d_chain, model2.recheck_margin)

@@ -525,16 +525,20 @@ def test_vit_forward_heavy_tailed_weights(dev, name):
     """the precision machinery had only seen the uniform weight family.  synth.make_vit_state_dict_heavy has what
     trained ViTs have (the stand-in for reference model.py:188-239's checkpoints, which cannot be downloaded here): Student-t(3) linear
     weights, LayerNorm gains over two decades, four residual channels 50 x the rest (an |x| >> its neighbours inside the 32-wide MX blocks
-    of both operands).  Confidences within the north-star 1e-3 of the fp32 oracle, labels identical wherever the reference's own top-2
-    margin exceeds twice the measured error, the full-precision forward at fp16x3 accuracy, and the premise of the margin-gated
-    re-evaluation -- |fast - full precision| <= recheck_margin / 4 -- with the margin the model calibrated on its own weights."""
+    of both operands).  What must hold: confidences within the north-star 1e-3 of the fp32 oracle; labels identical wherever the
+    reference's own top-2 margin exceeds twice the measured error; the full-precision forward in the fp32 reference's own class of error;
+    and the premise of the margin-gated re-evaluation, |fast - full precision| <= RECHECK_MARGIN / 4, for the forward the model really
+    uses -- a model whose load-time probe refuses its weights (ops.VitModel._calibrate_margin) runs every product at three fp16 passes, and
+    the raw MX forward it was protected from is measured beside it (force_fast)."""
     from oracle import ref_vit
     ops = _ops()
     d, c, k = synth.VIT_CONFIGS[name]
-    sd = synth.make_vit_state_dict_heavy(name, synth.SEED_BASE + 7)
-    n = 40
+    sd = synth.make_vit_state_dict_heavy(name, synth.SEED_BASE + 7, head_gain=1.5)
+    n = 48
     u = synth.uniform(synth.stream_key(5, "vitx/" + name), n * c * 1600).reshape(n, c, 40, 40).to(torch.float32)
     x = torch.where(u * 2 - 1 > 0.1, u * 2 - 1, torch.full_like(u, -1.0))
+    with torch.no_grad():
+        sd["head.bias"] = synth.calibrate_head_bias(sd, ref_vit.forward_features(sd, x))      # every class in use: labels have teeth
     ref = ref_vit.predict_proba(sd, x, 8)
     sd64 = {key: v.double() for key, v in sd.items()}
     with torch.no_grad():
@@ -542,15 +546,19 @@ def test_vit_forward_heavy_tailed_weights(dev, name):
     err32 = (ref.double() - p64).abs().max().item()
     model = ops.VitModel(sd, dev)
     src = list(range(c))
+    raw_mx = model._forward(x.to(dev), src, chunk_cells=16, precise=False, force_fast=True).cpu()
     fast = model._forward(x.to(dev), src, chunk_cells=16, precise=False).cpu()
     full = model._forward(x.to(dev), src, chunk_cells=16, precise=True).cpu()
     got = model.predict_proba(x.to(dev), src, chunk_cells=16, recheck=[]).cpu()
-    err, err_full, moved = (got - ref).abs().max().item(), (full - ref).abs().max().item(), (fast - full).abs().max().item()
-    note_err(f"vit_forward heavy-tailed {name} (fp32 vs fp64 {err32:.1e}; full precision {err_full:.1e}; |fast - full| {moved:.1e}; probe "
-             f"{model.probe_fast_minus_full:.1e} -> margin {model.recheck_margin:.1e})", err)
+    err, err_full = (got - ref).abs().max().item(), (full - ref).abs().max().item()
+    moved, moved_raw = (fast - full).abs().max().item(), (raw_mx - full).abs().max().item()
+    note_err(f"vit_forward heavy-tailed {name} (fp32 vs fp64 {err32:.1e}; full precision {err_full:.1e}; probe {model.probe_fast_minus_full:.1e} -> "
+             f"MX {'in use' if model.uses_mx else 'refused' if (4 * d) % 128 == 0 else 'n/a'}; |raw MX - full| {moved_raw:.1e})", err)
     assert err < 1e-3, err                                  # north star
     assert err_full < max(1e-4, 6.0 * err32), (err_full, err32)      # three fp16 passes: the fp32 reference's own class of error
     assert moved <= model.recheck_margin / 4, (moved, model.recheck_margin)
+    if not model.fast_ok:
+        assert torch.equal(fast, full)                      # a refused model runs the precise forward for every cell
     srt = ref.sort(dim=1, descending=True).values
     decided = (srt[:, 0] - srt[:, 1]) > 2.0 * err
     assert torch.equal(got.argmax(1)[decided], ref.argmax(1)[decided])

@@ -41,10 +41,17 @@ def _lo_codes_close(l8_p, l8_r, sc_p, m, what):
     fp16 lo, which a fused epilogue (fp32 lo) does not have.  Returns the decoded bytes of the fused producer."""
     got, want = mx.e4m3_decode(l8_p.cpu().numpy()), mx.e4m3_decode(l8_r.cpu().numpy())
     diff = got != want
-    frac = diff.mean()
-    note_err(f"{what}: lo codes differing from the packed-split detour", frac)
-    assert frac < 0.03, frac
     scale_e = np.repeat(2.0 ** (_scales(sc_p, m).astype(np.float64) - 127), 32, axis=1)
+    # The double-rounding argument (one value in 64) holds where the detour's lo is a NORMAL fp16.  Where it is subnormal (|lo| < 2^-14: the
+    # small outputs of a GELU, whose value a.s - 0.5 |x| cancels 8-12 bits) the detour quantises lo to 2^-24 and a fused epilogue does not:
+    # since round 6 the GELU's last step is ONE fused multiply-add (ribca_common.h gelu_erf1; the packed form of rounds 2-5 rounded the
+    # product first, so its small outputs were multiples of 2^-24 themselves and the two producers agreed by accident of that coarser
+    # arithmetic) -- there only the absolute bound below applies.
+    normal = np.abs(want * scale_e) >= 2.0 ** -14
+    frac = diff[normal].mean() if normal.any() else 0.0
+    note_err(f"{what}: lo codes differing from the packed-split detour (normal-fp16 lo; {diff[~normal].mean() if (~normal).any() else 0.0:.3f} of the "
+             f"{(~normal).mean():.3f} subnormal-lo values differ)", frac)
+    assert frac < 0.03, frac
     step = np.maximum(np.abs(want), 2.0 ** -6) * 2.0 ** -3
     assert np.all((np.abs(got - want) * scale_e)[diff] <= (step * scale_e)[diff] * 1.01 + 2.0 ** -24)
     return got

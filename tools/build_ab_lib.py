@@ -31,17 +31,19 @@ try:
         subprocess.run(["patch", "-p1", "-d", tmp, "-i", os.path.abspath(os.environ["RIBCA_AB_PATCH"])], check=True)
     csrc = os.path.join(tmp, "multiplexed-image-annotator_amd", "csrc")
     srcs = [s for s in B.SOURCES + B.TEST_SOURCES if os.path.exists(os.path.join(csrc, s))]
+    # revisions older than round 6 export their C++ launchers to the hook library and carry no visibility pragmas in their headers: default
+    # visibility, no version script, no --no-undefined for those
+    hidden = os.path.exists(os.path.join(csrc, "ribca_internal.h"))
+    flags = B.FLAGS if hidden else [f for f in B.FLAGS if not f.startswith("-fvisibility")]
 
     def cc(src):
         obj = os.path.join(tmp, src.replace(".hip", ".o"))
-        subprocess.run([B._hipcc()] + B.FLAGS + extra + ["-c", os.path.join(csrc, src), "-o", obj], check=True, capture_output=True)
+        subprocess.run([B._hipcc()] + flags + extra + ["-c", os.path.join(csrc, src), "-o", obj], check=True, capture_output=True)
         return obj
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
         objs = dict(zip(srcs, ex.map(cc, srcs)))
     lib = os.path.join(B.HERE, f"libribca_ab_{name}.so")
-    # revisions older than round 6 export their C++ launchers to the hook library: no version script, no --no-undefined for those
-    hidden = os.path.exists(os.path.join(csrc, "ribca_internal.h"))
     vs = ["-Wl,--version-script=" + B.EXPORTS] if hidden else []
     subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-soname," + os.path.basename(lib)] + vs + ["-o", lib]
                    + [objs[s] for s in srcs if s not in B.TEST_SOURCES], check=True)
