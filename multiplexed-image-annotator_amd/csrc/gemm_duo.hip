@@ -357,6 +357,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
     if (S < nkz) issue_a(S, S);
   });
   if (NT > 0 && last_issue < 0) touch();
+#ifdef RIBCA_KLOOP_PRIO      // A/B (tools/build_ab_lib.py ... -DRIBCA_KLOOP_PRIO): the K loop's waves ahead of the co-resident workgroup's epilogue waves at issue
+  __builtin_amdgcn_s_setprio(2);
+#endif
   int kk = 0;
   for (; kk + PERIOD <= nk; kk += PERIOD)
     static_for<PERIOD>([&](auto p_c) {
@@ -367,6 +370,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_ps_duo_kernel(const uint
     constexpr int P = decltype(p_c)::value;
     if (kk + P < nk) step(std::integral_constant<int, P % NST>{}, std::integral_constant<int, P % NWS>{}, kk + P);
   });
+#ifdef RIBCA_KLOOP_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
 
   if constexpr (ZK) {
     // ---- the residual tile: K step t holds columns n0 + 32 t .. + 31 of the stored rows; against the identity, the column tile whose

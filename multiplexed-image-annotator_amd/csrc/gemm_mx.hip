@@ -638,8 +638,14 @@ MxAct A, const uint16_t* __restrict__ WH, const unsigned char* __restrict__ WX, 
     MX_STAMP(st_mx)
   };
 
+#ifdef RIBCA_KLOOP_PRIO      // A/B: see gemm_duo.hip
+  __builtin_amdgcn_s_setprio(2);
+#endif
   for (int b = 0; b + 1 < nb; ++b) step(std::true_type{}, b);
   step(std::false_type{}, nb - 1);
+#ifdef RIBCA_KLOOP_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
 
   // the lane's position again, from the hardware: r16 / g of the prologue then end with the address registers formed from them instead of
   // occupying registers (or scratch) across the K loop for the epilogue's sake

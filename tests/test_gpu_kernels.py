@@ -527,7 +527,7 @@ def test_vit_forward_heavy_tailed_weights(dev, name):
     weights, LayerNorm gains over two decades, four residual channels 50 x the rest (an |x| >> its neighbours inside the 32-wide MX blocks
     of both operands).  What must hold: confidences within the north-star 1e-3 of the fp32 oracle; labels identical wherever the
     reference's own top-2 margin exceeds twice the measured error; the full-precision forward in the fp32 reference's own class of error;
-    and the premise of the margin-gated re-evaluation, |fast - full precision| <= RECHECK_MARGIN / 4, for the forward the model really
+    and the premise of the margin-gated re-evaluation, |fast - full precision| <= RECHECK_MARGIN / 2.5, for the forward the model really
     uses -- a model whose load-time probe refuses its weights (ops.VitModel._calibrate_margin) runs every product at three fp16 passes, and
     the raw MX forward it was protected from is measured beside it (force_fast)."""
     from oracle import ref_vit
@@ -556,7 +556,7 @@ def test_vit_forward_heavy_tailed_weights(dev, name):
              f"MX {'in use' if model.uses_mx else 'refused' if (4 * d) % 128 == 0 else 'n/a'}; |raw MX - full| {moved_raw:.1e})", err)
     assert err < 1e-3, err                                  # north star
     assert err_full < max(1e-4, 6.0 * err32), (err_full, err32)      # three fp16 passes: the fp32 reference's own class of error
-    assert moved <= model.recheck_margin / 4, (moved, model.recheck_margin)
+    assert moved <= model.recheck_margin / 2.5, (moved, model.recheck_margin)
     if not model.fast_ok:
         assert torch.equal(fast, full)                      # a refused model runs the precise forward for every cell
     srt = ref.sort(dim=1, descending=True).values
