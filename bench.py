@@ -207,6 +207,7 @@ def main():
     vote_pair = ("immune_full", "struct") if "immune_full" in models and "struct" in models else (next(iter(models)), None)
 
     ag_events, ag_state = [], {}
+    norm_shard = os.environ.get("RIBCA_NORM_SHARD") == "1"      # cell-sharded runs only; default: every rank normalises the whole tile
 
     # as Annotator.predict does: cells whose fast (MX) result lies within 1e-3 of a decision boundary (top-2 margin, the vote's confidence
     # threshold) are re-evaluated with three fp16 passes per product INSIDE the timed region
@@ -234,7 +235,14 @@ def main():
             return _S()
 
         with stage("normalise"):
-            image = ops.normalize_image(raw, blur=0.3, amax=99.8, u16_bits=True)
+            if sharded and norm_shard:
+                # channel-sharded form (Annotator: RIBCA_NORM_SHARD=1): this rank's ceil(C / world) channels, one all-gather of the fp32 planes
+                c0, c1 = dist.shard_bounds(raw.shape[0], rank, world)
+                local = (ops.normalize_image(raw[c0:c1], blur=0.3, amax=99.8, u16_bits=True) if c1 > c0
+                         else torch.empty((0,) + tuple(raw.shape[1:]), dtype=torch.float32, device=dev))
+                image = dist.all_gather_planes(local, raw.shape[0])
+            else:
+                image = ops.normalize_image(raw, blur=0.3, amax=99.8, u16_bits=True)
         with stage("label_table"):
             # ids and boxes stay on the device: the crop reads them there (only the label range and the cell count cross PCIe)
             ids_all, bb_all = ops.label_table_device(mask)
@@ -356,6 +364,8 @@ def main():
                    "precision": "fp16 hi+lo split operands, fp32 accumulate: 3 fp16 MFMA passes per product, or (mlp.fc2 where 4 D % 128 == 0; attn.qkv as a GEMM "
                                 "of its own and mlp.fc1 where D % 192 == 0) fp16 hi*hi + two block-scaled fp8/fp6 corrections = 1.75 matrix units per 128 k "
                                 "(matrix_units_per_product: issued units per algorithmic product, K padding included)",
+                   "normalise": ("channel-sharded + all-gather of the planes (RIBCA_NORM_SHARD=1)" if (world > 1 and not args.impute and os.environ.get("RIBCA_NORM_SHARD") == "1")
+                                 else "replicated on every rank" if world > 1 and not args.impute else "single rank"),
                    "parallelism": ("single GPU" if world == 1 else f"one tile per rank x {world} (replicas only)" if args.impute
                                    else f"cells sharded over {world} rank(s), one all-gather of per-cell probabilities")},
         "vit_gflop_per_cell": round(flops_cell / 1e9, 4),

@@ -100,6 +100,78 @@ def test_mx_pack_act(dev, m, k):
     assert np.abs(q).max() <= 256.0      # the scale rule keeps lo / scale away from the e4m3 maximum (the conversion does not saturate)
 
 
+def test_mx_pack_act_outlier_blocks(dev):
+    """32-column blocks with ONE element 2^12 above the rest (a massive-activation channel of a trained ViT): the block's
+    scale follows the outlier, so the small elements' lo sits 2^12 lower under the shared E8M0 scale -- still inside e4m3's subnormal range
+    (lo / scale >= 2^-9), never flushed.  Planes bit for bit against the emulation; the small elements' MX3 value keeps >= 11 + 3 bits."""
+    from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
+    m, k = 96, 1152
+    x = rnd((m, k), 171, dev) * 0.02
+    cols = torch.arange(5, k, 32, device=dev)                      # one outlier per 32-column block
+    x[:, cols] = x[:, cols] * 4096.0
+    x[7, :] = x[7, :] * 1e-3                                        # a row whose small elements are fp16-subnormal in hi as well
+    a_ps = ps_encode(x, k)
+    hi_p, l8_p, sc_p = _planes(m, k, dev)
+    check(lib().ribca_test_mx_pack_act(ptr(a_ps), 2 * k, m, k, ptr(hi_p), ptr(l8_p), ptr(sc_p), stream_ptr()), "mx_pack_act")
+    hi16, lo16 = _ps_halves(a_ps, k)
+    plane, lo_deq, q, sl = mx.pack_act(hi16.copy(), lo16.astype(np.float64))
+    assert np.array_equal(hi_p.cpu().numpy().view(np.float16).view(np.uint16), plane.view(np.uint16))
+    assert np.array_equal(_scales(sc_p, m), sl)
+    assert np.array_equal(mx.e4m3_decode(l8_p.cpu().numpy()), q)
+    # what the format keeps of the SMALL elements of such a block: their lo is rounded on the e4m3 grid of the OUTLIER's scale -- one step of
+    # lo (2^-4 relative) where lo / scale is a normal e4m3, half the subnormal quantum (2^-10 scale = 2^-29 of the outlier) where it is not.
+    # Measured: the smallest elements (|x| ~ 2^-20 of the outlier) keep hi only (relative 2^-11), a typical small one hi + 5 bits of lo.
+    val = hi16.astype(np.float64) + lo_deq
+    exact = hi16.astype(np.float64) + lo16.astype(np.float64)
+    scale = np.repeat(2.0 ** (sl.astype(np.float64) - 127), 32, axis=1)
+    bound = np.maximum(np.abs(lo16.astype(np.float64)) * 2.0 ** -4, scale * 2.0 ** -10)
+    assert np.all(np.abs(val - exact) <= bound * 1.0001)
+    small = np.ones((m, k), bool); small[:, cols.cpu().numpy()] = False; small[7] = False
+    rel = np.abs(val - exact)[small] / np.maximum(np.abs(exact)[small], 1e-30)
+    note_err("mx3 small elements beside a 2^12 outlier: relative error of hi + lo' (max; median %.1e)" % float(np.median(rel)), rel.max())
+    assert rel.max() <= 2.0 ** -11 * 1.001, rel.max()      # never worse than hi alone
+
+
+def test_gemm_mx_resid_outlier_operands(dev):
+    """the MX product with massive-activation columns in A (4 columns 50 x the rest, as synth.make_vit_state_dict_heavy's residual channels)
+    and heavy-tailed (Student-t(3)) weights: against the exact product within the scheme's 2^-15 class of sum |a w| -- the small elements of
+    an outlier's block lose their fp6 image (flushed under the block scale), i.e. their two correction terms, which is 2^-11 of THEIR
+    products and nothing beside the outlier's own"""
+    from multiplexed_image_annotator_amd._lib import check, lib, ptr, stream_ptr
+    m, n, k = 515, 576, 2304
+    a = rnd((m, k), 181, dev) * 0.1
+    a[:, [37, 700, 1501, 2222]] *= 50.0
+    num = rnd((n, k), 182, dev)
+    den = torch.sqrt((rnd((n, k), 183, dev) ** 2 + rnd((n, k), 184, dev) ** 2 + rnd((n, k), 185, dev) ** 2) / 3.0).clamp_min(1e-3)
+    w = (num / den) / np.sqrt(3.0) / np.sqrt(k)
+    bias = rnd((n,), 186, dev, 0.1)
+    z0 = rnd((m, n), 187, dev)
+    a_ps, w_ps, z_ps = ps_encode(a, k), ps_encode(w, k, n), ps_encode(z0, n)
+    z0q = ps_decode(z_ps, n)
+    hi_p, l8_p, sc_p = _planes(m, k, dev)
+    wh = torch.zeros(lib().ribca_test_mx_weight_bytes(n, k, 0), dtype=torch.uint8, device=dev)
+    wx = torch.zeros(lib().ribca_test_mx_weight_bytes(n, k, 1), dtype=torch.uint8, device=dev)
+    part = torch.zeros((n // 48, m, 2), dtype=torch.float32, device=dev)
+    rs = torch.zeros((m, 2), dtype=torch.float32, device=dev)
+    check(lib().ribca_test_gemm_mx_resid(ptr(a_ps), 2 * k, ptr(w_ps), 2 * k, m, n, k, ptr(bias), ptr(hi_p), ptr(l8_p), ptr(sc_p), ptr(wh), ptr(wx),
+                                         ptr(z_ps), 2 * n, ptr(part), ptr(rs), None, stream_ptr()), "gemm_mx_resid")
+    got = ps_decode(z_ps, n)
+    a_hi, a_lo = _ps_halves(a_ps, k)
+    w_hi, w_lo = _ps_halves(w_ps, k)
+    _, a_lo_q, _, _ = mx.pack_act(a_hi, a_lo.astype(np.float64))
+    emu = torch.from_numpy(mx.gemm(a_hi, a_lo_q, w_hi[:n], w_lo[:n])).to(dev)
+    scale = 1.0 + (a.double().abs() @ w.double().abs().t())
+    e_emu = ((got - (z0q + emu + bias.double())).abs() / scale).max().item()
+    e_ref = ((got - (z0q + a.double() @ w.double().t() + bias.double())).abs() / scale).max().item()
+    note_err("gemm_mx outlier operands vs emulated operands", e_emu)
+    note_err("gemm_mx outlier operands vs exact product", e_ref)
+    assert e_emu < 2e-6, e_emu
+    # the scheme's worst case (test_gemm_mx_resid): 2^-13 of sum |a w|.  Gaussian operands land at 2-4e-6 (random signs); with Student-t(3)
+    # weights the fp6 image of W hi flushes the small weights of a block that holds a 10-30 sigma one, i.e. drops THEIR A lo x W hi term:
+    # measured 3.9e-5
+    assert e_ref < 2.0 ** -13, e_ref
+
+
 MX_SHAPES = [(1, 576, 2304), (130, 576, 2304), (300, 384, 1536), (257, 288, 1152), (128, 192, 128), (515, 576, 640), (4000, 576, 2304), (9001, 384, 1536)]
 
 
