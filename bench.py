@@ -393,9 +393,11 @@ def main():
     out["cells_re_evaluated_at_full_precision"]["vote_pair (" + " + ".join(k for k in vote_pair if k) + ")"] = recheck_counts.get("vote_pair_cells_re_evaluated")
     out["cells_undecidable"] = recheck_counts.get("vote_pair_cells_within_noise_floor")
     out["recheck_margin"] = ops.VitModel.RECHECK_MARGIN
-    # whether each classifier's weights were accepted for the MX products: |fast - full precision| on a fixed 64-cell probe, measured at load
-    # time, against RECHECK_MARGIN / 10 (a model beyond the bar runs every product at three fp16 passes)
-    out["mx_probe_fast_minus_full"] = {name: m.probe_fast_minus_full for name, m in models.items()}
+    # whether each classifier's weights were accepted for the MX products: the largest move of a logit difference between the fast and the
+    # full-precision forward on a fixed 64-cell probe, measured at load time; predicted worst |dp| = 3 x delta / 4 against RECHECK_MARGIN / 2.5
+    # (a model beyond the bar runs every product at three fp16 passes)
+    out["mx_probe_logit_delta"] = {name: m.probe_logit_delta for name, m in models.items()}
+    out["mx_probe_predicted_worst_dp"] = {name: m.probe_predicted_dp for name, m in models.items()}
     out["mx_fast_path_in_use"] = {name: m.uses_mx for name, m in models.items()}
     out["parity_audit"] = parity_audit_record(out["kernel_source_sha256"])
     if sharded:

@@ -683,7 +683,7 @@ def _config3_parity_audit(family: str, n_cells: int, out_name: str):
         fast = vm._forward(patches, list(range(c)), 1024, 0, 1, precise=False)
         full = vm._forward(patches, list(range(c)), 1024, 0, 1, precise=True)
         fast_vs_full = (fast - full).abs().max().item()
-        assert fast_vs_full <= vm.recheck_margin / 2.5, (name, fast_vs_full, vm.recheck_margin, vm.probe_fast_minus_full)
+        assert fast_vs_full <= vm.recheck_margin / 2.5, (name, fast_vs_full, vm.recheck_margin, vm.probe_logit_delta)
         # the raw MX forward, whatever the load-time probe decided for these weights (what a refused model is protected from), and -- for
         # the heavy family -- the reference's own distance from exact arithmetic on these patches
         raw_mx_vs_full = (vm._forward(patches, list(range(c)), 1024, 0, 1, precise=False, force_fast=True) - full).abs().max().item()
@@ -714,10 +714,10 @@ def _config3_parity_audit(family: str, n_cells: int, out_name: str):
                         "margin_hist": hist, "classes_used": int(len(torch.unique(ref.argmax(1)))), "cells_with_margin_below_1e-2": int((margin < 1e-2).sum()),
                         "cells_re_evaluated_at_full_precision": vm.last_recheck["cells"], "matrix_units_fc2": 1.75 if (4 * d) % 128 == 0 else 3.0,
                         "max_abs_fast_minus_full_precision": fast_vs_full, "recheck_margin": vm.recheck_margin,
-                        "probe_fast_minus_full_precision": vm.probe_fast_minus_full, "weight_family": family, "mx_fast_path_in_use": vm.uses_mx,
+                        "probe_logit_delta": vm.probe_logit_delta, "probe_predicted_worst_dp": vm.probe_predicted_dp, "weight_family": family, "mx_fast_path_in_use": vm.uses_mx,
                         "max_abs_raw_mx_minus_full_precision": raw_mx_vs_full, "fp32_reference_vs_fp64": ref32_vs_fp64,
                         "max_abs_dp_vs_fp64": err_vs_fp64 if heavy else None}
-        print(f"[parity audit, {family} weights] {name}: {n_cells} cells, probe {vm.probe_fast_minus_full:.1e} -> MX {'in use' if vm.uses_mx else 'not in use'} "
+        print(f"[parity audit, {family} weights] {name}: {n_cells} cells, probe delta {vm.probe_logit_delta:.1e} (predicted worst |dp| {vm.probe_predicted_dp:.1e}) -> MX {'in use' if vm.uses_mx else 'not in use'} "
               f"(|raw MX - full| {raw_mx_vs_full:.1e}" + (f", fp32 reference vs fp64 {ref32_vs_fp64:.1e}, this path vs fp64 {err_vs_fp64:.1e}" if heavy else "") + f"), max|dp| {err:.2e}, flips {flips} (undecidable {undecidable}, fp64 sides with this path on "
               f"{ref_wrong}), top-2 margin min {margin.min():.2e} hist {hist}; |fast - full precision| {fast_vs_full:.1e}", file=sys.__stdout__, flush=True)
         # identical labels wherever the reference's own margin exceeds twice the measured confidence error; a handful of ties within

@@ -552,7 +552,7 @@ def test_vit_forward_heavy_tailed_weights(dev, name):
     got = model.predict_proba(x.to(dev), src, chunk_cells=16, recheck=[]).cpu()
     err, err_full = (got - ref).abs().max().item(), (full - ref).abs().max().item()
     moved, moved_raw = (fast - full).abs().max().item(), (raw_mx - full).abs().max().item()
-    note_err(f"vit_forward heavy-tailed {name} (fp32 vs fp64 {err32:.1e}; full precision {err_full:.1e}; probe {model.probe_fast_minus_full:.1e} -> "
+    note_err(f"vit_forward heavy-tailed {name} (fp32 vs fp64 {err32:.1e}; full precision {err_full:.1e}; probe delta {model.probe_logit_delta:.1e} (predicted worst |dp| {model.probe_predicted_dp:.1e}) -> "
              f"MX {'in use' if model.uses_mx else 'refused' if (4 * d) % 128 == 0 else 'n/a'}; |raw MX - full| {moved_raw:.1e})", err)
     assert err < 1e-3, err                                  # north star
     assert err_full < max(1e-4, 6.0 * err32), (err_full, err32)      # three fp16 passes: the fp32 reference's own class of error

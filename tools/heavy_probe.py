@@ -29,5 +29,5 @@ for name, (d, c, k) in synth.VIT_CONFIGS.items():
     fast = vm._forward(patches, list(range(c)), 1024, 0, 1, precise=False).cpu().double()
     full = vm._forward(patches, list(range(c)), 1024, 0, 1, precise=True).cpu().double()
     f = lambda a, b: float((a - b).abs().max())
-    print(f"{family} {name}: probe {vm.probe_fast_minus_full:.1e} | fp32 ref vs fp64 {f(p32, p64):.2e} | fast vs fp32 {f(fast, p32):.2e} vs fp64 {f(fast, p64):.2e} | "
+    print(f"{family} {name}: probe delta {vm.probe_logit_delta:.1e} | fp32 ref vs fp64 {f(p32, p64):.2e} | fast vs fp32 {f(fast, p32):.2e} vs fp64 {f(fast, p64):.2e} | "
           f"full vs fp32 {f(full, p32):.2e} vs fp64 {f(full, p64):.2e} | fast vs full {f(fast, full):.2e}", flush=True)
