@@ -530,6 +530,8 @@ class Annotator(object):
             x = tab[:, 5].astype(np.float64) / tab[:, 6].astype(np.float64)      # np.mean(Column), np.mean(Row) of the reference
             y = tab[:, 4].astype(np.float64) / tab[:, 6].astype(np.float64)
             acc = ops.knn_cooccurrence(x, y, self._cell_type_ints(i), t, n_neighbors, out=acc)
+        if acc is None:      # a rank that owns no image of the batch (tile-per-rank mode forced on a batch smaller than the world)
+            return np.zeros((t, t), dtype=np.float64)
         return acc.cpu().numpy().astype(np.float64)
 
     def neighborhood_analysis(self, n_neighbors=25, integrate=True, normalize=True):
@@ -541,8 +543,8 @@ class Annotator(object):
         for g, idx in enumerate(groups):
             m = self.neighborhood_matrix(idx, n_neighbors)
             if integrate and self.tile_mode:
-                # the integrated matrix sums over ALL images of the batch: T x T counts from every rank (cell_types are per rank in this
-                # mode, so the type axes must agree: guaranteed when the ranks see the same label set, checked through the matrix shape)
+                # the integrated matrix sums over ALL images of the batch: T x T counts from every rank (cell_types is the batch-wide union on
+                # every rank, _get_unique_cell_types, so the type axes agree)
                 m = dist.all_reduce_sum(torch.from_numpy(m)).numpy()
             if normalize:
                 sums = m.sum(axis=1, keepdims=True)
