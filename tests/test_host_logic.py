@@ -134,3 +134,34 @@ def test_decision_distance_covers_every_comparison_of_the_vote():
     assert abs(d[3].item() - 0.05) < 1e-6           # .9 against "Others" .95 of the second model
     single = decision_distance(pa, 2, None, None, [0.3, -1])
     assert abs(single[0].item() - 0.2) < 1e-6 and abs(single[2].item() - 0.04) < 1e-6      # cell 2: |.26 - .3|
+
+
+def test_effective_chunk_is_clamped():
+    """the per-width chunk scale (x 4 at D = 576) never pushes a forward beyond MAX_SCALED_CHUNK cells; a caller that asks for
+    more than that itself gets what it asked for, unscaled"""
+    from multiplexed_image_annotator_amd import ops
+
+    class M:      # the two things effective_chunk reads, without a GPU
+        CHUNK_SCALE, MAX_SCALED_CHUNK = ops.VitModel.CHUNK_SCALE, ops.VitModel.MAX_SCALED_CHUNK
+        chunk_scale = ops.VitModel.chunk_scale
+        effective_chunk = ops.VitModel.effective_chunk
+
+        def __init__(self, d):
+            self.D = d
+
+    assert M(576).effective_chunk(1024) == 4096 and M(576).effective_chunk(256) == 1024
+    assert M(576).effective_chunk(2048) == 4096          # 4 x 2048 clamped
+    assert M(576).effective_chunk(8192) == 8192          # the caller's own choice stands
+    assert M(288).effective_chunk(1024) == 1024 and M(384).effective_chunk(4096) == 4096
+    assert M(576).effective_chunk(0) == 4                # (degenerate: at least one cell, scaled)
+
+
+def test_probe_rule_constants_are_consistent():
+    """the load-time probe's acceptance bar in logit units: delta <= RECHECK_MARGIN / PROBE_DIVISOR / (PROBE_FACTOR / 4) = 5.33e-4, and the
+    bench's classifiers (delta 1.7e-4 ... 4.4e-4, profiles/r6/probe_vs_real.txt) sit below it"""
+    from multiplexed_image_annotator_amd import ops
+    v = ops.VitModel
+    bar = v.RECHECK_MARGIN / v.PROBE_DIVISOR / (v.PROBE_FACTOR * 0.25)
+    assert abs(bar - 5.333e-4) < 1e-6
+    assert v.PROBE_FACTOR >= 2.76          # the largest ratio measured (real |dp| over delta / 4)
+    assert 4.41e-4 < bar
