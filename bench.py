@@ -481,6 +481,15 @@ def main():
                               "issued_tflops": round(alg * row["matrix_units"], 1),
                               "vendor_fp16_gemm_tflops": vendor.get(key, {}).get("tflops"),
                               "issued_over_vendor": round(alg * row["matrix_units"] / vendor[key]["tflops"], 3) if key in vendor else None}
+        # one number for the comparison: the shapes the yardstick covers, at the product's time and at the time the SAME matrix units would take
+        # at the vendor's plain-GEMM rate on each shape (no epilogue work counted for the vendor)
+        cov = [v for v in per_shape.values() if v["vendor_fp16_gemm_tflops"]]
+        vendor_summary = None
+        if cov:
+            ours_ms = sum(v["ms_per_pass"] for v in cov)
+            at_vendor_ms = sum(v["ms_per_pass"] * v["issued_over_vendor"] for v in cov)
+            vendor_summary = {"shapes": len(cov), "product_ms_per_pass": round(ours_ms, 1), "same_matrix_units_at_vendor_rate_ms_per_pass": round(at_vendor_ms, 1),
+                              "product_speed_vs_vendor_rate": round(at_vendor_ms / ours_ms, 3)}
         gemm_flops = 0.0
         for name, model in models.items():
             d = model.D
@@ -553,6 +562,7 @@ def main():
                            "algorithmic_bytes_per_launch": round(alg_bytes / max(g_n, 1)),
                            # per GEMM shape: this run's launches beside the vendor library's plain fp16 GEMM of the same shape, timed in this run
                            "per_shape": per_shape,
+                           "vendor_rate_summary": vendor_summary,
                            "per_shape_note": "issued_tflops = algorithmic_tflops x matrix_units_per_product (the work the matrix cores are handed); "
                                              "vendor_fp16_gemm_tflops = torch.matmul (hipBLASLt) in plain fp16, ONE unit per product, same M / K / N, "
                                              "operands rotated, measured in this run outside the product path (tools/vendor_gemm.py); the product kernels also "
