@@ -399,6 +399,9 @@ def main():
     out["mx_probe_logit_delta"] = {name: m.probe_logit_delta for name, m in models.items()}
     out["mx_probe_predicted_worst_dp"] = {name: m.probe_predicted_dp for name, m in models.items()}
     out["mx_fast_path_in_use"] = {name: m.uses_mx for name, m in models.items()}
+    if imputer is not None:      # the imputer's own load-time probe: its imputed plane against the fp16x3 imputer's on 64 probe cells (bar 1e-3)
+        out["imputer_probe_plane_delta"] = imputer.probe_plane_delta
+        out["imputer_fast_path_in_use"] = imputer.fast_ok
     out["parity_audit"] = parity_audit_record(out["kernel_source_sha256"])
     if sharded:
         ag_ms = sum(a.elapsed_time(b) for a, b in ag_events)

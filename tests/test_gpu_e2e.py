@@ -374,6 +374,33 @@ def test_two_ranks_match_single_rank(tmp_path):
     assert a == b and len(a.splitlines()) == len(one.annotations[0]) + 1
 
 
+def test_imputer_load_time_probe():
+    """the re-evaluation of immune_full re-runs the imputer on its fast path (folded blocks, 768-wide encoder on the MX kernel),
+    which has no full-precision form inside one handle.  ops.MaeModel therefore measures, at load time, its imputed plane against a
+    second handle on the fp16x3 path (RIBCA_MAE_FOLD=0) on a fixed 64-cell probe and keeps the fast handle only within 1e-3 (pixel values in
+    [-1, 1]); with RIBCA_MAE_FOLD set the caller has chosen and no probe runs."""
+    from multiplexed_image_annotator_amd import _lib, ops
+    dev = _lib.require_gpu()
+    sd = synth.make_mae_state_dict("immune_base", synth.SEED_BASE + 5)
+    m = ops.MaeModel(sd, dev)
+    print(f"[imputer probe] immune_base panel: fast vs fp16x3 imputed plane on the probe {m.probe_plane_delta:.2e} -> fast path {'kept' if m.fast_ok else 'refused'}",
+          file=sys.__stdout__, flush=True)
+    assert m.fast_ok and 0.0 < m.probe_plane_delta < 5e-4
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand((20, 7, 40, 40), generator=g) * 2 - 1).to(dev)
+    a, b = x.clone(), x.clone()
+    m.impute(a, [0, 1, 2, 4, 5, 6])
+    os.environ["RIBCA_MAE_FOLD"] = "0"
+    try:
+        slow = ops.MaeModel(sd, dev)
+    finally:
+        del os.environ["RIBCA_MAE_FOLD"]
+    assert slow.probe_plane_delta == 0.0          # no probe: the environment chose the path
+    slow.impute(b, [0, 1, 2, 4, 5, 6])
+    assert torch.equal(a[:, [0, 1, 2, 4, 5, 6]], b[:, [0, 1, 2, 4, 5, 6]])      # present planes pass through bit for bit on both
+    assert (a[:, 3] - b[:, 3]).abs().max().item() < 1e-3
+
+
 def _tile_rank_worker(rank, world, port, root, seed):
     """One rank of a tile-per-rank run: a batch CSV of three images over two ranks (both on cuda:0 here; gloo for the control plane)."""
     import torch.distributed as tdist
