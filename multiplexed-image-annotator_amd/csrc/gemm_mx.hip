@@ -290,7 +290,12 @@ __device__ __forceinline__ int mx_f8(int row) { return (row >> 1) & 7; }
 }  // namespace
 
 // ABL (diagnostic library only): 1 = no epilogue (results dropped)
-template <class Epi, int ABL>
+// HALF (round 6; the launcher sets it where N is not a multiple of the 192-column tile: mlp.fc2 at D = 288, whose second column tile holds 96
+// columns): the waves of a tile that lie wholly beyond N -- their accumulators are never stored -- skip their W requests, their fragment
+// reads and their MFMAs, and keep what the workgroup needs from them: their share of the A requests, the hi -> fp6 conversion of their two row
+// tiles, the residual units' requests and every barrier.  A separate instantiation: with HALF = false `dead` is a compile-time false and the
+// code of every other launch is the round-5 kernel's, instruction for instruction.
+template <class Epi, int ABL, bool HALF = false>
 #ifdef MX_BIG
 __global__ __launch_bounds__(256, 1) void gemm_mx_duo_kernel(
 #else
@@ -404,6 +409,10 @@ MxAct A, const uint16_t* __restrict__ WH, const unsigned char* __restrict__ WX, 
 
   // ---- W: the wave's three column tiles; hi fragments stream through three register sets, the fp6 images are single-buffered
   const int wn = wave;
+  // (MX_DEAD folds to a literal false in the front end where HALF is false: those instantiations never see the branch)
+  bool dead_rt = false;
+  if constexpr (HALF && ZK) dead_rt = __builtin_amdgcn_readfirstlane((int)(n0 + wn * (16 * MX_TN) >= epi.N)) != 0;
+#define MX_DEAD (HALF && ZK && dead_rt)
   const unsigned wvoff16 = (unsigned)lane * 16u, wvoff8 = (unsigned)lane * 8u;
   const size_t jb = (size_t)(n0 / 48) + (size_t)wn;
   const char* whb = reinterpret_cast<const char*>(WH) + jb * (size_t)nb * kMxWhBytes;
@@ -451,16 +460,26 @@ MxAct A, const uint16_t* __restrict__ WH, const unsigned char* __restrict__ WX, 
   const unsigned rd_sc = lds_base + L_SC + (unsigned)(r16 * 4 + g);                                        // + 64 i + slot
 
   // ---- prologue
+  if (!MX_DEAD) {
 #ifndef MXDBG_NOW
-  gld8<0>(wsh, wvoff8, uniform_ptr(wxh));
+    gld8<0>(wsh, wvoff8, uniform_ptr(wxh));
 #endif
-  issue_whi(0, whi[0]);
-  issue_whi(1, whi[1]);
-  issue_whi(2, whi[2]);
-  issue_whi(3, whi[3]);
+    issue_whi(0, whi[0]);
+    issue_whi(1, whi[1]);
+    issue_whi(2, whi[2]);
+    issue_whi(3, whi[3]);
+  } else {      // (defined values in the registers the skipped phases would have filled: nothing reads them, the compiler still wants them initialised)
+    wsh = u32v2{0u, 0u}; wsc = u32v2{0u, 0u};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) whi[s4][j] = f16x8{};
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { wl6a[j] = u32v4{0u, 0u, 0u, 0u}; wl6b[j] = u32v2{0u, 0u}; }
+  }
   issue_l8(0);
   issue_hi(0);
-  issue_wx(0);
+  if (!MX_DEAD) issue_wx(0);
 
 #ifdef MXDBG_STAMP      // timing variant (tools/build_mx_variant.py): shader-clock cycles per phase, summed over the K loop, per wave
   unsigned long long st_prev = __builtin_amdgcn_s_memtime(), st_b1 = 0, st_f16 = 0, st_cv = 0, st_b2 = 0, st_mx = 0;
@@ -474,10 +493,13 @@ MxAct A, const uint16_t* __restrict__ WH, const unsigned char* __restrict__ WX, 
   auto step = [&](auto more_c, int b) {
     constexpr bool more = decltype(more_c)::value;
     // B1: hi units, lo / scale unit and the four W hi sets of this step have landed (only the 7 operations of W's fp6 lo image and scale bytes are younger)
-    wait_vmcnt<NWX>();
+    // (a dead wave has no W operation in flight: its youngest operations ARE the hi / lo units, so it waits for all of them)
+    if (MX_DEAD) wait_vmcnt<0>();
+    else wait_vmcnt<NWX>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     MX_STAMP(st_b1)
+    if (!MX_DEAD) {
     // the fp6 image of this step's W hi, from the four resident fragment sets (they are refilled for the next step right behind their last use,
     // so now is the moment); scale byte = the packer's sh of the tile, which travelled with the PREVIOUS block's words (wsh)
 #pragma unroll
@@ -529,6 +551,7 @@ MxAct A, const uint16_t* __restrict__ WH, const unsigned char* __restrict__ WX, 
       if constexpr (more) issue_whi(4 * b + 4 + S, whi[S]);
       __builtin_amdgcn_sched_barrier(0);
     });
+    }
     // the next step's lo and scale units (their slot was last read in the MX phase of step b - 1, which every wave left before B1)
     if constexpr (more) issue_l8(b + 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -580,6 +603,7 @@ MxAct A, const uint16_t* __restrict__ WH, const unsigned char* __restrict__ WX, 
       issue_z(2, L_L8 + ((b + 1) & 1) * L_HALF);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (!MX_DEAD) {
     // ---- MX phase
 #ifndef MXDBG_NOMX
 #pragma unroll
@@ -635,6 +659,7 @@ MxAct A, const uint16_t* __restrict__ WH, const unsigned char* __restrict__ WX, 
     asm volatile("" : "+v"(wsh));
     if constexpr (more) issue_wx(b + 1);
     __builtin_amdgcn_sched_barrier(0);
+    }
     MX_STAMP(st_mx)
   };
 
@@ -787,11 +812,11 @@ MxAct A, const uint16_t* __restrict__ WH, const unsigned char* __restrict__ WX, 
 // ----------------------------------------------------------------------------------------------------------- host side
 bool gemm_mx_supported(int N, int Kp) { return N % 48 == 0 && N % 8 == 0 && Kp % 128 == 0 && Kp >= 128; }
 
-template <class Epi, int ABL>
+template <class Epi, int ABL, bool HALF = false>
 static void launch_mx_impl(const MxAct& A, const MxWeight& W, int M, int N, const Epi& epi, hipStream_t s) {
   const int mtiles = (M + MX_BM - 1) / MX_BM, ntiles = (N + MX_BN - 1) / MX_BN;
   const int nb = A.Kp / 128;
-  void (*kernel)(MxAct, const uint16_t*, const unsigned char*, int, int, int, int, Epi, int) = gemm_mx_duo_kernel<Epi, ABL>;
+  void (*kernel)(MxAct, const uint16_t*, const unsigned char*, int, int, int, int, Epi, int) = gemm_mx_duo_kernel<Epi, ABL, HALF>;
   static unsigned long long attr_done = 0ull;
   if (!ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), L_TOTAL, attr_done)) return;
   // W-panel walk (see the kernel's tile map): RIBCA_MX_PANEL_KB = the most weight image (KB) a panel may hold, applied only where the
@@ -826,7 +851,10 @@ ResidStatGeom launch_gemm_mx_resid(const MxAct& A, const MxWeight& W, int M, int
   if (abl == 1) { launch_mx_impl<EpiResidZK, 1>(A, W, M, N, epi, s); return ResidStatGeom{N / 48, 48}; }
 #endif
   (void)abl;
-  launch_mx_impl<EpiResidZK, 0>(A, W, M, N, epi, s);
+  // RIBCA_MX_HALF=0: the whole-tile kernel for the ragged last column tile as well (A/B; the results are the same bits either way)
+  static const bool half_on = !(getenv("RIBCA_MX_HALF") && atoi(getenv("RIBCA_MX_HALF")) == 0);
+  if (N % MX_BN != 0 && half_on) launch_mx_impl<EpiResidZK, 0, true>(A, W, M, N, epi, s);
+  else launch_mx_impl<EpiResidZK, 0>(A, W, M, N, epi, s);
   return ResidStatGeom{N / 48, 48};
 }
 
